@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ (run in the BUILD container
+only; /root/reference does not exist on the GPU box).
+
+    python tests/golden/make_golden.py
+
+What is produced and from what:
+
+* aasist_modules.npz  -- outputs of the reference's own classes
+  (/root/reference/models/aasist_modules.py loaded by file path): GraphAttention
+  Layer, HtrgGraphAttentionLayer (with and without master), GraphPool,
+  Residual_block, on seeded inputs with the modules' own default init.
+* aasist_backend.npz  -- the reference's XLSR_AASIST.forward
+  (/root/reference/models/xlsr_aasist.py) run end to end with a stub ``fairseq``
+  whose SSL model returns the given (B,T,1024) features; head weights = the
+  seeded synthetic state_dict; stores features, weights, logits, e_S/e_T taps.
+* ssl_tiny.npz        -- a tiny wav2vec2 (2 layers, D=64) from the in-container
+  ``transformers`` implementation, weights renamed to fairseq keys (the third-
+  party stand-in for the absent fairseq).
+* pre_eer.npz         -- pre-emphasis via F.pad(reflect)+F.conv1d exactly as
+  data/preprocess.py:22-25 writes it, EER via the formula of trainer.py:134-139,
+  tile/crop per data/test_set.py:201-227.
+
+Only data (inputs, weights, expected outputs) is written; no reference source.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(ROOT, "real-time-deepfake-speech-detection_amd"))
+from afx import synth  # noqa: E402
+
+
+def _np(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def load_ref_aasist_modules():
+    spec = importlib.util.spec_from_file_location("ref_aasist_modules", f"{REF}/models/aasist_modules.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def gen_modules():
+    m = load_ref_aasist_modules()
+    out = {}
+    torch.manual_seed(7)
+
+    def perturb_bn(mod):
+        for sub in mod.modules():
+            if isinstance(sub, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                sub.running_mean.normal_(0, 0.1)
+                sub.running_var.uniform_(0.5, 1.5)
+                sub.weight.data.normal_(1, 0.1)
+                sub.bias.data.normal_(0, 0.1)
+
+    gat = m.GraphAttentionLayer(64, 64, temperature=2.0).eval()
+    perturb_bn(gat)
+    x = torch.randn(2, 42, 64)
+    with torch.no_grad():
+        y = gat(x)
+    out.update({f"gat.sd.{k}": v for k, v in _np(gat.state_dict()).items()})
+    out["gat.x"], out["gat.y"] = x.numpy(), y.numpy()
+
+    for tag, di, do, n1, n2 in (("h64", 64, 32, 33, 21), ("h32", 32, 32, 16, 10)):
+        h = m.HtrgGraphAttentionLayer(di, do, temperature=100.0).eval()
+        perturb_bn(h)
+        x1, x2, ms = torch.randn(2, n1, di), torch.randn(2, n2, di), torch.randn(1, 1, di)
+        with torch.no_grad():
+            a1, a2, am = h(x1, x2, master=ms)
+            b1, b2, bm = h(x1, x2)
+        out.update({f"{tag}.sd.{k}": v for k, v in _np(h.state_dict()).items()})
+        out[f"{tag}.x1"], out[f"{tag}.x2"], out[f"{tag}.master"] = x1.numpy(), x2.numpy(), ms.numpy()
+        out[f"{tag}.y1"], out[f"{tag}.y2"], out[f"{tag}.ym"] = a1.numpy(), a2.numpy(), am.numpy()
+        out[f"{tag}.n1"], out[f"{tag}.n2"], out[f"{tag}.nm"] = b1.numpy(), b2.numpy(), bm.numpy()
+
+    pool = m.GraphPool(0.5, 64, 0.3).eval()
+    x = torch.randn(3, 42, 64)
+    with torch.no_grad():
+        y = pool(x)
+    out.update({f"pool.sd.{k}": v for k, v in _np(pool.state_dict()).items()})
+    out["pool.x"], out["pool.y"] = x.numpy(), y.numpy()
+
+    for tag, filts, first in (("rb_first", [1, 32], True), ("rb_down", [32, 64], False), ("rb_same", [64, 64], False)):
+        rb = m.Residual_block(nb_filts=filts, first=first).eval()
+        perturb_bn(rb)
+        x = torch.randn(2, filts[0], 12, 20)
+        with torch.no_grad():
+            y = rb(x)
+        out.update({f"{tag}.sd.{k}": v for k, v in _np(rb.state_dict()).items()})
+        out[f"{tag}.x"], out[f"{tag}.y"] = x.numpy(), y.numpy()
+    np.savez_compressed(os.path.join(HERE, "aasist_modules.npz"), **out)
+    print("aasist_modules.npz", len(out), "arrays")
+
+
+class _StubSSL(nn.Module):
+    """Stands in for fairseq's Wav2Vec2Model: returns preset features."""
+    feats = None
+
+    def forward(self, source, mask=False, features_only=True):
+        return {"x": _StubSSL.feats}
+
+
+def gen_backend():
+    fs = types.ModuleType("fairseq")
+    fs.checkpoint_utils = types.SimpleNamespace(
+        load_model_ensemble_and_task=lambda paths: ([_StubSSL()], None, None))
+    sys.modules["fairseq"] = fs
+    sys.path.insert(0, REF)
+    from models.xlsr_aasist import XLSR_AASIST  # the reference's own class
+    sys.path.pop(0)
+    model = XLSR_AASIST(device="cpu").eval()
+    head = synth.aasist_head_state_dict()
+    missing, unexpected = model.load_state_dict(head, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    out = {f"sd.{k}": v.numpy() for k, v in head.items()}
+    taps = {}
+    model.GAT_layer_S.register_forward_hook(lambda mod, i, o: taps.__setitem__("e_S", i[0].detach().clone()))
+    model.GAT_layer_T.register_forward_hook(lambda mod, i, o: taps.__setitem__("e_T", i[0].detach().clone()))
+    model.out_layer.register_forward_hook(lambda mod, i, o: taps.__setitem__("hidden", i[0].detach().clone()))
+    for tag, B, T in (("t199", 2, 199), ("t49", 2, 49), ("t201", 1, 201)):
+        g = torch.Generator().manual_seed(100 + T)
+        feats = torch.randn(B, T, 1024, generator=g)
+        _StubSSL.feats = feats
+        with torch.no_grad():
+            logits = model(torch.zeros(B, 16))
+        out[f"{tag}.feats"] = feats.numpy()
+        out[f"{tag}.logits"] = logits.numpy()
+        for k, v in taps.items():
+            out[f"{tag}.{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "aasist_backend.npz"), **out)
+    print("aasist_backend.npz logits", out["t199.logits"])
+
+
+def gen_ssl_tiny():
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    torch.manual_seed(11)
+    cfg = Wav2Vec2Config(
+        hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+        conv_dim=(32,) * 7, conv_stride=(5, 2, 2, 2, 2, 2, 2), conv_kernel=(10, 3, 3, 3, 3, 2, 2),
+        conv_bias=True, feat_extract_norm="layer", do_stable_layer_norm=True,
+        num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4,
+        hidden_dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, feat_proj_dropout=0.0,
+        layerdrop=0.0, mask_time_prob=0.0, hidden_act="gelu", layer_norm_eps=1e-5)
+    hf = Wav2Vec2Model(cfg).eval()
+    with torch.no_grad():  # make every norm / bias non-trivial
+        for n, p in hf.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.05)
+            elif "layer_norm" in n and n.endswith("weight"):
+                p.normal_(1, 0.1)
+    hsd = hf.state_dict()
+    sd = {}
+    for i in range(7):
+        sd[f"feature_extractor.conv_layers.{i}.0.weight"] = hsd[f"feature_extractor.conv_layers.{i}.conv.weight"]
+        sd[f"feature_extractor.conv_layers.{i}.0.bias"] = hsd[f"feature_extractor.conv_layers.{i}.conv.bias"]
+        sd[f"feature_extractor.conv_layers.{i}.2.1.weight"] = hsd[f"feature_extractor.conv_layers.{i}.layer_norm.weight"]
+        sd[f"feature_extractor.conv_layers.{i}.2.1.bias"] = hsd[f"feature_extractor.conv_layers.{i}.layer_norm.bias"]
+    sd["layer_norm.weight"] = hsd["feature_projection.layer_norm.weight"]
+    sd["layer_norm.bias"] = hsd["feature_projection.layer_norm.bias"]
+    sd["post_extract_proj.weight"] = hsd["feature_projection.projection.weight"]
+    sd["post_extract_proj.bias"] = hsd["feature_projection.projection.bias"]
+    pc = "encoder.pos_conv_embed.conv."
+    sd["encoder.pos_conv.0.weight_g"] = hsd[pc + "parametrizations.weight.original0"]
+    sd["encoder.pos_conv.0.weight_v"] = hsd[pc + "parametrizations.weight.original1"]
+    sd["encoder.pos_conv.0.bias"] = hsd[pc + "bias"]
+    for n in range(2):
+        a, b = f"encoder.layers.{n}.", f"encoder.layers.{n}."
+        for pj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[a + f"self_attn.{pj}.weight"] = hsd[b + f"attention.{pj}.weight"]
+            sd[a + f"self_attn.{pj}.bias"] = hsd[b + f"attention.{pj}.bias"]
+        sd[a + "self_attn_layer_norm.weight"] = hsd[b + "layer_norm.weight"]
+        sd[a + "self_attn_layer_norm.bias"] = hsd[b + "layer_norm.bias"]
+        sd[a + "fc1.weight"] = hsd[b + "feed_forward.intermediate_dense.weight"]
+        sd[a + "fc1.bias"] = hsd[b + "feed_forward.intermediate_dense.bias"]
+        sd[a + "fc2.weight"] = hsd[b + "feed_forward.output_dense.weight"]
+        sd[a + "fc2.bias"] = hsd[b + "feed_forward.output_dense.bias"]
+        sd[a + "final_layer_norm.weight"] = hsd[b + "final_layer_norm.weight"]
+        sd[a + "final_layer_norm.bias"] = hsd[b + "final_layer_norm.bias"]
+    sd["encoder.layer_norm.weight"] = hsd["encoder.layer_norm.weight"]
+    sd["encoder.layer_norm.bias"] = hsd["encoder.layer_norm.bias"]
+    wave = torch.randn(2, 4000) * 0.1
+    with torch.no_grad():
+        y = hf(wave).last_hidden_state
+        conv = hf.feature_extractor(wave).transpose(1, 2)
+    out = {f"sd.{k}": v.detach().numpy() for k, v in sd.items()}
+    out["wave"], out["y"], out["conv"] = wave.numpy(), y.numpy(), conv.numpy()
+    np.savez_compressed(os.path.join(HERE, "ssl_tiny.npz"), **out)
+    print("ssl_tiny.npz y", tuple(y.shape))
+
+
+def gen_pre_eer():
+    from scipy.interpolate import interp1d
+    from scipy.optimize import brentq
+    from sklearn import metrics
+    torch.manual_seed(3)
+    x = torch.randn(3, 257)
+    filt = torch.FloatTensor([[[-0.97, 1.0]]])
+    y = F.conv1d(F.pad(x.unsqueeze(1), (1, 0), mode="reflect"), filt).squeeze(1)
+    rng = np.random.RandomState(5)
+    labels = (rng.rand(600) > 0.7).astype(np.int64)
+    scores = (rng.randn(600) + labels * 1.2).astype(np.float32)
+    fpr, tpr, _ = metrics.roc_curve(labels, scores, pos_label=1)
+    eer = brentq(lambda t: 1.0 - t - interp1d(fpr, tpr)(t), 0.0, 1.0) * 100
+    short = torch.arange(1, 8, dtype=torch.float32)  # 7 samples tiled to 24
+    tiled = torch.cat([short] * (24 // 7) + [short[: 24 % 7]])[:24]
+    np.savez_compressed(os.path.join(HERE, "pre_eer.npz"), x=x.numpy(), y=y.numpy(), labels=labels,
+                        scores=scores, eer=np.float64(eer), short=short.numpy(), tiled=tiled.numpy())
+    print("pre_eer.npz eer", eer)
+
+
+if __name__ == "__main__":
+    gen_modules()
+    gen_backend()
+    gen_ssl_tiny()
+    gen_pre_eer()

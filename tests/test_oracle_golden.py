@@ -1,0 +1,115 @@
+"""Pin the CPU oracle against the golden vectors (CPU only).
+
+aasist_*: produced by the reference's own code; ssl_tiny: by the in-container
+transformers wav2vec2 (stand-in for the absent fairseq); pre_eer: formula
+known-answers.  See tests/golden/make_golden.py.
+"""
+import numpy as np
+import torch
+
+from conftest import load_golden, sub_sd
+from oracle import aasist, pre, ssl_trunk
+
+TOL = dict(rtol=1e-4, atol=2e-5)
+
+
+def _t(a):
+    return torch.from_numpy(a)
+
+
+def test_graph_attention_layer_matches_reference():
+    z = load_golden("aasist_modules.npz")
+    y = aasist.graph_attention(sub_sd(z, "gat."), "", _t(z["gat.x"]), 2.0)
+    np.testing.assert_allclose(y.numpy(), z["gat.y"], **TOL)
+
+
+def test_htrg_layer_matches_reference_with_and_without_master():
+    z = load_golden("aasist_modules.npz")
+    for tag in ("h64", "h32"):
+        sd = sub_sd(z, tag + ".")
+        y1, y2, ym = aasist.htrg_graph_attention(sd, "", _t(z[tag + ".x1"]), _t(z[tag + ".x2"]), _t(z[tag + ".master"]), 100.0)
+        np.testing.assert_allclose(y1.numpy(), z[tag + ".y1"], **TOL)
+        np.testing.assert_allclose(y2.numpy(), z[tag + ".y2"], **TOL)
+        np.testing.assert_allclose(ym.numpy(), z[tag + ".ym"], **TOL)
+        n1, n2, nm = aasist.htrg_graph_attention(sd, "", _t(z[tag + ".x1"]), _t(z[tag + ".x2"]), None, 100.0)
+        np.testing.assert_allclose(n1.numpy(), z[tag + ".n1"], **TOL)
+        np.testing.assert_allclose(n2.numpy(), z[tag + ".n2"], **TOL)
+        np.testing.assert_allclose(nm.numpy(), z[tag + ".nm"], **TOL)
+
+
+def test_graph_pool_matches_reference_order_and_values():
+    z = load_golden("aasist_modules.npz")
+    y = aasist.graph_pool(sub_sd(z, "pool."), "", _t(z["pool.x"]), 0.5)
+    assert y.shape == (3, 21, 64)
+    np.testing.assert_allclose(y.numpy(), z["pool.y"], **TOL)
+
+
+def test_residual_block_matches_reference_including_dead_bn1():
+    z = load_golden("aasist_modules.npz")
+    for tag, first in (("rb_first", True), ("rb_down", False), ("rb_same", False)):
+        y = aasist.residual_block(sub_sd(z, tag + "."), "", _t(z[tag + ".x"]), first)
+        np.testing.assert_allclose(y.numpy(), z[tag + ".y"], **TOL)
+
+
+def test_backend_end_to_end_matches_reference_forward():
+    z = load_golden("aasist_backend.npz")
+    sd = sub_sd(z, "")
+    for tag in ("t199", "t49", "t201"):
+        taps = {}
+        logits = aasist.aasist_backend(sd, _t(z[tag + ".feats"]), taps)
+        np.testing.assert_allclose(taps["e_S"].numpy(), z[tag + ".e_S"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(taps["e_T"].numpy(), z[tag + ".e_T"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(taps["hidden"].numpy(), z[tag + ".hidden"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(logits.numpy(), z[tag + ".logits"], rtol=1e-4, atol=1e-4)
+
+
+def test_ssl_trunk_matches_transformers_wav2vec2():
+    z = load_golden("ssl_tiny.npz")
+    sd = sub_sd(z, "")
+    layers = [(32, 10, 5)] + [(32, 3, 2)] * 4 + [(32, 2, 2)] * 2
+    conv = ssl_trunk.feature_extractor(sd, _t(z["wave"]), layers=layers)
+    np.testing.assert_allclose(conv.numpy(), z["conv"], rtol=1e-4, atol=1e-5)
+    y = ssl_trunk.ssl_forward(sd, _t(z["wave"]), heads=4, layers=layers, groups=4)
+    np.testing.assert_allclose(y.numpy(), z["y"], rtol=1e-4, atol=2e-5)
+    y3 = ssl_trunk.ssl_forward(sd, _t(z["wave"]).unsqueeze(-1), heads=4, layers=layers, groups=4)
+    assert torch.equal(y, y3)  # (B,L,1) inputs use channel 0 (models/fe.py:18)
+
+
+def test_conv_lengths_for_baseline_clips():
+    assert ssl_trunk.conv_out_lengths(64000)[-1] == 199
+    assert ssl_trunk.conv_out_lengths(64000) == [12799, 6399, 3199, 1599, 799, 399, 199]
+    assert ssl_trunk.conv_out_lengths(16000)[-1] == 49
+    assert ssl_trunk.conv_out_lengths(64600)[-1] == 201
+    assert ssl_trunk.conv_out_lengths(4000)[-1] == 12
+
+
+def test_select_layers_policies_and_errors():
+    import pytest
+    sd = {f"encoder.layers.{i}.fc1.weight": torch.full((1,), float(i)) for i in range(24)}
+    sd["encoder.layer_norm.weight"] = torch.ones(1)
+    first = ssl_trunk.select_layers(sd, 6, "first")
+    assert [first[f"encoder.layers.{i}.fc1.weight"].item() for i in range(6)] == [0, 1, 2, 3, 4, 5]
+    assert ssl_trunk.num_layers(first) == 6
+    last = ssl_trunk.select_layers(sd, 3, "last")
+    assert [last[f"encoder.layers.{i}.fc1.weight"].item() for i in range(3)] == [21, 22, 23]
+    mid = ssl_trunk.select_layers(sd, 4, "middle")
+    assert [mid[f"encoder.layers.{i}.fc1.weight"].item() for i in range(4)] == [10, 11, 12, 13]
+    cus = ssl_trunk.select_layers(sd, 2, "custom", [5, 1])
+    assert [cus[f"encoder.layers.{i}.fc1.weight"].item() for i in range(2)] == [5, 1]
+    for bad in (0, 25):
+        with pytest.raises(ValueError):
+            ssl_trunk.select_layers(sd, bad, "first")
+    with pytest.raises(ValueError):
+        ssl_trunk.select_layers(sd, 2, "custom", None)
+    with pytest.raises(ValueError):
+        ssl_trunk.select_layers(sd, 2, "custom", (1, 2))
+
+
+def test_pre_emphasis_eer_and_tiling_known_answers():
+    z = load_golden("pre_eer.npz")
+    y = pre.pre_emphasis(_t(z["x"]))
+    np.testing.assert_allclose(y.numpy(), z["y"], rtol=1e-6, atol=1e-6)
+    assert abs(pre.eer_percent(z["scores"], z["labels"]) - float(z["eer"])) < 1e-9
+    np.testing.assert_array_equal(pre.adjust_duration(_t(z["short"]), 24).numpy(), z["tiled"])
+    assert pre.adjust_duration(torch.arange(100.0), 24).shape[0] == 24
+    assert pre.pad_tile(np.arange(10.0), 25).shape[0] == 25
