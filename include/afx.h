@@ -1,0 +1,112 @@
+/*
+ * afx.h -- C ABI of libafx.so, the MI355X (gfx950) native anti-spoof inference path.
+ *
+ * This is the drop-in boundary for the reference's model forward
+ *   waveform (B,L) fp32  ->  logits (B,2) fp32   (index 1 = bonafide score)
+ * i.e. what the reference obtains from `model(batch_x)` at main.py:210 and
+ * trainer.py:106, for the model families of models/xlsr_aasist.py:5-177,
+ * models/conformer_baseline.py:31-99 and the bare SSL extractor of
+ * models/fe.py:8-40,53-99 / models/models.py:13-41.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer that is documented "device" is a
+ *     HIP device pointer on the current device; `stream` is a hipStream_t passed as
+ *     void* (NULL = the default stream).  Calls are asynchronous on that stream.
+ *   - every function returns 0 on success, non-zero on error; afx_last_error() gives
+ *     a thread-local message (mirrors the Python exceptions of the reference:
+ *     ValueError text for bad layer counts etc.).
+ *   - the caller owns inputs, outputs and the workspace; the handle owns only the
+ *     packed weights.  A handle is re-entrant across streams as long as each
+ *     concurrent call has its own workspace.
+ *
+ * The Python host side (real-time-deepfake-speech-detection_amd/afx/_lib.py) binds
+ * exactly these symbols with ctypes; INTEGRATION.md shows the stub.
+ */
+#ifndef AFX_H_
+#define AFX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct afx_engine* afx_handle;
+
+enum { AFX_ARCH_SSL = 0, AFX_ARCH_XLSR_AASIST = 1, AFX_ARCH_CONFORMER = 2 };
+enum { AFX_DT_BF16 = 0, AFX_DT_FP16 = 1 }; /* matrix-core operand type; accumulation is always fp32 */
+
+typedef struct afx_config {
+  int arch;          /* AFX_ARCH_* */
+  int dtype;         /* AFX_DT_* */
+  int n_layers;      /* transformer layers in the SSL trunk, 1..24 (models/fe.py:60-62) */
+  int conf_emb;      /* Conformer: emb_size   (models/conformer_baseline.py:38) */
+  int conf_heads;    /*            heads      (:39) */
+  int conf_kernel;   /*            kernel_size(:40) */
+  int conf_blocks;   /*            n_encoders (:41) */
+  int pre_emphasis;  /* 1: apply data/preprocess.py:16-29 inside the first kernel */
+  float pre_emphasis_coef;
+} afx_config;
+
+/* ---- lifecycle ---------------------------------------------------------------- */
+int afx_create(const afx_config* cfg, afx_handle* out);
+void afx_destroy(afx_handle h);
+const char* afx_last_error(void);
+const char* afx_version(void);
+
+/* ---- weights: reference checkpoint key names, without
+ * the optional "module." prefix (utils.py:13-43).  `dev_ptr` is a contiguous fp32
+ * device tensor; it is copied / repacked, the caller may free it afterwards.
+ * Unknown-but-harmless keys (quantizer.*, project_q.*, final_proj.*, mask_emb,
+ * *.bn1.*, num_batches_tracked) return 0 and are ignored. ------------------------- */
+int afx_load_weight(afx_handle h, const char* name, const float* dev_ptr, const int64_t* shape, int ndim,
+                    void* stream);
+/* fold BatchNorms / weight-norm, check that every required tensor arrived */
+int afx_finalize(afx_handle h, void* stream);
+
+/* ---- forward ------------------------------------------------------------------ */
+int afx_num_frames(int n_samples);                       /* T after the 7 conv layers */
+size_t afx_workspace_bytes(afx_handle h, int B, int L);  /* scratch needed by one call */
+/* wave: device (B,L) fp32.  logits: device (B,2) fp32. */
+int afx_forward(afx_handle h, const float* wave, int B, int L, float* logits, void* ws, size_t ws_bytes,
+                void* stream);
+/* SSL features only: feats device (B,T,1024) fp32 == extract_feat() of models/fe.py:17-21 */
+int afx_ssl_forward(afx_handle h, const float* wave, int B, int L, float* feats, void* ws, size_t ws_bytes,
+                    void* stream);
+/* back-end alone from given SSL features (B,T,1024) fp32 -> logits (B,2) */
+int afx_head_forward(afx_handle h, const float* feats, int B, int T, float* logits, void* ws, size_t ws_bytes,
+                     void* stream);
+size_t afx_head_workspace_bytes(afx_handle h, int B, int T);
+/* debug taps (off by default; when on, forward keeps fp32 copies of intermediates) */
+int afx_enable_taps(afx_handle h, int on);
+/* debug taps: copy an intermediate of the LAST forward on this workspace into `out`
+ * (device fp32).  Names: "conv", "proj", "pos", "layer<N>", "ssl", "tokens",
+ * "block<N>", "e_S", "e_T", "hidden".  Returns the element count through n_out. */
+int afx_tap(afx_handle h, const char* name, float* out, size_t cap_elems, size_t* n_out, void* stream);
+
+/* ---- single-kernel entry points (unit parity tests; operand pointers are bf16 or
+ * fp16 device arrays according to `dtype`) ---------------------------------------- */
+int afx_k_gemm(int dtype, const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
+               int act, float alpha, const float* resid, long ldr, float* out_f, long ldo_f, void* out_h, long ldo_h,
+               void* stream);
+/* Conv1d(Cin->N, k, stride s) on channel-last input (B,Tin,Cin) as one GEMM; Wp is
+ * the tap-major packed weight [N][k*Cin]; out_f (B,Tout,N) fp32 */
+int afx_k_conv_gemm(int dtype, const void* in_h, const void* Wp, int B, int Tin, int Tout, int Cin, int k, int s,
+                    int N, const float* bias, float* out_f, void* stream);
+int afx_k_pack_linear(int dtype, const float* w, int N, int K, int Kpad, void* out_h, void* stream);
+int afx_k_pack_conv(int dtype, const float* w, int N, int Cin, int k, void* out_h, void* stream);
+int afx_k_conv0(int dtype, const float* wave, int B, int L, const float* w, const float* bias, const float* gamma,
+                const float* beta, int pre_emph, float coef, void* out_h, void* stream);
+int afx_k_rownorm(int dtype, const float* x, long ldx, int rows, int C, const float* gamma, const float* beta,
+                  float eps, int act, float* out_f, long ldo_f, void* out_h, long ldo_h, void* stream);
+int afx_k_mhsa(int dtype, const void* qkv, void* out, int B, int T, int H, void* stream);
+int afx_k_conf_attn(int dtype, const float* q, long ldq, const float* kv, long ldkv, const float* rel, int max_pos,
+                    int B, int N, int H, int dh, void* out_h, long ldo, void* stream);
+int afx_k_conf_dwconv(int dtype, const float* x, long ldx, const float* w, const float* bias, const float* bn_scale,
+                      const float* bn_shift, int B, int N, int C, int k, void* out_h, long ldo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFX_H_ */

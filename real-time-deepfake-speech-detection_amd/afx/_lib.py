@@ -1,0 +1,87 @@
+"""ctypes binding of libafx.so (the C ABI declared in include/afx.h).
+
+There is deliberately no fallback: if the shared library is missing, or it
+reports an error, the call raises.  Build it with ``__graft_entry__.build()``
+or ``make -C real-time-deepfake-speech-detection_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libafx.so")
+
+ARCH_SSL, ARCH_XLSR_AASIST, ARCH_CONFORMER = 0, 1, 2
+DT_BF16, DT_FP16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_SWISH, ACT_SELU = 0, 1, 2, 3
+
+
+class AfxError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("arch", C.c_int), ("dtype", C.c_int), ("n_layers", C.c_int),
+                ("conf_emb", C.c_int), ("conf_heads", C.c_int), ("conf_kernel", C.c_int),
+                ("conf_blocks", C.c_int), ("pre_emphasis", C.c_int), ("pre_emphasis_coef", C.c_float)]
+
+
+_P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+
+# symbol -> (restype, argtypes); must list every function include/afx.h declares
+SIGNATURES = {
+    "afx_create": (_I, [C.POINTER(Config), C.POINTER(_P)]),
+    "afx_destroy": (None, [_P]),
+    "afx_last_error": (C.c_char_p, []),
+    "afx_version": (C.c_char_p, []),
+    "afx_load_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I, _P]),
+    "afx_finalize": (_I, [_P, _P]),
+    "afx_num_frames": (_I, [_I]),
+    "afx_workspace_bytes": (_Z, [_P, _I, _I]),
+    "afx_head_workspace_bytes": (_Z, [_P, _I, _I]),
+    "afx_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
+    "afx_ssl_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
+    "afx_head_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
+    "afx_enable_taps": (_I, [_P, _I]),
+    "afx_tap": (_I, [_P, C.c_char_p, _P, _Z, C.POINTER(_Z), _P]),
+    "afx_k_gemm": (_I, [_I, _P, _L, _P, _L, _I, _I, _I, _P, _I, _F, _P, _L, _P, _L, _P, _L, _P]),
+    "afx_k_conv_gemm": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "afx_k_pack_linear": (_I, [_I, _P, _I, _I, _I, _P, _P]),
+    "afx_k_pack_conv": (_I, [_I, _P, _I, _I, _I, _P, _P]),
+    "afx_k_conv0": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
+    "afx_k_rownorm": (_I, [_I, _P, _L, _I, _I, _P, _P, _F, _I, _P, _L, _P, _L, _P]),
+    "afx_k_mhsa": (_I, [_I, _P, _P, _I, _I, _I, _P]),
+    "afx_k_conf_attn": (_I, [_I, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "afx_k_conf_dwconv": (_I, [_I, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises AfxError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AfxError(f"{LIB_PATH} is missing: the HIP library has not been built "
+                           "(run __graft_entry__.build()); there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AfxError(lib().afx_last_error().decode())
+
+
+def ptr(t):
+    """Device/host address of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,116 @@
+"""Host-side handle on the native engine: owns an afx_handle, feeds it weights by
+their reference checkpoint names and runs forwards on the current HIP stream.
+PyTorch is used for device memory and streams only."""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib
+from ._lib import AfxError, Config, check, lib, ptr, stream_ptr
+
+ARCHS = {"ssl": _lib.ARCH_SSL, "xlsr_aasist": _lib.ARCH_XLSR_AASIST, "conformer": _lib.ARCH_CONFORMER}
+DTYPES = {"bf16": _lib.DT_BF16, "fp16": _lib.DT_FP16}
+# fp16 and bf16 run at the same matrix-core rate on gfx950; fp16's 3 extra mantissa bits
+# are what keeps the scores within 1e-3 of the fp32 reference (DESIGN.md "Numerics").
+DEFAULT_DTYPE = os.environ.get("AFX_DTYPE", "fp16")
+
+
+def torch_dtype(name):
+    return torch.bfloat16 if name == "bf16" else torch.float16
+
+
+class Engine:
+    def __init__(self, arch, n_layers=24, dtype=None, conf_emb=144, conf_heads=4, conf_kernel=31,
+                 conf_blocks=4, pre_emphasis=False, pre_emphasis_coef=0.97):
+        dtype = dtype or DEFAULT_DTYPE
+        if dtype not in DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(DTYPES)}, got {dtype!r}")
+        if not torch.cuda.is_available():
+            raise AfxError("no HIP device: the MI355X-native path has no CPU fallback")
+        self.arch, self.dtype, self.n_layers = arch, dtype, n_layers
+        cfg = Config(ARCHS[arch], DTYPES[dtype], n_layers, conf_emb, conf_heads, conf_kernel, conf_blocks,
+                     1 if pre_emphasis else 0, pre_emphasis_coef)
+        self._h = C.c_void_p()
+        check(lib().afx_create(C.byref(cfg), C.byref(self._h)))
+        self._ws = None
+        self._taps = False
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            lib().afx_destroy(h)
+            self._h = None
+
+    # ---- weights -------------------------------------------------------------------
+    def load_state_dict(self, sd):
+        """sd: name -> tensor (reference checkpoint names).  Tensors are moved to
+        the device as contiguous fp32 and copied / repacked by the library."""
+        l, s = lib(), stream_ptr()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        for name, t in sd.items():
+            if not torch.is_tensor(t) or not t.dtype.is_floating_point:
+                continue
+            t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            shape = (C.c_int64 * max(t.ndim, 1))(*t.shape)
+            check(l.afx_load_weight(self._h, name.encode(), ptr(t), shape, t.ndim, s))
+        torch.cuda.current_stream().synchronize()  # sources may be freed by the caller
+        check(l.afx_finalize(self._h, s))
+
+    # ---- forward -------------------------------------------------------------------
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        return self._ws
+
+    @staticmethod
+    def _wave(x):
+        if x.ndim == 3:  # (B,L,1): models/fe.py:18 uses channel 0
+            x = x[:, :, 0]
+        if x.ndim != 2:
+            raise ValueError(f"expected a (B,L) or (B,L,1) waveform batch, got shape {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise AfxError("input must live on the GPU (the caller does batch_x.to(device), main.py:209)")
+        return x.to(torch.float32).contiguous()
+
+    def forward(self, wave):
+        x = self._wave(wave)
+        B, L = x.shape
+        l = lib()
+        ws = self._workspace(l.afx_workspace_bytes(self._h, B, L))
+        out = torch.empty(B, 2, dtype=torch.float32, device=x.device)
+        check(l.afx_forward(self._h, ptr(x), B, L, ptr(out), ptr(ws), ws.numel(), stream_ptr()))
+        return out
+
+    def ssl(self, wave):
+        x = self._wave(wave)
+        B, L = x.shape
+        l = lib()
+        T = l.afx_num_frames(L)
+        ws = self._workspace(l.afx_workspace_bytes(self._h, B, L))
+        buf = torch.empty(B, max(T, 1), 1024, dtype=torch.float32, device=x.device)
+        check(l.afx_ssl_forward(self._h, ptr(x), B, L, ptr(buf), ptr(ws), ws.numel(), stream_ptr()))
+        return buf[:, :max(T, 0)]
+
+    def head(self, feats):
+        f = feats.to(torch.float32).contiguous()
+        B, T, D = f.shape
+        if D != 1024:
+            raise ValueError("SSL features must have 1024 channels")
+        l = lib()
+        ws = self._workspace(l.afx_head_workspace_bytes(self._h, B, T))
+        out = torch.empty(B, 2, dtype=torch.float32, device=f.device)
+        check(l.afx_head_forward(self._h, ptr(f), B, T, ptr(out), ptr(ws), ws.numel(), stream_ptr()))
+        return out
+
+    # ---- debug taps ----------------------------------------------------------------
+    def enable_taps(self, on=True):
+        check(lib().afx_enable_taps(self._h, 1 if on else 0))
+
+    def tap(self, name):
+        n = C.c_size_t(0)
+        check(lib().afx_tap(self._h, name.encode(), None, 0, C.byref(n), stream_ptr()))
+        out = torch.empty(n.value, dtype=torch.float32, device="cuda")
+        check(lib().afx_tap(self._h, name.encode(), ptr(out), n.value, C.byref(n), stream_ptr()))
+        return out

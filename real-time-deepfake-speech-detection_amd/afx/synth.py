@@ -32,7 +32,8 @@ def _rand(name, shape, lo=0.0, hi=1.0):
 
 
 def _linear(sd, name, out_f, in_f, std=None, bias=True):
-    std = std if std is not None else 1.0 / math.sqrt(in_f)
+    # default: the std of torch's own nn.Linear init, U(+-1/sqrt(fan_in))
+    std = std if std is not None else 1.0 / math.sqrt(3.0 * in_f)
     sd[name + ".weight"] = _randn(name + ".weight", (out_f, in_f), std)
     if bias:
         sd[name + ".bias"] = _randn(name + ".bias", (out_f,), 0.02)
@@ -92,18 +93,18 @@ def aasist_head_state_dict(ssl_dim=1024):
         p = f"encoder.{i}.0."
         if i > 0:
             _bn(sd, p + "bn1", ci)  # present in checkpoints, never used (Q2)
-        sd[p + "conv1.weight"] = _randn(p + "conv1.weight", (co, ci, 2, 3), math.sqrt(1.0 / (ci * 6)))
+        sd[p + "conv1.weight"] = _randn(p + "conv1.weight", (co, ci, 2, 3), math.sqrt(1.0 / (3 * ci * 6)))
         sd[p + "conv1.bias"] = _randn(p + "conv1.bias", (co,), 0.02)
         _bn(sd, p + "bn2", co)
-        sd[p + "conv2.weight"] = _randn(p + "conv2.weight", (co, co, 2, 3), math.sqrt(1.0 / (co * 6)))
+        sd[p + "conv2.weight"] = _randn(p + "conv2.weight", (co, co, 2, 3), math.sqrt(1.0 / (3 * co * 6)))
         sd[p + "conv2.bias"] = _randn(p + "conv2.bias", (co,), 0.02)
         if ci != co:
-            sd[p + "conv_downsample.weight"] = _randn(p + "conv_downsample.weight", (co, ci, 1, 3), math.sqrt(1.0 / (ci * 3)))
+            sd[p + "conv_downsample.weight"] = _randn(p + "conv_downsample.weight", (co, ci, 1, 3), math.sqrt(1.0 / (3 * ci * 3)))
             sd[p + "conv_downsample.bias"] = _randn(p + "conv_downsample.bias", (co,), 0.02)
-    sd["attention.0.weight"] = _randn("attention.0.weight", (128, 64, 1, 1), 0.125)
+    sd["attention.0.weight"] = _randn("attention.0.weight", (128, 64, 1, 1), 0.072)
     sd["attention.0.bias"] = _randn("attention.0.bias", (128,), 0.02)
     _bn(sd, "attention.2", 128)
-    sd["attention.3.weight"] = _randn("attention.3.weight", (64, 128, 1, 1), 0.09)
+    sd["attention.3.weight"] = _randn("attention.3.weight", (64, 128, 1, 1), 0.051)
     sd["attention.3.bias"] = _randn("attention.3.bias", (64,), 0.02)
     sd["pos_S"] = _randn("pos_S", (1, 42, 64))
     sd["master1"] = _randn("master1", (1, 1, 64))
@@ -164,12 +165,12 @@ def conformer_head_state_dict(emb_size=144, heads=4, kernel_size=31, n_encoders=
         _linear(sd, p + "attn.fn.to_out", emb_size, inner)
         sd[p + "attn.fn.rel_pos_emb.weight"] = _randn(p + "attn.fn.rel_pos_emb.weight", (2 * max_pos + 1, dh), 1.0)
         _norm(sd, p + "conv.net.0", emb_size)
-        sd[p + "conv.net.2.weight"] = _randn(p + "conv.net.2.weight", (ci * 2, emb_size, 1), 1.0 / math.sqrt(emb_size))
+        sd[p + "conv.net.2.weight"] = _randn(p + "conv.net.2.weight", (ci * 2, emb_size, 1), 1.0 / math.sqrt(3.0 * emb_size))
         sd[p + "conv.net.2.bias"] = _randn(p + "conv.net.2.bias", (ci * 2,), 0.02)
-        sd[p + "conv.net.4.conv.weight"] = _randn(p + "conv.net.4.conv.weight", (ci, 1, kernel_size), 1.0 / math.sqrt(kernel_size))
+        sd[p + "conv.net.4.conv.weight"] = _randn(p + "conv.net.4.conv.weight", (ci, 1, kernel_size), 1.0 / math.sqrt(3.0 * kernel_size))
         sd[p + "conv.net.4.conv.bias"] = _randn(p + "conv.net.4.conv.bias", (ci,), 0.02)
         _bn(sd, p + "conv.net.5", ci)
-        sd[p + "conv.net.7.weight"] = _randn(p + "conv.net.7.weight", (emb_size, ci, 1), 1.0 / math.sqrt(ci))
+        sd[p + "conv.net.7.weight"] = _randn(p + "conv.net.7.weight", (emb_size, ci, 1), 1.0 / math.sqrt(3.0 * ci))
         sd[p + "conv.net.7.bias"] = _randn(p + "conv.net.7.bias", (emb_size,), 0.02)
         _norm(sd, p + "post_norm", emb_size)
     _linear(sd, "conformer.fc5", 2, emb_size)

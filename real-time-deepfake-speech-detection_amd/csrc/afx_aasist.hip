@@ -1,0 +1,736 @@
+// AASIST graph-attention back-end on gfx950, all fp32.
+//
+// Why fp32 everywhere: GraphPool's top-k is discontinuous, so the head is kept free
+// of operand rounding.  The FLOP-heavy part (the 2-D residual encoder, ~1.2 GFLOP per
+// utterance) still runs on the matrix cores through v_mfma_f32_16x16x4_f32, which is
+// bit-for-bit an fp32 fma chain (cdna guide, "FP32-input MFMA").
+//
+// Data layout: encoder activations are channel-last in a zero-padded image
+// (B, HP, WP, C), logical pixel (h,w) at (h+1,w+1).  With the padding materialised a
+// (kh,3) convolution of "virtual pixel" m = h*WP + w is
+//     out[m][n] = sum_{dh<kh} A[(m + dh*WP)*C : +3C] . Wt[n][dh*3C : +3C]
+// i.e. a GEMM whose K dimension is kh contiguous chunks -- no im2col, no bounds tests
+// in the inner loop; virtual pixels that fall in the padding are masked to zero in the
+// epilogue, which at the same time re-creates the zero border of the output image.
+#include "afx_aasist.h"
+
+#include <cstring>
+
+#include "afx_common.h"
+
+namespace afx {
+
+// ===================================================================================
+// fp32 matrix-core GEMM with chunked K (convs, 1x1 convs, the LL linear)
+// ===================================================================================
+struct F32GemmArgs {
+  const float* A;
+  long lda;            // elements between consecutive (virtual) rows
+  int nch, kc;         // K = nch chunks of kc contiguous elements (kc % 16 == 0)
+  long chunk_stride;   // elements between chunks of one row
+  const float* W;      // [N][nch*kc]
+  int M, N;            // N = 16 * NT
+  const float* bias;   // [N] or null
+  const float* resid;  // indexed like out, or null
+  const float* bn_scale;  // [N] or null
+  const float* bn_shift;
+  int post;            // 0: none  1: bn -> selu (after resid)  2: selu -> bn
+  // validity mask of virtual pixels (img == 0 disables): pix = m % img; valid iff
+  // pix / wp < hout && pix % wp < wd; invalid outputs are written as 0
+  int img, wp, hout, wd;
+  float* out;
+  long ldo;
+  long o_off;          // output row = m + o_off
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void f32_gemm_kernel(F32GemmArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const long m0 = ((long)blockIdx.x * 4 + wave) * 32;
+  if (m0 >= p.M) return;
+  const long ldw = (long)p.nch * p.kc;
+  const float* arow[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    long m = m0 + mt * 16 + r;
+    m = m < p.M ? m : p.M - 1;
+    arow[mt] = p.A + m * p.lda + kq * 4;
+  }
+  const float* wrow = p.W + (long)r * ldw + kq * 4;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ch = 0; ch < p.nch; ++ch) {
+    const long ao = (long)ch * p.chunk_stride;
+    const long wo = (long)ch * p.kc;
+    for (int k0 = 0; k0 < p.kc; k0 += 16) {
+      f32x4 a[2], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) a[mt] = *(const f32x4*)(arow[mt] + ao + k0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)(wrow + (long)nt * 16 * ldw + wo + k0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][s], a[mt][s], acc[mt][nt], 0, 0, 0);
+    }
+  }
+  // operands swapped: lane holds out[m = .. + (lane&15)][n = 16nt + 4*(lane>>4) + 0..3]
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const long m = m0 + mt * 16 + r;
+    if (m >= p.M) continue;
+    bool valid = true;
+    if (p.img) {
+      const int pix = (int)(m % p.img);
+      valid = (pix / p.wp < p.hout) && (pix % p.wp < p.wd);
+    }
+    const long orow = (m + p.o_off) * p.ldo;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + kq * 4;
+      f32x4 v = acc[mt][nt];
+      if (p.bias) v += *(const f32x4*)(p.bias + n);
+      if (p.resid) v += *(const f32x4*)(p.resid + orow + n);
+      if (p.post == 1) {
+        const f32x4 sc = *(const f32x4*)(p.bn_scale + n), sh = *(const f32x4*)(p.bn_shift + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = selu(fmaf(v[i], sc[i], sh[i]));
+      } else if (p.post == 2) {
+        const f32x4 sc = *(const f32x4*)(p.bn_scale + n), sh = *(const f32x4*)(p.bn_shift + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaf(selu(v[i]), sc[i], sh[i]);
+      }
+      if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)(p.out + orow + n) = v;
+    }
+  }
+}
+
+static const char* launch_f32_gemm(const F32GemmArgs& p, hipStream_t s) {
+  if (p.kc % 16 || p.M <= 0) return "aasist gemm: chunk length must be a multiple of 16";
+  dim3 grid((unsigned)((p.M + 127) / 128));
+  switch (p.N) {
+    case 32: hipLaunchKernelGGL(f32_gemm_kernel<2>, grid, dim3(256), 0, s, p); break;
+    case 64: hipLaunchKernelGGL(f32_gemm_kernel<4>, grid, dim3(256), 0, s, p); break;
+    case 128: hipLaunchKernelGGL(f32_gemm_kernel<8>, grid, dim3(256), 0, s, p); break;
+    default: return "aasist gemm: N must be 32, 64 or 128";
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ===================================================================================
+// small kernels
+// ===================================================================================
+// models/xlsr_aasist.py:92-96: (B,T,128) -> transpose -> max_pool2d(3,3) -> BN2d(1) -> SELU,
+// written as a 1-channel padded image.
+__global__ void pool_bn_selu_kernel(const float* __restrict__ ll, int T, int wd, int wp, int img, float sc, float sh,
+                                    float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= AAS_F * wd) return;
+  const int fi = idx / wd, ti = idx % wd;
+  float m = -INFINITY;
+#pragma unroll
+  for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+    for (int df = 0; df < 3; ++df) m = fmaxf(m, ll[((long)b * T + ti * 3 + dt) * 128 + fi * 3 + df]);
+  out[(long)b * img + (fi + 1) * wp + ti + 1] = selu(fmaf(m, sc, sh));
+}
+
+// first residual block (Cin = 1): conv1 (2,3) pad (1,1) -> bn2 -> selu into Y (43 rows) and
+// the (1,3) downsample conv into D (42 rows).  One thread per (virtual pixel, channel).
+__global__ void first_block_kernel(const float* __restrict__ x, int M, int img, int wp, int wd, const float* __restrict__ w1,
+                                   const float* __restrict__ b1, const float* __restrict__ sc, const float* __restrict__ sh,
+                                   const float* __restrict__ wd_, const float* __restrict__ bd, float* __restrict__ Y,
+                                   float* __restrict__ D, int cout) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)M * cout) return;
+  const long m = idx / cout;
+  const int n = (int)(idx % cout);
+  const int pix = (int)(m % img), h = pix / wp, w = pix % wp;
+  float y = 0.f, d = 0.f;
+  if (w < wd && h < 43) {
+    float a = b1[n];
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) a = fmaf(x[m + dh * wp + dw], w1[n * 6 + dh * 3 + dw], a);
+    y = selu(fmaf(a, sc[n], sh[n]));
+    if (h < 42) {
+      float e = bd[n];
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) e = fmaf(x[m + wp + dw], wd_[n * 3 + dw], e);
+      d = e;
+    }
+  }
+  const long o = (m + wp + 1) * cout + n;
+  Y[o] = y;
+  D[o] = d;
+}
+
+// conv weight [cout][cin][kh][kw] -> tap-major [cout][(dh*kw + dw)*cin + c]
+__global__ void pack_conv2d_kernel(const float* w, int cout, int cin, int kh, int kw, float* out) {
+  const int total = cout * cin * kh * kw;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int n = i / (cin * kh * kw), rem = i % (cin * kh * kw);
+    const int tap = rem / cin, c = rem % cin;
+    out[i] = w[((long)n * cin + c) * kh * kw + tap];
+  }
+}
+__global__ void bn_fold2_kernel(const float* w, const float* b, const float* m, const float* v, float eps, int n,
+                                float* scale, float* shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float s = w[i] / sqrtf(v[i] + eps);
+    scale[i] = s;
+    shift[i] = b[i] - m[i] * s;
+  }
+}
+
+// models/xlsr_aasist.py:106-118: softmax-weighted pooling over time (e_S, + pos_S) and over
+// frequency (e_T).  Block = 64 threads (channels); blockIdx.x < 42 -> spectral node h,
+// else temporal node w.
+__global__ void att_pool_kernel(const float* __restrict__ x, const float* __restrict__ wm, int img, int wp, int wd,
+                                const float* __restrict__ pos_S, float* __restrict__ eS, float* __restrict__ eT) {
+  const int b = blockIdx.y, c = threadIdx.x;
+  const float* xb = x + (long)b * img * 64;
+  const float* wb = wm + (long)b * img * 64;
+  if (blockIdx.x < AAS_F) {
+    const int h = blockIdx.x;
+    const long base = ((long)(h + 1) * wp + 1) * 64 + c;
+    float mx = -INFINITY;
+    for (int w = 0; w < wd; ++w) mx = fmaxf(mx, wb[base + (long)w * 64]);
+    float den = 0.f, num = 0.f;
+    for (int w = 0; w < wd; ++w) {
+      const float e = expf(wb[base + (long)w * 64] - mx);
+      den += e;
+      num = fmaf(xb[base + (long)w * 64], e, num);
+    }
+    eS[((long)b * AAS_F + h) * 64 + c] = num / den + pos_S[h * 64 + c];
+  } else {
+    const int w = blockIdx.x - AAS_F;
+    const long base = ((long)wp + w + 1) * 64 + c;
+    const long st = (long)wp * 64;
+    float mx = -INFINITY;
+    for (int h = 0; h < AAS_F; ++h) mx = fmaxf(mx, wb[base + h * st]);
+    float den = 0.f, num = 0.f;
+    for (int h = 0; h < AAS_F; ++h) {
+      const float e = expf(wb[base + h * st] - mx);
+      den += e;
+      num = fmaf(xb[base + h * st], e, num);
+    }
+    eT[((long)b * wd + w) * 64 + c] = num / den;
+  }
+}
+
+// y[r][o] = b[o] + W[o] . x[r]   (rows of <= 64 features; wave per row, lane per output)
+__global__ void rowlin_kernel(const float* __restrict__ x, long ldx, int rows, int K, const float* __restrict__ W,
+                              const float* __restrict__ bias, int N, float* __restrict__ y, long ldy, int rpb,
+                              int o_batch_rows, int o_row_off) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows || lane >= N) return;
+  const float* xr = x + (long)r * ldx;
+  const float* wr = W + (long)lane * K;
+  float a = bias[lane];
+  for (int k = 0; k < K; ++k) a = fmaf(wr[k], xr[k], a);
+  const long orow = (long)(r / rpb) * o_batch_rows + (r % rpb) + o_row_off;
+  y[orow * ldy + lane] = a;
+}
+
+// ===================================================================================
+// graph attention (GraphAttentionLayer and the node/master parts of HtrgGraphAttention
+// Layer, models/aasist_modules.py:17-110,112-294).  Grid (N [+1], B): block i updates
+// node i; for the heterogeneous layer block N updates the master node.
+//   att[i][j] = softmax_j( tanh(W_att (x_i * x_j) + b) . v_blk(i,j) / temp )
+//   out_i = SELU(BN(W1 (sum_j att[i][j] x_j) + b1 + W2 x_i + b2))
+// The (N,N,D) pairwise tensor is never materialised: thread o keeps row o of W_att
+// pre-multiplied by x_i in registers and streams x_j from LDS.
+// ===================================================================================
+struct GatArgs {
+  const float* x;  // (B, N, DIN) node features (already type-projected for the htrg layer)
+  int N, n1;       // n1 = nodes of type 1 (== N for the homogeneous layer)
+  const float *att_w, *att_b;       // [DOUT][DIN], [DOUT]
+  const float *v11, *v22, *v12;     // [DOUT] each (homogeneous: all the same)
+  const float *w1, *b1, *w2, *b2;   // proj_with_att / proj_without_att
+  const float *bn_scale, *bn_shift;
+  float temp;
+  float* y1;  // (B, n1, DOUT)
+  float* y2;  // (B, N-n1, DOUT)
+  // master (htrg only; master == nullptr disables)
+  const float* master;  // (B or 1, DIN)
+  long master_bstride;  // 0 when the parameter is shared by the batch
+  const float *attM_w, *attM_b, *vM, *w1M, *b1M, *w2M, *b2M;
+  float* master_out;  // (B, DOUT)
+};
+
+template <int DIN, int DOUT>
+__global__ __launch_bounds__(256) void gat_kernel(GatArgs p) {
+  constexpr int JPW = 64 / DOUT;  // nodes handled at once by one wave
+  __shared__ __attribute__((aligned(16))) float xs[AAS_WP_MAX * 64];
+  __shared__ float att[AAS_WP_MAX + 8];
+  __shared__ __attribute__((aligned(16))) float agg[64];
+  const int b = blockIdx.y, i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = p.N;
+  const bool is_master = i == N;
+  const float* xb = p.x + (long)b * N * DIN;
+  for (int idx = tid; idx < N * DIN / 4; idx += 256) *(f32x4*)(xs + idx * 4) = *(const f32x4*)(xb + idx * 4);
+  __syncthreads();
+  const int o = lane % DOUT, jsub = lane / DOUT;
+  // centre vector: x_i for a node, the master vector for the master update
+  const float* ctr = is_master ? p.master + (long)b * p.master_bstride : xs + i * DIN;
+  const float* aw = is_master ? p.attM_w : p.att_w;
+  float wi[DIN];
+#pragma unroll
+  for (int d = 0; d < DIN; ++d) wi[d] = aw[o * DIN + d] * ctr[d];
+  const float ab = is_master ? p.attM_b[o] : p.att_b[o];
+  for (int j0 = wave * JPW; j0 < N; j0 += 4 * JPW) {
+    const int j = j0 + jsub;
+    const int jc = j < N ? j : N - 1;
+    float h = ab;
+#pragma unroll
+    for (int d = 0; d < DIN; d += 4) {
+      const f32x4 xv = *(const f32x4*)(xs + jc * DIN + d);
+      h = fmaf(wi[d], xv[0], h);
+      h = fmaf(wi[d + 1], xv[1], h);
+      h = fmaf(wi[d + 2], xv[2], h);
+      h = fmaf(wi[d + 3], xv[3], h);
+    }
+    const float* vv = is_master ? p.vM : ((i < p.n1) == (jc < p.n1) ? (i < p.n1 ? p.v11 : p.v22) : p.v12);
+    float t = tanhf(h) * vv[o];
+#pragma unroll
+    for (int off = DOUT / 2; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (o == 0 && j < N) att[j] = t / p.temp;
+  }
+  __syncthreads();
+  if (wave == 0) {  // softmax over j (N <= 128: two per lane)
+    const float a0 = lane < N ? att[lane] : -INFINITY;
+    const float a1 = lane + 64 < N ? att[lane + 64] : -INFINITY;
+    const float mx = wave_max(fmaxf(a0, a1));
+    const float e0 = lane < N ? expf(a0 - mx) : 0.f;
+    const float e1 = lane + 64 < N ? expf(a1 - mx) : 0.f;
+    const float den = wave_sum(e0 + e1);
+    if (lane < N) att[lane] = e0 / den;
+    if (lane + 64 < N) att[lane + 64] = e1 / den;
+  }
+  __syncthreads();
+  if (tid < DIN) {
+    float a = 0.f;
+    for (int j = 0; j < N; ++j) a = fmaf(att[j], xs[j * DIN + tid], a);
+    agg[tid] = a;
+  }
+  __syncthreads();
+  if (tid < DOUT) {
+    const float* W1 = is_master ? p.w1M : p.w1;
+    const float* W2 = is_master ? p.w2M : p.w2;
+    float a = is_master ? p.b1M[tid] : p.b1[tid];
+    float c = is_master ? p.b2M[tid] : p.b2[tid];
+    for (int d = 0; d < DIN; ++d) {
+      a = fmaf(W1[tid * DIN + d], agg[d], a);
+      c = fmaf(W2[tid * DIN + d], ctr[d], c);
+    }
+    const float v = a + c;
+    if (is_master) {
+      p.master_out[(long)b * DOUT + tid] = v;
+    } else {
+      const float y = selu(fmaf(v, p.bn_scale[tid], p.bn_shift[tid]));
+      if (i < p.n1)
+        p.y1[((long)b * p.n1 + i) * DOUT + tid] = y;
+      else
+        p.y2[((long)b * (N - p.n1) + (i - p.n1)) * DOUT + tid] = y;
+    }
+  }
+}
+
+static const char* launch_gat(const GatArgs& a, int B, int din, int dout, hipStream_t s) {
+  if (a.N < 1 || a.N > AAS_WP_MAX) return "aasist: graph has too many nodes for the LDS slab (clip too long)";
+  dim3 grid(a.N + (a.master ? 1 : 0), B);
+  if (din == 64 && dout == 64)
+    hipLaunchKernelGGL((gat_kernel<64, 64>), grid, dim3(256), 0, s, a);
+  else if (din == 64 && dout == 32)
+    hipLaunchKernelGGL((gat_kernel<64, 32>), grid, dim3(256), 0, s, a);
+  else if (din == 32 && dout == 32)
+    hipLaunchKernelGGL((gat_kernel<32, 32>), grid, dim3(256), 0, s, a);
+  else
+    return "aasist: unsupported graph layer dims";
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// GraphPool (models/aasist_modules.py:296-338): s = sigmoid(w.h + b); keep the top
+// max(int(N*k),1) nodes in DESCENDING score order; out = h * s.  One block per utterance.
+__global__ void graph_pool_kernel(const float* __restrict__ h, int N, int D, int keep, const float* __restrict__ w,
+                                  const float* __restrict__ bias, float* __restrict__ out) {
+  __shared__ float sc[AAS_WP_MAX + 8];
+  const int b = blockIdx.x, j = threadIdx.x;
+  const float* hb = h + (long)b * N * D;
+  if (j < N) {
+    float a = bias[0];
+    for (int d = 0; d < D; ++d) a = fmaf(hb[j * D + d], w[d], a);
+    sc[j] = sigmoid_acc(a);
+  }
+  __syncthreads();
+  if (j < N) {
+    const float s = sc[j];
+    int rank = 0;
+    for (int q = 0; q < N; ++q) rank += (sc[q] > s) || (sc[q] == s && q < j);
+    if (rank < keep)
+      for (int d = 0; d < D; ++d) out[((long)b * keep + rank) * D + d] = hb[j * D + d] * s;
+  }
+}
+
+// models/xlsr_aasist.py:137-175: residual adds (incl. the literal "+ 1", Q1), branch max,
+// readout [max|T|, mean T, max|S|, mean S, master] and the 160 -> 2 output layer.
+__global__ void readout_kernel(const float* T1, const float* Ta1, const float* S1, const float* m1, const float* ma1,
+                               const float* T2, const float* Ta2, const float* S2, const float* Sa2, const float* m2,
+                               const float* ma2, int nT, int nS, const float* __restrict__ ow,
+                               const float* __restrict__ ob, float* __restrict__ hidden, float* __restrict__ logits) {
+  __shared__ float hid[160];
+  const int b = blockIdx.x, d = threadIdx.x;  // 32 threads
+  float tmax = 0.f, tsum = 0.f;
+  for (int n = 0; n < nT; ++n) {
+    const long o = ((long)b * nT + n) * 32 + d;
+    const float v = fmaxf(T1[o] + Ta1[o], T2[o] + Ta2[o]);
+    tmax = n == 0 ? fabsf(v) : fmaxf(tmax, fabsf(v));
+    tsum += v;
+  }
+  float smax = 0.f, ssum = 0.f;
+  for (int n = 0; n < nS; ++n) {
+    const long o = ((long)b * nS + n) * 32 + d;
+    const float v = fmaxf(S1[o] + 1.0f, S2[o] + Sa2[o]);  // Q1: branch 1 adds the constant 1
+    smax = n == 0 ? fabsf(v) : fmaxf(smax, fabsf(v));
+    ssum += v;
+  }
+  const long mo = (long)b * 32 + d;
+  hid[d] = tmax;
+  hid[32 + d] = tsum / (float)nT;
+  hid[64 + d] = smax;
+  hid[96 + d] = ssum / (float)nS;
+  hid[128 + d] = fmaxf(m1[mo] + ma1[mo], m2[mo] + ma2[mo]);
+  __syncthreads();
+  for (int k = d; k < 160; k += 32) hidden[(long)b * 160 + k] = hid[k];
+  if (d < 2) {
+    float a = ob[d];
+    for (int k = 0; k < 160; ++k) a = fmaf(ow[d * 160 + k], hid[k], a);
+    logits[b * 2 + d] = a;
+  }
+}
+
+// ===================================================================================
+// host side
+// ===================================================================================
+static const float kEps = 1e-5f;
+
+const char* aasist_finalize(AasistWeights& w, const GetF& get, const Alloc& alloc, hipStream_t s) {
+  static thread_local std::string err;
+  auto need = [&](const std::string& k) -> const float* {
+    const float* p = get(k);
+    if (!p && err.empty()) err = "missing weight '" + k + "'";
+    return p;
+  };
+  err.clear();
+  auto fold = [&](const std::string& pre, int n, float** sc, float** sh) {
+    const float *g = need(pre + "weight"), *b = need(pre + "bias"), *m = need(pre + "running_mean"),
+                *v = need(pre + "running_var");
+    *sc = (float*)alloc((size_t)n * 4);
+    *sh = (float*)alloc((size_t)n * 4);
+    if (g && b && m && v && *sc && *sh)
+      hipLaunchKernelGGL(bn_fold2_kernel, dim3((n + 63) / 64), dim3(64), 0, s, g, b, m, v, kEps, n, *sc, *sh);
+  };
+  auto pack = [&](const std::string& k, int cout, int cin, int kh, int kw) -> float* {
+    const float* src = need(k);
+    float* dst = (float*)alloc((size_t)cout * cin * kh * kw * 4);
+    if (src && dst) hipLaunchKernelGGL(pack_conv2d_kernel, dim3(64), dim3(256), 0, s, src, cout, cin, kh, kw, dst);
+    return dst;
+  };
+  w.LLw = need("LL.weight");
+  w.LLb = need("LL.bias");
+  static const int filt[6][2] = {{1, 32}, {32, 32}, {32, 64}, {64, 64}, {64, 64}, {64, 64}};
+  for (int i = 0; i < 6; ++i) {
+    AasistWeights::Block& B = w.blk[i];
+    const std::string p = "encoder." + std::to_string(i) + ".0.";
+    B.cin = filt[i][0];
+    B.cout = filt[i][1];
+    B.w1 = pack(p + "conv1.weight", B.cout, B.cin, 2, 3);
+    B.b1 = need(p + "conv1.bias");
+    B.w2 = pack(p + "conv2.weight", B.cout, B.cout, 2, 3);
+    B.b2 = need(p + "conv2.bias");
+    fold(p + "bn2.", B.cout, &B.bn2_scale, &B.bn2_shift);
+    B.wd = nullptr;
+    B.bd = nullptr;
+    if (B.cin != B.cout) {
+      B.wd = pack(p + "conv_downsample.weight", B.cout, B.cin, 1, 3);
+      B.bd = need(p + "conv_downsample.bias");
+    }
+  }
+  fold("first_bn1.", 64, &w.bn1_scale, &w.bn1_shift);
+  w.att_w0 = pack("attention.0.weight", 128, 64, 1, 1);
+  w.att_b0 = need("attention.0.bias");
+  fold("attention.2.", 128, &w.att_bn_scale, &w.att_bn_shift);
+  w.att_w3 = pack("attention.3.weight", 64, 128, 1, 1);
+  w.att_b3 = need("attention.3.bias");
+  w.pos_S = need("pos_S");
+  w.master1 = need("master1");
+  w.master2 = need("master2");
+  auto gat = [&](AasistWeights::Gat& g, const std::string& p) {
+    g.att_w = need(p + "att_proj.weight");
+    g.att_b = need(p + "att_proj.bias");
+    g.att_vec = need(p + "att_weight");
+    g.w1 = need(p + "proj_with_att.weight");
+    g.b1 = need(p + "proj_with_att.bias");
+    g.w2 = need(p + "proj_without_att.weight");
+    g.b2 = need(p + "proj_without_att.bias");
+    fold(p + "bn.", 64, &g.bn_scale, &g.bn_shift);
+  };
+  gat(w.gatS, "GAT_layer_S.");
+  gat(w.gatT, "GAT_layer_T.");
+  auto hgat = [&](AasistWeights::HGat& g, const std::string& p, int din, int dout) {
+    g.din = din;
+    g.dout = dout;
+    g.t1w = need(p + "proj_type1.weight"); g.t1b = need(p + "proj_type1.bias");
+    g.t2w = need(p + "proj_type2.weight"); g.t2b = need(p + "proj_type2.bias");
+    g.att_w = need(p + "att_proj.weight"); g.att_b = need(p + "att_proj.bias");
+    g.attM_w = need(p + "att_projM.weight"); g.attM_b = need(p + "att_projM.bias");
+    g.v11 = need(p + "att_weight11"); g.v22 = need(p + "att_weight22");
+    g.v12 = need(p + "att_weight12"); g.vM = need(p + "att_weightM");
+    g.w1 = need(p + "proj_with_att.weight"); g.b1 = need(p + "proj_with_att.bias");
+    g.w2 = need(p + "proj_without_att.weight"); g.b2 = need(p + "proj_without_att.bias");
+    g.w1M = need(p + "proj_with_attM.weight"); g.b1M = need(p + "proj_with_attM.bias");
+    g.w2M = need(p + "proj_without_attM.weight"); g.b2M = need(p + "proj_without_attM.bias");
+    fold(p + "bn.", dout, &g.bn_scale, &g.bn_shift);
+  };
+  hgat(w.h11, "HtrgGAT_layer_ST11.", 64, 32);
+  hgat(w.h12, "HtrgGAT_layer_ST12.", 32, 32);
+  hgat(w.h21, "HtrgGAT_layer_ST21.", 64, 32);
+  hgat(w.h22, "HtrgGAT_layer_ST22.", 32, 32);
+  auto pool = [&](AasistWeights::Pool& q, const std::string& p) {
+    q.w = need(p + "proj.weight");
+    q.b = need(p + "proj.bias");
+  };
+  pool(w.pS, "pool_S."); pool(w.pT, "pool_T.");
+  pool(w.phS1, "pool_hS1."); pool(w.phT1, "pool_hT1.");
+  pool(w.phS2, "pool_hS2."); pool(w.phT2, "pool_hT2.");
+  w.out_w = need("out_layer.weight");
+  w.out_b = need("out_layer.bias");
+  // BatchNorm2d(1) of the front: scalars to the host (one-off sync)
+  const float *g0 = need("first_bn.weight"), *b0 = need("first_bn.bias"), *m0 = need("first_bn.running_mean"),
+              *v0 = need("first_bn.running_var");
+  if (!err.empty()) return err.c_str();
+  if (hipStreamSynchronize(s) != hipSuccess) return "aasist: stream sync failed";
+  float hw, hb, hm, hv;
+  if (hipMemcpy(&hw, g0, 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&hb, b0, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(&hm, m0, 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&hv, v0, 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return "aasist: reading first_bn failed";
+  w.bn0_scale = hw / sqrtf(hv + kEps);
+  w.bn0_shift = hb - hm * w.bn0_scale;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hipGetErrorString(e);
+  w.ready = true;
+  return nullptr;
+}
+
+static void dims(int T, int* wd, int* wp, int* img) {
+  *wd = T / 3;
+  *wp = *wd + 2;
+  *img = AAS_HP * *wp;
+}
+
+void aasist_carve(int B, int T, const Alloc& take, AasistWs* ws) {
+  int wd, wp, img;
+  dims(T, &wd, &wp, &img);
+  const size_t pix = (size_t)B * img + 3 * (size_t)wp + 16;  // + slack for the shifted reads / writes
+  ws->ll = (float*)take((size_t)B * T * 128 * 4);
+  ws->imgA = (float*)take(pix * 64 * 4);
+  ws->imgB = (float*)take(pix * 64 * 4);
+  ws->imgC = (float*)take(pix * 64 * 4);
+  ws->wmap1 = (float*)take(pix * 128 * 4);
+  ws->wmap2 = (float*)take(pix * 64 * 4);
+  ws->eS = (float*)take((size_t)B * AAS_F * 64 * 4);
+  ws->eT = (float*)take((size_t)B * (wd > 0 ? wd : 1) * 64 * 4);
+  ws->gS = (float*)take((size_t)B * AAS_F * 64 * 4);
+  ws->gT = (float*)take((size_t)B * (wd > 0 ? wd : 1) * 64 * 4);
+  ws->oS = (float*)take((size_t)B * AAS_F * 64 * 4);
+  ws->oT = (float*)take((size_t)B * (wd > 0 ? wd : 1) * 64 * 4);
+  ws->br = (float*)take((size_t)B * 2 * 16 * (AAS_F + (wd > 0 ? wd : 1) + 8) * 64 * 4);
+  ws->hidden = (float*)take((size_t)B * 160 * 4);
+}
+
+#define AOK(expr)                  \
+  do {                             \
+    const char* m_ = (expr);       \
+    if (m_) return m_;             \
+  } while (0)
+#define HOK(expr)                                          \
+  do {                                                     \
+    hipError_t e_ = (expr);                                \
+    if (e_ != hipSuccess) return hipGetErrorString(e_);    \
+  } while (0)
+
+const char* aasist_forward(const AasistWeights& w, const float* feats, int B, int T, const AasistWs& ws, float* logits,
+                           hipStream_t s) {
+  if (!w.ready) return "aasist: weights not finalized";
+  int wd, wp, img;
+  dims(T, &wd, &wp, &img);
+  if (wd < 2) return "aasist: clip too short (need at least 6 SSL frames)";
+  if (wp > AAS_WP_MAX) return "aasist: clip too long for the graph kernels (T <= 234 frames)";
+  const int M = B * img;
+  const size_t pixbytes = ((size_t)M + 3 * (size_t)wp + 16) * 4;
+  // ---- LL: (B*T,1024) x [128][1024] on the fp32 matrix cores ------------------------
+  {
+    F32GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = feats; g.lda = 1024; g.nch = 1; g.kc = 1024; g.W = w.LLw; g.M = B * T; g.N = 128;
+    g.bias = w.LLb; g.out = ws.ll; g.ldo = 128;
+    AOK(launch_f32_gemm(g, s));
+  }
+  // ---- max-pool + BN + SELU into a 1-channel padded image ---------------------------
+  float *X = ws.imgA, *Y = ws.imgB, *D = ws.imgC;
+  HOK(hipMemsetAsync(ws.imgA, 0, pixbytes * 64, s));
+  HOK(hipMemsetAsync(ws.imgB, 0, pixbytes * 64, s));
+  HOK(hipMemsetAsync(ws.imgC, 0, pixbytes * 64, s));
+  float* x1 = ws.wmap2;  // 1-channel image borrowed from a later buffer
+  HOK(hipMemsetAsync(x1, 0, pixbytes, s));
+  hipLaunchKernelGGL(pool_bn_selu_kernel, dim3((AAS_F * wd + 255) / 256, B), dim3(256), 0, s, ws.ll, T, wd, wp, img,
+                     w.bn0_scale, w.bn0_shift, x1);
+  // ---- residual encoder ----------------------------------------------------------------
+  {  // block 0 (Cin = 1): conv1+bn2+selu -> Y, downsample -> D, conv2(Y) + D -> X
+    const AasistWeights::Block& K = w.blk[0];
+    const long n = (long)M * K.cout;
+    hipLaunchKernelGGL(first_block_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x1, M, img, wp, wd, K.w1,
+                       K.b1, K.bn2_scale, K.bn2_shift, K.wd, K.bd, Y, D, K.cout);
+    F32GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = Y + (long)wp * K.cout; g.lda = K.cout; g.nch = 2; g.kc = 3 * K.cout; g.chunk_stride = (long)wp * K.cout;
+    g.W = K.w2; g.M = M; g.N = K.cout; g.bias = K.b2; g.resid = D;
+    g.img = img; g.wp = wp; g.hout = AAS_F; g.wd = wd; g.out = X; g.ldo = K.cout; g.o_off = wp + 1;
+    AOK(launch_f32_gemm(g, s));
+  }
+  for (int i = 1; i < 6; ++i) {
+    const AasistWeights::Block& K = w.blk[i];
+    F32GemmArgs g;
+    memset(&g, 0, sizeof g);  // conv1 (pad (1,1)) on X -> bn2 -> selu -> Y, 43 rows
+    g.A = X; g.lda = K.cin; g.nch = 2; g.kc = 3 * K.cin; g.chunk_stride = (long)wp * K.cin;
+    g.W = K.w1; g.M = M; g.N = K.cout; g.bias = K.b1; g.bn_scale = K.bn2_scale; g.bn_shift = K.bn2_shift; g.post = 1;
+    g.img = img; g.wp = wp; g.hout = AAS_F + 1; g.wd = wd; g.out = Y; g.ldo = K.cout; g.o_off = wp + 1;
+    AOK(launch_f32_gemm(g, s));
+    const float* resid = X;
+    if (K.wd) {  // (1,3) downsample conv of X -> D
+      memset(&g, 0, sizeof g);
+      g.A = X + (long)wp * K.cin; g.lda = K.cin; g.nch = 1; g.kc = 3 * K.cin; g.W = K.wd; g.M = M; g.N = K.cout;
+      g.bias = K.bd; g.img = img; g.wp = wp; g.hout = AAS_F; g.wd = wd; g.out = D; g.ldo = K.cout; g.o_off = wp + 1;
+      AOK(launch_f32_gemm(g, s));
+      resid = D;
+    }
+    // conv2 (pad (0,1)) on Y + residual -> Z (written over X when the widths agree)
+    float* Z = K.wd ? X : X;
+    if (K.wd) {  // X held cin channels; its storage is re-used with cout channels only after D is complete
+      Z = X;
+    }
+    memset(&g, 0, sizeof g);
+    g.A = Y + (long)wp * K.cout; g.lda = K.cout; g.nch = 2; g.kc = 3 * K.cout; g.chunk_stride = (long)wp * K.cout;
+    g.W = K.w2; g.M = M; g.N = K.cout; g.bias = K.b2; g.resid = resid;
+    if (i == 5) {  // first_bn1 + SELU close the encoder (models/xlsr_aasist.py:100-101)
+      g.bn_scale = w.bn1_scale; g.bn_shift = w.bn1_shift; g.post = 1;
+    }
+    g.img = img; g.wp = wp; g.hout = AAS_F; g.wd = wd; g.out = Z; g.ldo = K.cout; g.o_off = wp + 1;
+    if (K.wd) {
+      // channel count of X changes (32 -> 64): the first row + 1 pixels of the new
+      // image are never written by the shifted store, so clear them explicitly
+      AOK(launch_f32_gemm(g, s));
+    } else {
+      AOK(launch_f32_gemm(g, s));
+    }
+  }
+  // ---- attention maps: 1x1 convs over the padded image --------------------------------
+  {
+    F32GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = X; g.lda = 64; g.nch = 1; g.kc = 64; g.W = w.att_w0; g.M = M; g.N = 128; g.bias = w.att_b0;
+    g.bn_scale = w.att_bn_scale; g.bn_shift = w.att_bn_shift; g.post = 2; g.out = ws.wmap1; g.ldo = 128;
+    AOK(launch_f32_gemm(g, s));
+    memset(&g, 0, sizeof g);
+    g.A = ws.wmap1; g.lda = 128; g.nch = 1; g.kc = 128; g.W = w.att_w3; g.M = M; g.N = 64; g.bias = w.att_b3;
+    g.out = ws.wmap2; g.ldo = 64;
+    AOK(launch_f32_gemm(g, s));
+  }
+  hipLaunchKernelGGL(att_pool_kernel, dim3(AAS_F + wd, B), dim3(64), 0, s, X, ws.wmap2, img, wp, wd, w.pos_S, ws.eS,
+                     ws.eT);
+  // ---- graph layers ---------------------------------------------------------------------
+  const int nS = AAS_F / 2, nT = wd / 2 > 0 ? wd / 2 : 1;        // after pool_S / pool_T
+  const int nS1 = nS / 2 > 0 ? nS / 2 : 1, nT1 = nT / 2 > 0 ? nT / 2 : 1;  // after pool_h*
+  auto run_gat = [&](const AasistWeights::Gat& G, const float* x, int N, float* y) -> const char* {
+    GatArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x; a.N = N; a.n1 = N; a.att_w = G.att_w; a.att_b = G.att_b; a.v11 = a.v22 = a.v12 = G.att_vec;
+    a.w1 = G.w1; a.b1 = G.b1; a.w2 = G.w2; a.b2 = G.b2; a.bn_scale = G.bn_scale; a.bn_shift = G.bn_shift;
+    a.temp = 2.0f; a.y1 = y; a.y2 = y;
+    return launch_gat(a, B, 64, 64, s);
+  };
+  auto run_pool = [&](const AasistWeights::Pool& P, const float* h, int N, int Dm, int keep, float* out) {
+    hipLaunchKernelGGL(graph_pool_kernel, dim3(B), dim3(128), 0, s, h, N, Dm, keep, P.w, P.b, out);
+  };
+  AOK(run_gat(w.gatS, ws.eS, AAS_F, ws.gS));
+  run_pool(w.pS, ws.gS, AAS_F, 64, nS, ws.oS);
+  AOK(run_gat(w.gatT, ws.eT, wd, ws.gT));
+  run_pool(w.pT, ws.gT, wd, 64, nT, ws.oT);
+  // branch scratch carve
+  float* p = ws.br;
+  auto take = [&](size_t n) { float* r = p; p += (n + 63) / 64 * 64; return r; };
+  struct Branch { float *xp, *T1, *S1, *m1, *T1p, *S1p, *xp2, *Ta, *Sa, *ma; } br[2];
+  for (int k = 0; k < 2; ++k) {
+    br[k].xp = take((size_t)B * (nT + nS) * 64);
+    br[k].T1 = take((size_t)B * nT * 32);
+    br[k].S1 = take((size_t)B * nS * 32);
+    br[k].m1 = take((size_t)B * 32);
+    br[k].T1p = take((size_t)B * nT1 * 32);
+    br[k].S1p = take((size_t)B * nS1 * 32);
+    br[k].xp2 = take((size_t)B * (nT1 + nS1) * 32);
+    br[k].Ta = take((size_t)B * nT1 * 32);
+    br[k].Sa = take((size_t)B * nS1 * 32);
+    br[k].ma = take((size_t)B * 32);
+  }
+  auto run_hgat = [&](const AasistWeights::HGat& G, const float* x1, int n1, const float* x2, int n2, float* xp,
+                      const float* master, long mstride, float* y1, float* y2, float* mout) -> const char* {
+    const int N = n1 + n2;
+    hipLaunchKernelGGL(rowlin_kernel, dim3((B * n1 + 3) / 4), dim3(256), 0, s, x1, (long)G.din, B * n1, G.din, G.t1w,
+                       G.t1b, G.din, xp, (long)G.din, n1, N, 0);
+    hipLaunchKernelGGL(rowlin_kernel, dim3((B * n2 + 3) / 4), dim3(256), 0, s, x2, (long)G.din, B * n2, G.din, G.t2w,
+                       G.t2b, G.din, xp, (long)G.din, n2, N, n1);
+    GatArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = xp; a.N = N; a.n1 = n1; a.att_w = G.att_w; a.att_b = G.att_b; a.v11 = G.v11; a.v22 = G.v22; a.v12 = G.v12;
+    a.w1 = G.w1; a.b1 = G.b1; a.w2 = G.w2; a.b2 = G.b2; a.bn_scale = G.bn_scale; a.bn_shift = G.bn_shift;
+    a.temp = 100.0f; a.y1 = y1; a.y2 = y2;
+    a.master = master; a.master_bstride = mstride; a.attM_w = G.attM_w; a.attM_b = G.attM_b; a.vM = G.vM;
+    a.w1M = G.w1M; a.b1M = G.b1M; a.w2M = G.w2M; a.b2M = G.b2M; a.master_out = mout;
+    return launch_gat(a, B, G.din, G.dout, s);
+  };
+  const AasistWeights::HGat* H1[2] = {&w.h11, &w.h21};
+  const AasistWeights::HGat* H2[2] = {&w.h12, &w.h22};
+  const AasistWeights::Pool* PS[2] = {&w.phS1, &w.phS2};
+  const AasistWeights::Pool* PT[2] = {&w.phT1, &w.phT2};
+  const float* M0[2] = {w.master1, w.master2};
+  for (int k = 0; k < 2; ++k) {
+    // x1 = temporal nodes, x2 = spectral nodes (models/xlsr_aasist.py:129-130); the raw
+    // (1,1,64) parameter is the master of the first layer (Q3)
+    AOK(run_hgat(*H1[k], ws.oT, nT, ws.oS, nS, br[k].xp, M0[k], 0, br[k].T1, br[k].S1, br[k].m1));
+    run_pool(*PS[k], br[k].S1, nS, 32, nS1, br[k].S1p);
+    run_pool(*PT[k], br[k].T1, nT, 32, nT1, br[k].T1p);
+    AOK(run_hgat(*H2[k], br[k].T1p, nT1, br[k].S1p, nS1, br[k].xp2, br[k].m1, 32, br[k].Ta, br[k].Sa, br[k].ma));
+  }
+  hipLaunchKernelGGL(readout_kernel, dim3(B), dim3(32), 0, s, br[0].T1p, br[0].Ta, br[0].S1p, br[0].m1, br[0].ma,
+                     br[1].T1p, br[1].Ta, br[1].S1p, br[1].Sa, br[1].m1, br[1].ma, nT1, nS1, w.out_w, w.out_b,
+                     ws.hidden, logits);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+}  // namespace afx

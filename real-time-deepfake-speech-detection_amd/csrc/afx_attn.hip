@@ -1,0 +1,168 @@
+// Transformer self-attention for the SSL trunk, gfx950.
+// T <= 224 frames (4-s clips give T = 199..201), head dim 64: one workgroup per
+// (utterance, head) keeps that head's whole K (row-major, XOR-swizzled 128-B rows)
+// and V^T (keys contiguous) in LDS -- 57 KB -- and its 4 waves walk the 16-row query
+// tiles.  Per query tile:
+//   S^T = K Q^T   via v_mfma 16x16x32 with K as the A-operand, so a lane owns one
+//                 query row (lane&15) and keys 16*kt + 4*(lane>>4) + 0..3;
+//   softmax       in registers: lane-local max/sum + two xor-shuffles (lanes 16/32
+//                 apart share the row); masked keys contribute exactly 0;
+//   O = P V       the S^T accumulator layout is re-used directly as the A-operand
+//                 (k-slots permuted identically on the V^T side), no LDS round trip.
+// Q never touches LDS (each wave reads its own 16 rows as 16-B fragments).
+#include "afx_common.h"
+#include "afx_kernels.h"
+
+namespace afx {
+
+constexpr int ATT_KEYS = 224;       // padded key capacity (7 k-steps of 32)
+constexpr int ATT_VT_STRIDE = 232;  // halfs per V^T row: 464 B, conflict-free ds_read_b64
+
+template <class HT, int KS>  // KS = number of 32-key steps actually computed
+__global__ __launch_bounds__(256) void mhsa_kernel(const typename HT::T* __restrict__ qkv,
+                                                   typename HT::T* __restrict__ out, int T, int H, float scale) {
+  typedef typename HT::T Tt;
+  typedef typename HT::V8 V8;
+  typedef typename HT::V4 V4;
+  constexpr int NKT = KS * 2;     // 16-key tiles
+  constexpr int KEYS = KS * 32;   // keys covered
+  __shared__ __attribute__((aligned(16))) char k_lds[ATT_KEYS * 128];
+  __shared__ __attribute__((aligned(16))) Tt vt_lds[64 * ATT_VT_STRIDE];
+
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long ld = 3L * H * 64;
+  const Tt* base = qkv + (long)b * T * ld + h * 64;
+  const Tt* kbase = base + (long)H * 64;
+  const Tt* vbase = base + 2L * H * 64;
+
+  // ---- stage K (swizzled rows) and V^T ------------------------------------------
+  for (int idx = tid; idx < KEYS * 8; idx += 256) {
+    const int key = idx >> 3, c = idx & 7;
+    u32x4 kv = u32x4{0u, 0u, 0u, 0u};
+    V8 vv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vv[i] = (Tt)0.f;
+    if (key < T) {
+      kv = *(const u32x4*)(kbase + (long)key * ld + c * 8);
+      vv = *(const V8*)(vbase + (long)key * ld + c * 8);
+    }
+    *(u32x4*)(k_lds + key * 128 + ((c ^ ((key >> 1) & 7)) * 16)) = kv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vt_lds[(c * 8 + i) * ATT_VT_STRIDE + key] = vv[i];
+  }
+  __syncthreads();
+
+  const int ql = lane & 15, g = lane >> 4;
+  const int nqt = (T + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q0 = qt * 16;
+    int qrow = q0 + ql;
+    qrow = qrow < T ? qrow : T - 1;
+    V8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const V8*)(base + (long)qrow * ld + ks * 32 + g * 8);
+
+    // S^T tiles: s[kt][r] = S[q0+ql][16kt + 4g + r]
+    f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int krow = kt * 16 + ql;
+      const int sw = (krow >> 1) & 7;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const V8 kf = *(const V8*)(k_lds + krow * 128 + (((ks * 4 + g) ^ sw) * 16));
+        s[kt] = HT::mfma(kf, qf[ks], s[kt]);
+      }
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + g * 4 + r;
+        const float v = key < T ? s[kt][r] * scale : -1e30f;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[kt][r] - mx);
+        s[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float rinv = 1.0f / sum;
+
+    // O = P V : k-slot (g, jj) of step s2 <-> key 32*s2 + 16*(jj>>2) + 4g + (jj&3)
+    f32x4 o[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      V8 pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pf[r] = (Tt)s[2 * s2][r];
+        pf[4 + r] = (Tt)s[2 * s2 + 1][r];
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const Tt* vr = vt_lds + (nt * 16 + ql) * ATT_VT_STRIDE + s2 * 32 + g * 4;
+        const V4 lo = *(const V4*)vr;
+        const V4 hi = *(const V4*)(vr + 16);
+        V8 vf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vf[r] = lo[r];
+          vf[4 + r] = hi[r];
+        }
+        o[nt] = HT::mfma(pf, vf, o[nt]);
+      }
+    }
+    // o[nt][r] = O[q0 + 4g + r][16nt + ql]; the row's 1/sum lives in lane (4g + r)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ri = __shfl(rinv, g * 4 + r, 64);
+      const int q = q0 + g * 4 + r;
+      if (q < T) {
+        Tt* orow = out + ((long)b * T + q) * (H * 64) + h * 64 + ql;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) orow[nt * 16] = (Tt)(o[nt][r] * ri);
+      }
+    }
+  }
+}
+
+template <class HT>
+static void launch_mhsa_t(const void* qkv, void* out, int B, int T, int H, float scale, hipStream_t s) {
+  typedef typename HT::T Tt;
+  dim3 grid(H, B), blk(256);
+  if (T <= 64)
+    hipLaunchKernelGGL((mhsa_kernel<HT, 2>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale);
+  else if (T <= 128)
+    hipLaunchKernelGGL((mhsa_kernel<HT, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale);
+  else
+    hipLaunchKernelGGL((mhsa_kernel<HT, 7>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale);
+}
+
+const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t s) {
+  if (T <= 0 || T > ATT_KEYS) return "mhsa: sequence length must be in 1..224 frames (<= 4.5 s clips)";
+  if (B <= 0 || H <= 0) return "mhsa: bad shape";
+  const float scale = 0.125f;  // 64^-0.5
+  if (dtype == DT_BF16)
+    launch_mhsa_t<BF16>(qkv, out, B, T, H, scale, s);
+  else
+    launch_mhsa_t<FP16>(qkv, out, B, T, H, scale, s);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+}  // namespace afx

@@ -1,0 +1,238 @@
+// Conformer student head kernels, gfx950.  The dense
+// products of the block run on the shared MFMA GEMM; what is here is the non-GEMM
+// remainder, all fp32: token assembly, Shaw relative-position attention,
+// GLU + depthwise conv + BatchNorm + Swish, and the 2-way classifier.
+#include "afx_common.h"
+#include "afx_kernels.h"
+
+namespace afx {
+
+// ---------------------------------------------------------------------------------
+// models/conformer_baseline.py:59-62 + :23-24 -- BatchNorm2d(1) (eval: one scalar
+// scale/shift), SELU, then the class token prepended to every utterance.
+// ---------------------------------------------------------------------------------
+__global__ void conf_tokens_kernel(const float* __restrict__ ll, const float* __restrict__ cls, float bn_scale,
+                                   float bn_shift, int T, int E, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const long n = (long)(T + 1) * E;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / E), c = (int)(i % E);
+    float v;
+    if (row == 0)
+      v = cls[c];
+    else
+      v = selu(fmaf(ll[((long)b * T + row - 1) * E + c], bn_scale, bn_shift));
+    out[(long)b * n + i] = v;
+  }
+}
+const char* launch_conf_tokens(const float* ll, const float* cls, float bn_scale, float bn_shift, int B, int T,
+                               int E, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(conf_tokens_kernel, dim3(16, B), dim3(256), 0, s, ll, cls, bn_scale, bn_shift, T, E, out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------
+// Shaw relative-position multi-head attention (lucidrains ConformerBlock.attn):
+//   logits[i][j] = (q_i . k_j + q_i . E[clamp(i-j, +-P) + P]) * dh^-0.5
+// One workgroup per (utterance, head); K, V and the (2N-1)-row window of E live in
+// LDS as fp32 (115 KB at N=200, dh=36 -- sized for CDNA4's 160 KB).  Thread i owns
+// query row i: q in registers, online softmax, K/V rows are LDS broadcasts and the E
+// row (i-j+N-1) is a conflict-free ds_read_b128 (row stride 36 dwords).
+// The (N,N,dh) relative tensor of the reference is never materialised.
+// ---------------------------------------------------------------------------------
+template <int DH, class HT>
+__global__ __launch_bounds__(256) void conf_attn_kernel(const float* __restrict__ q, long ldq,
+                                                        const float* __restrict__ kv, long ldkv,
+                                                        const float* __restrict__ rel, int max_pos, int N, int H,
+                                                        typename HT::T* __restrict__ out, long ldo) {
+  typedef typename HT::T Tt;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ks = sm;                 // [N][DH]
+  float* Vs = Ks + (long)N * DH;  // [N][DH]
+  float* Es = Vs + (long)N * DH;  // [2N-1][DH]
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int inner = H * DH;
+  for (int idx = tid; idx < N * (DH / 4); idx += 256) {
+    const int j = idx / (DH / 4), d4 = idx % (DH / 4);
+    const float* row = kv + ((long)b * N + j) * ldkv + h * DH + d4 * 4;
+    *(f32x4*)(Ks + j * DH + d4 * 4) = *(const f32x4*)row;
+    *(f32x4*)(Vs + j * DH + d4 * 4) = *(const f32x4*)(row + inner);
+  }
+  for (int idx = tid; idx < (2 * N - 1) * (DH / 4); idx += 256) {
+    const int r = idx / (DH / 4), d4 = idx % (DH / 4);
+    int dist = r - (N - 1);
+    dist = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
+    *(f32x4*)(Es + r * DH + d4 * 4) = *(const f32x4*)(rel + (long)(dist + max_pos) * DH + d4 * 4);
+  }
+  __syncthreads();
+  const int i = tid;
+  if (i >= N) return;
+  const float scale = 1.0f / sqrtf((float)DH);
+  float qv[DH], o[DH];
+  const float* qrow = q + ((long)b * N + i) * ldq + h * DH;
+#pragma unroll
+  for (int d = 0; d < DH; d += 4) {
+    const f32x4 t = *(const f32x4*)(qrow + d);
+    qv[d] = t[0] * scale; qv[d + 1] = t[1] * scale; qv[d + 2] = t[2] * scale; qv[d + 3] = t[3] * scale;
+    o[d] = o[d + 1] = o[d + 2] = o[d + 3] = 0.f;
+  }
+  float m = -1e30f, l = 0.f;
+  for (int j = 0; j < N; ++j) {
+    const float* kr = Ks + j * DH;
+    const float* er = Es + (i - j + N - 1) * DH;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; d += 4) {
+      const f32x4 kk = *(const f32x4*)(kr + d);
+      const f32x4 ee = *(const f32x4*)(er + d);
+      s = fmaf(qv[d], kk[0] + ee[0], s);
+      s = fmaf(qv[d + 1], kk[1] + ee[1], s);
+      s = fmaf(qv[d + 2], kk[2] + ee[2], s);
+      s = fmaf(qv[d + 3], kk[3] + ee[3], s);
+    }
+    const float mn = fmaxf(m, s);
+    const float corr = __expf(m - mn);
+    const float p = __expf(s - mn);
+    l = fmaf(l, corr, p);
+    const float* vr = Vs + j * DH;
+#pragma unroll
+    for (int d = 0; d < DH; d += 4) {
+      const f32x4 vv = *(const f32x4*)(vr + d);
+      o[d] = fmaf(o[d], corr, p * vv[0]);
+      o[d + 1] = fmaf(o[d + 1], corr, p * vv[1]);
+      o[d + 2] = fmaf(o[d + 2], corr, p * vv[2]);
+      o[d + 3] = fmaf(o[d + 3], corr, p * vv[3]);
+    }
+    m = mn;
+  }
+  const float rl = 1.0f / l;
+  Tt* orow = out + ((long)b * N + i) * ldo + h * DH;
+#pragma unroll
+  for (int d = 0; d < DH; d += 4) {
+    typename HT::V4 v4;
+    v4[0] = (Tt)(o[d] * rl); v4[1] = (Tt)(o[d + 1] * rl); v4[2] = (Tt)(o[d + 2] * rl); v4[3] = (Tt)(o[d + 3] * rl);
+    *(typename HT::V4*)(orow + d) = v4;
+  }
+}
+
+template <int DH, class HT>
+static hipError_t launch_conf_attn_t(const float* q, long ldq, const float* kv, long ldkv, const float* rel,
+                                     int max_pos, int B, int N, int H, void* out, long ldo, hipStream_t s) {
+  const int lds = (int)((4L * N - 1) * DH * sizeof(float));
+  hipError_t e = hipFuncSetAttribute((const void*)conf_attn_kernel<DH, HT>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((conf_attn_kernel<DH, HT>), dim3(H, B), dim3(256), lds, s, q, ldq, kv, ldkv, rel, max_pos, N,
+                     H, (typename HT::T*)out, ldo);
+  return hipGetLastError();
+}
+
+const char* launch_conf_attn(const float* q, long ldq, const float* kv, long ldkv, const float* rel, int max_pos,
+                             int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s) {
+  if (N <= 0 || N > 256) return "conf_attn: sequence (frames + class token) must be <= 256";
+  if ((4L * N - 1) * dh * 4 > 160 * 1024) return "conf_attn: K/V/E window does not fit the 160 KB LDS";
+  if ((ldq % 4) || (ldkv % 4) || (ldo % 4)) return "conf_attn: row strides must be multiples of 4";
+  hipError_t e;
+#define AFX_CA(DHv)                                                                                         \
+  e = dtype == DT_BF16 ? launch_conf_attn_t<DHv, BF16>(q, ldq, kv, ldkv, rel, max_pos, B, N, H, out_h, ldo, s) \
+                       : launch_conf_attn_t<DHv, FP16>(q, ldq, kv, ldkv, rel, max_pos, B, N, H, out_h, ldo, s)
+  if (dh == 36) { AFX_CA(36); }
+  else if (dh == 32) { AFX_CA(32); }
+  else if (dh == 64) { AFX_CA(64); }
+  else return "conf_attn: supported head dims are 32, 36 (emb 144 / 4 heads) and 64";
+#undef AFX_CA
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------
+// ConformerConvModule middle: GLU(channel) -> depthwise Conv1d(k, "same" pad
+// (k/2, k/2 - (k+1)%2)) -> BatchNorm1d (eval, folded to scale/shift) -> Swish.
+// One workgroup per (utterance, 32-channel slab): the gated activations for every
+// frame of the slab sit in LDS with the zero padding materialised.
+// ---------------------------------------------------------------------------------
+template <class HT>
+__global__ __launch_bounds__(256) void conf_dwconv_kernel(const float* __restrict__ x, long ldx,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          const float* __restrict__ bn_scale,
+                                                          const float* __restrict__ bn_shift, int N, int C, int k,
+                                                          typename HT::T* __restrict__ out, long ldo) {
+  typedef typename HT::T Tt;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int c0 = blockIdx.x * 32, b = blockIdx.y, tid = threadIdx.x;
+  const int pl = k / 2;
+  const int rows = N + k - 1;
+  float* us = sm;              // [rows][32]
+  float* ws = sm + rows * 32;  // [k][32]
+  const int cl = tid & 31, tl = tid >> 5;
+  const int c = c0 + cl;
+  const bool cok = c < C;
+  for (int r = tl; r < rows; r += 8) {
+    const int t = r - pl;
+    float u = 0.f;
+    if (cok && t >= 0 && t < N) {
+      const float* row = x + ((long)b * N + t) * ldx;
+      u = row[c] * sigmoid_acc(row[C + c]);
+    }
+    us[r * 32 + cl] = u;
+  }
+  for (int j = tl; j < k; j += 8) ws[j * 32 + cl] = cok ? w[(long)c * k + j] : 0.f;
+  __syncthreads();
+  if (!cok) return;
+  const float bi = bias[c], sc = bn_scale[c], sh = bn_shift[c];
+  for (int t = tl; t < N; t += 8) {
+    float a = bi;
+    for (int j = 0; j < k; ++j) a = fmaf(ws[j * 32 + cl], us[(t + j) * 32 + cl], a);
+    out[((long)b * N + t) * ldo + c] = (Tt)swish(fmaf(a, sc, sh));
+  }
+}
+
+const char* launch_conf_dwconv(const float* x, long ldx, const float* w, const float* bias, const float* bn_scale,
+                               const float* bn_shift, int B, int N, int C, int k, void* out_h, long ldo, int dtype,
+                               hipStream_t s) {
+  const int lds = (N + k - 1 + k) * 32 * (int)sizeof(float);
+  if (lds > 160 * 1024) return "conf_dwconv: sequence too long for the LDS slab";
+  dim3 grid((C + 31) / 32, B);
+  hipError_t e;
+  if (dtype == DT_BF16) {
+    e = hipFuncSetAttribute((const void*)conf_dwconv_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess)
+      hipLaunchKernelGGL(conf_dwconv_kernel<BF16>, grid, dim3(256), lds, s, x, ldx, w, bias, bn_scale, bn_shift, N, C,
+                         k, (__bf16*)out_h, ldo);
+  } else {
+    e = hipFuncSetAttribute((const void*)conf_dwconv_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess)
+      hipLaunchKernelGGL(conf_dwconv_kernel<FP16>, grid, dim3(256), lds, s, x, ldx, w, bias, bn_scale, bn_shift, N, C,
+                         k, (_Float16*)out_h, ldo);
+  }
+  if (e == hipSuccess) e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------
+// Tiny fp32 linear (classifier heads): out[r][n] = b[n] + x[r*row_stride + :K] . w[n]
+// One wave per output row; K is walked 64 lanes at a time.
+// ---------------------------------------------------------------------------------
+__global__ void small_linear_kernel(const float* __restrict__ x, long row_stride, int rows, int K,
+                                    const float* __restrict__ w, const float* __restrict__ b, int N,
+                                    float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + (long)r * row_stride;
+  for (int n = 0; n < N; ++n) {
+    float a = 0.f;
+    for (int kk = lane; kk < K; kk += 64) a = fmaf(xr[kk], w[(long)n * K + kk], a);
+    a = wave_sum(a);
+    if (lane == 0) out[(long)r * N + n] = a + (b ? b[n] : 0.f);
+  }
+}
+const char* launch_small_linear(const float* x, long row_stride, int rows, int K, const float* w, const float* b,
+                                int N, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(small_linear_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, row_stride, rows, K, w, b, N,
+                     out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+}  // namespace afx

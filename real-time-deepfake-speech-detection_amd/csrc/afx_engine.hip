@@ -1,0 +1,914 @@
+// libafx engine: weight store + forward orchestration + the C ABI of include/afx.h.
+// Host code (C++) over the HIP runtime; the only device code here is a few one-off
+// weight-preparation kernels.  The forward is a fixed sequence of asynchronous kernel
+// launches on the caller's stream: no allocation, no synchronisation, no host<->device
+// copies inside afx_forward (it can be captured into a hipGraph by the caller).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/afx.h"
+#include "afx_common.h"
+#include "afx_kernels.h"
+#include "afx_aasist.h"
+
+using namespace afx;
+
+// ---------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return 1;
+}
+#define HIP_OK(expr)                                                               \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e_));     \
+  } while (0)
+#define KOK(expr)                                    \
+  do {                                               \
+    const char* m_ = (expr);                         \
+    if (m_) return fail("%s", m_);                   \
+  } while (0)
+
+// ---------------------------------------------------------------------------------
+// model constants (XLS-R 300M trunk)
+// ---------------------------------------------------------------------------------
+static const int kConvK[7] = {10, 3, 3, 3, 3, 2, 2};
+static const int kConvS[7] = {5, 2, 2, 2, 2, 2, 2};
+constexpr int kC = 512;      // conv channels
+constexpr int kD = 1024;     // encoder width
+constexpr int kF = 4096;     // FFN width
+constexpr int kH = 16;       // heads
+constexpr int kPosK = 128;   // positional conv taps
+constexpr int kPosG = 16;    // positional conv groups
+constexpr int kPosPad = 64;  // = kPosK / 2
+constexpr float kLnEps = 1e-5f;
+constexpr float kBnEps = 1e-5f;
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static void conv_lengths(int L, int* T) {
+  for (int i = 0; i < 7; ++i) {
+    L = L >= kConvK[i] ? (L - kConvK[i]) / kConvS[i] + 1 : 0;
+    T[i] = L;
+  }
+}
+
+// one-off device helpers ------------------------------------------------------------
+__global__ void bn_fold_kernel(const float* w, const float* b, const float* m, const float* v, float eps, int n,
+                               float* scale, float* shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float s = w[i] / sqrtf(v[i] + eps);
+    scale[i] = s;
+    shift[i] = b[i] - m[i] * s;
+  }
+}
+
+struct FT {  // fp32 device tensor owned by the engine
+  float* p = nullptr;
+  size_t n = 0;
+  std::vector<int64_t> shape;
+};
+
+struct TapRec {
+  float* p = nullptr;  // engine-owned fp32 copy
+  size_t cap = 0, n = 0;
+};
+
+struct ConfBlock {
+  void *ff1_w1, *ff1_w2, *ff2_w1, *ff2_w2, *wqkv, *wout, *pw1, *pw2;
+  float *bn_scale, *bn_shift;
+};
+
+struct afx_engine {
+  afx_config cfg;
+  int dt;
+  size_t hsz;  // bytes per operand element
+  std::vector<void*> allocs;
+  std::unordered_map<std::string, FT> f;  // raw fp32 tensors by canonical name
+  std::unordered_set<std::string> loaded;
+  bool finalized = false;
+  bool taps_on = false;
+  std::unordered_map<std::string, TapRec> taps;
+
+  // trunk, packed operand-type weights
+  void* convw[7] = {nullptr};
+  void* projw = nullptr;
+  void* posw = nullptr;
+  float* pos_norm = nullptr;
+  std::vector<void*> wqkv, wo, w1, w2;
+  std::vector<float*> bqkv;
+  // Conformer head
+  int E = 0, Ep = 0, heads = 0, dh = 0, inner = 0, FF = 0, FFp = 0, C2 = 0, C2p = 0, ck = 0, nblk = 0;
+  void* conf_ll = nullptr;
+  float conf_bn_scale = 1.f, conf_bn_shift = 0.f;
+  std::vector<ConfBlock> blk;
+  // AASIST head
+  AasistWeights aw;
+
+  void* dalloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    allocs.push_back(p);
+    return p;
+  }
+  const float* F(const std::string& k) const {
+    auto it = f.find(k);
+    return it == f.end() ? nullptr : it->second.p;
+  }
+};
+
+// ---------------------------------------------------------------------------------
+// lifecycle
+// ---------------------------------------------------------------------------------
+extern "C" const char* afx_last_error(void) { return g_err; }
+extern "C" const char* afx_version(void) { return "afx 0.1 (gfx950)"; }
+
+extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
+  if (!cfg || !out) return fail("afx_create: null argument");
+  if (cfg->n_layers < 1 || cfg->n_layers > 24)
+    return fail("Number of layers must be at least 1 and at most 24.");  // models/fe.py:60-62
+  if (cfg->dtype != AFX_DT_BF16 && cfg->dtype != AFX_DT_FP16) return fail("afx_create: unknown dtype %d", cfg->dtype);
+  if (cfg->arch < AFX_ARCH_SSL || cfg->arch > AFX_ARCH_CONFORMER) return fail("afx_create: unknown arch %d", cfg->arch);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail("afx_create: no HIP device visible -- this library has no CPU fallback");
+  afx_engine* e = new afx_engine();
+  e->cfg = *cfg;
+  e->dt = cfg->dtype;
+  e->hsz = 2;
+  const int nl = cfg->n_layers;
+  e->wqkv.assign(nl, nullptr);
+  e->wo.assign(nl, nullptr);
+  e->w1.assign(nl, nullptr);
+  e->w2.assign(nl, nullptr);
+  e->bqkv.assign(nl, nullptr);
+  bool ok = true;
+  for (int i = 1; i < 7; ++i) ok &= (e->convw[i] = e->dalloc((size_t)kC * kC * kConvK[i] * 2)) != nullptr;
+  ok &= (e->projw = e->dalloc((size_t)kD * kC * 2)) != nullptr;
+  ok &= (e->posw = e->dalloc((size_t)kD * (kD / kPosG) * kPosK * 2)) != nullptr;
+  ok &= (e->pos_norm = (float*)e->dalloc(kPosK * 4)) != nullptr;
+  for (int l = 0; l < nl && ok; ++l) {
+    ok &= (e->wqkv[l] = e->dalloc((size_t)3 * kD * kD * 2)) != nullptr;
+    ok &= (e->wo[l] = e->dalloc((size_t)kD * kD * 2)) != nullptr;
+    ok &= (e->w1[l] = e->dalloc((size_t)kF * kD * 2)) != nullptr;
+    ok &= (e->w2[l] = e->dalloc((size_t)kD * kF * 2)) != nullptr;
+    ok &= (e->bqkv[l] = (float*)e->dalloc((size_t)3 * kD * 4)) != nullptr;
+  }
+  if (cfg->arch == AFX_ARCH_CONFORMER) {
+    e->E = cfg->conf_emb;
+    e->heads = cfg->conf_heads;
+    e->ck = cfg->conf_kernel;
+    e->nblk = cfg->conf_blocks;
+    if (e->E <= 0 || e->heads <= 0 || e->E % e->heads || e->E % 4 || e->ck <= 0 || e->nblk <= 0) {
+      afx_destroy(e);
+      return fail("afx_create: bad Conformer configuration (emb %d heads %d kernel %d blocks %d)", e->E, e->heads,
+                  e->ck, e->nblk);
+    }
+    e->dh = e->E / e->heads;
+    e->inner = e->dh * e->heads;
+    e->Ep = round_up(e->E, 64);
+    e->FF = 4 * e->E;
+    e->FFp = round_up(e->FF, 64);
+    e->C2 = 2 * e->E;
+    e->C2p = round_up(e->C2, 64);
+    ok &= (e->conf_ll = e->dalloc((size_t)e->E * kD * 2)) != nullptr;
+    e->blk.resize(e->nblk);
+    for (int b = 0; b < e->nblk && ok; ++b) {
+      ConfBlock& B = e->blk[b];
+      ok &= (B.ff1_w1 = e->dalloc((size_t)e->FF * e->Ep * 2)) != nullptr;
+      ok &= (B.ff1_w2 = e->dalloc((size_t)e->E * e->FFp * 2)) != nullptr;
+      ok &= (B.ff2_w1 = e->dalloc((size_t)e->FF * e->Ep * 2)) != nullptr;
+      ok &= (B.ff2_w2 = e->dalloc((size_t)e->E * e->FFp * 2)) != nullptr;
+      ok &= (B.wqkv = e->dalloc((size_t)3 * e->inner * e->Ep * 2)) != nullptr;
+      ok &= (B.wout = e->dalloc((size_t)e->E * e->Ep * 2)) != nullptr;
+      ok &= (B.pw1 = e->dalloc((size_t)2 * e->C2 * e->Ep * 2)) != nullptr;
+      ok &= (B.pw2 = e->dalloc((size_t)e->E * e->C2p * 2)) != nullptr;
+      ok &= (B.bn_scale = (float*)e->dalloc((size_t)e->C2 * 4)) != nullptr;
+      ok &= (B.bn_shift = (float*)e->dalloc((size_t)e->C2 * 4)) != nullptr;
+    }
+  }
+  if (!ok) {
+    afx_destroy(e);
+    return fail("afx_create: device allocation failed");
+  }
+  *out = e;
+  return 0;
+}
+
+extern "C" void afx_destroy(afx_handle h) {
+  if (!h) return;
+  for (void* p : h->allocs) (void)hipFree(p);
+  for (auto& t : h->taps)
+    if (t.second.p) (void)hipFree(t.second.p);
+  delete h;
+}
+
+extern "C" int afx_enable_taps(afx_handle h, int on) {
+  if (!h) return fail("afx_enable_taps: null handle");
+  h->taps_on = on != 0;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------------
+static bool starts_with(const std::string& s, const char* p) { return s.compare(0, strlen(p), p) == 0; }
+static bool ends_with(const std::string& s, const char* p) {
+  const size_t n = strlen(p);
+  return s.size() >= n && s.compare(s.size() - n, n, p) == 0;
+}
+static size_t numel(const int64_t* shape, int ndim) {
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+  return n;
+}
+static int expect_shape(const char* name, const int64_t* shape, int ndim, std::initializer_list<int64_t> want) {
+  size_t have = numel(shape, ndim), w = 1;
+  for (int64_t v : want) w *= (size_t)v;
+  if (have != w) return fail("afx_load_weight: %s has %zu elements, expected %zu", name, have, w);
+  return 0;
+}
+
+static int store_raw(afx_engine* e, const std::string& key, const float* src, const int64_t* shape, int ndim,
+                     hipStream_t s) {
+  FT& t = e->f[key];
+  const size_t n = numel(shape, ndim);
+  if (!t.p || t.n != n) {
+    t.p = (float*)e->dalloc(n * 4);
+    if (!t.p) return fail("afx_load_weight: device allocation failed for %s", key.c_str());
+    t.n = n;
+  }
+  t.shape.assign(shape, shape + ndim);
+  HIP_OK(hipMemcpyAsync(t.p, src, n * 4, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// trunk tensor (name without the "ssl_model.model." prefix)
+static int load_ssl(afx_engine* e, const std::string& k, const float* src, const int64_t* shape, int ndim,
+                    hipStream_t s) {
+  int i = 0, n = 0;
+  char tail[96];
+  if (sscanf(k.c_str(), "feature_extractor.conv_layers.%d.%95s", &i, tail) == 2 && !strcmp(tail, "0.weight")) {
+    if (i < 0 || i > 6) return fail("afx_load_weight: conv layer %d out of range", i);
+    if (i == 0) {
+      if (expect_shape(k.c_str(), shape, ndim, {kC, 1, kConvK[0]})) return 1;
+      return store_raw(e, "ssl." + k, src, shape, ndim, s);
+    }
+    if (expect_shape(k.c_str(), shape, ndim, {kC, kC, kConvK[i]})) return 1;
+    KOK(launch_pack_conv(src, kC, kC, kConvK[i], e->convw[i], e->dt, s));
+    return 0;
+  }
+  if (k == "post_extract_proj.weight") {
+    if (expect_shape(k.c_str(), shape, ndim, {kD, kC})) return 1;
+    KOK(launch_pack_linear(src, kD, kC, kC, e->projw, e->dt, s));
+    return 0;
+  }
+  if (sscanf(k.c_str(), "encoder.layers.%d.%95s", &n, tail) == 2) {
+    if (n < 0) return fail("afx_load_weight: bad layer index in %s", k.c_str());
+    if (n >= e->cfg.n_layers) return 0;  // a deeper checkpoint than this (truncated) trunk keeps: ignore
+    const std::string t = tail;
+    static const char* proj[3] = {"self_attn.q_proj.", "self_attn.k_proj.", "self_attn.v_proj."};
+    for (int j = 0; j < 3; ++j) {
+      if (t == std::string(proj[j]) + "weight") {
+        if (expect_shape(k.c_str(), shape, ndim, {kD, kD})) return 1;
+        KOK(launch_pack_linear(src, kD, kD, kD, (char*)e->wqkv[n] + (size_t)j * kD * kD * 2, e->dt, s));
+        return 0;
+      }
+      if (t == std::string(proj[j]) + "bias") {
+        if (expect_shape(k.c_str(), shape, ndim, {kD})) return 1;
+        HIP_OK(hipMemcpyAsync(e->bqkv[n] + j * kD, src, kD * 4, hipMemcpyDeviceToDevice, s));
+        return 0;
+      }
+    }
+    if (t == "self_attn.out_proj.weight") {
+      if (expect_shape(k.c_str(), shape, ndim, {kD, kD})) return 1;
+      KOK(launch_pack_linear(src, kD, kD, kD, e->wo[n], e->dt, s));
+      return 0;
+    }
+    if (t == "fc1.weight") {
+      if (expect_shape(k.c_str(), shape, ndim, {kF, kD})) return 1;
+      KOK(launch_pack_linear(src, kF, kD, kD, e->w1[n], e->dt, s));
+      return 0;
+    }
+    if (t == "fc2.weight") {
+      if (expect_shape(k.c_str(), shape, ndim, {kD, kF})) return 1;
+      KOK(launch_pack_linear(src, kD, kF, kF, e->w2[n], e->dt, s));
+      return 0;
+    }
+    return store_raw(e, "ssl." + k, src, shape, ndim, s);
+  }
+  // everything else on the path is a small fp32 tensor; off-path keys are dropped
+  if (starts_with(k, "quantizer.") || starts_with(k, "project_q.") || starts_with(k, "final_proj.") ||
+      k == "mask_emb" || starts_with(k, "target_glu") || starts_with(k, "layer_norm_") )
+    return 0;
+  return store_raw(e, "ssl." + k, src, shape, ndim, s);
+}
+
+static int load_conformer(afx_engine* e, const std::string& k, const float* src, const int64_t* shape, int ndim,
+                          hipStream_t s) {
+  const int E = e->E, Ep = e->Ep;
+  if (k == "LL.weight") {
+    if (expect_shape(k.c_str(), shape, ndim, {E, kD})) return 1;
+    KOK(launch_pack_linear(src, E, kD, kD, e->conf_ll, e->dt, s));
+    return 0;
+  }
+  int b = 0;
+  char tail[96];
+  if (sscanf(k.c_str(), "conformer.encoder_blocks.%d.%95s", &b, tail) == 2) {
+    if (b < 0 || b >= e->nblk) return fail("afx_load_weight: Conformer block %d out of range (n_encoders=%d)", b, e->nblk);
+    ConfBlock& B = e->blk[b];
+    const std::string t = tail;
+    struct { const char* name; void* dst; int N, K, Kp; } lin[] = {
+        {"ff1.fn.fn.net.0.weight", B.ff1_w1, e->FF, E, Ep},   {"ff1.fn.fn.net.3.weight", B.ff1_w2, E, e->FF, e->FFp},
+        {"ff2.fn.fn.net.0.weight", B.ff2_w1, e->FF, E, Ep},   {"ff2.fn.fn.net.3.weight", B.ff2_w2, E, e->FF, e->FFp},
+        {"attn.fn.to_q.weight", B.wqkv, e->inner, E, Ep},
+        {"attn.fn.to_kv.weight", (char*)B.wqkv + (size_t)e->inner * Ep * 2, 2 * e->inner, E, Ep},
+        {"attn.fn.to_out.weight", B.wout, E, e->inner, Ep},   {"conv.net.2.weight", B.pw1, 2 * e->C2, E, Ep},
+        {"conv.net.7.weight", B.pw2, E, e->C2, e->C2p},
+    };
+    for (auto& L : lin)
+      if (t == L.name) {
+        if (expect_shape(k.c_str(), shape, ndim, {L.N, L.K})) return 1;
+        KOK(launch_pack_linear(src, L.N, L.K, L.Kp, L.dst, e->dt, s));
+        return 0;
+      }
+  }
+  return store_raw(e, k, src, shape, ndim, s);
+}
+
+extern "C" int afx_load_weight(afx_handle h, const char* name, const float* dev_ptr, const int64_t* shape, int ndim,
+                               void* stream) {
+  if (!h || !name || !dev_ptr || (ndim > 0 && !shape)) return fail("afx_load_weight: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  std::string k = name;
+  if (starts_with(k, "module.")) k = k.substr(7);  // utils.py:13-43
+  if (ends_with(k, "num_batches_tracked")) return 0;
+  h->finalized = false;
+  h->loaded.insert(k);
+  if (starts_with(k, "ssl_model.model.")) return load_ssl(h, k.substr(16), dev_ptr, shape, ndim, s);
+  if (h->cfg.arch == AFX_ARCH_SSL) {
+    if (starts_with(k, "model.")) {
+      h->loaded.insert("ssl_model." + k);
+      return load_ssl(h, k.substr(6), dev_ptr, shape, ndim, s);
+    }
+    return 0;
+  }
+  if (h->cfg.arch == AFX_ARCH_CONFORMER) return load_conformer(h, k, dev_ptr, shape, ndim, s);
+  // AASIST head: everything is small fp32; bn1.* never influences the output (Q2)
+  if (k.find(".bn1.") != std::string::npos) return 0;
+  return store_raw(h, k, dev_ptr, shape, ndim, s);
+}
+
+static int need(afx_engine* e, const std::string& k) {
+  if (!e->loaded.count(k)) return fail("afx_finalize: missing weight '%s'", k.c_str());
+  return 0;
+}
+
+static int fold_bn(afx_engine* e, const std::string& p, int n, float* scale, float* shift, hipStream_t s) {
+  const float *w = e->F(p + "weight"), *b = e->F(p + "bias"), *m = e->F(p + "running_mean"), *v = e->F(p + "running_var");
+  if (!w || !b || !m || !v) return fail("afx_finalize: BatchNorm '%s*' incomplete", p.c_str());
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, b, m, v, kBnEps, n, scale, shift);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int afx_finalize(afx_handle h, void* stream) {
+  if (!h) return fail("afx_finalize: null handle");
+  hipStream_t s = (hipStream_t)stream;
+  const std::string P = "ssl_model.model.";
+  for (int i = 0; i < 7; ++i) {
+    const std::string c = P + "feature_extractor.conv_layers." + std::to_string(i);
+    if (need(h, c + ".0.weight") || need(h, c + ".0.bias") || need(h, c + ".2.1.weight") || need(h, c + ".2.1.bias"))
+      return 1;
+  }
+  for (const char* k : {"layer_norm.weight", "layer_norm.bias", "post_extract_proj.weight", "post_extract_proj.bias",
+                        "encoder.pos_conv.0.bias", "encoder.layer_norm.weight", "encoder.layer_norm.bias"})
+    if (need(h, P + k)) return 1;
+  for (int l = 0; l < h->cfg.n_layers; ++l) {
+    const std::string L = P + "encoder.layers." + std::to_string(l) + ".";
+    for (const char* k : {"self_attn.q_proj.weight", "self_attn.q_proj.bias", "self_attn.k_proj.weight",
+                          "self_attn.k_proj.bias", "self_attn.v_proj.weight", "self_attn.v_proj.bias",
+                          "self_attn.out_proj.weight", "self_attn.out_proj.bias", "self_attn_layer_norm.weight",
+                          "self_attn_layer_norm.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias",
+                          "final_layer_norm.weight", "final_layer_norm.bias"})
+      if (need(h, L + k)) return 1;
+  }
+  // positional conv: weight-norm (dim=2) folded into the packed operand
+  const float* pv = h->F("ssl.encoder.pos_conv.0.weight_v");
+  const float* pg = h->F("ssl.encoder.pos_conv.0.weight_g");
+  const float* pw = h->F("ssl.encoder.pos_conv.0.weight");
+  if (pv && pg) {
+    KOK(launch_pack_posconv(pv, pg, kD, kD / kPosG, kPosK, h->pos_norm, h->posw, h->dt, s));
+  } else if (pw) {
+    KOK(launch_pack_posconv(pw, nullptr, kD, kD / kPosG, kPosK, h->pos_norm, h->posw, h->dt, s));
+  } else {
+    return fail("afx_finalize: missing weight '%sencoder.pos_conv.0.weight_g/weight_v'", P.c_str());
+  }
+  if (h->cfg.arch == AFX_ARCH_CONFORMER) {
+    for (const char* k : {"LL.weight", "LL.bias", "first_bn.weight", "first_bn.bias", "first_bn.running_mean",
+                          "first_bn.running_var", "conformer.class_token", "conformer.fc5.weight", "conformer.fc5.bias"})
+      if (need(h, k)) return 1;
+    for (int b = 0; b < h->nblk; ++b) {
+      const std::string B = "conformer.encoder_blocks." + std::to_string(b) + ".";
+      for (const char* k :
+           {"ff1.fn.norm.weight", "ff1.fn.norm.bias", "ff1.fn.fn.net.0.weight", "ff1.fn.fn.net.0.bias",
+            "ff1.fn.fn.net.3.weight", "ff1.fn.fn.net.3.bias", "ff2.fn.norm.weight", "ff2.fn.norm.bias",
+            "ff2.fn.fn.net.0.weight", "ff2.fn.fn.net.0.bias", "ff2.fn.fn.net.3.weight", "ff2.fn.fn.net.3.bias",
+            "attn.norm.weight", "attn.norm.bias", "attn.fn.to_q.weight", "attn.fn.to_kv.weight",
+            "attn.fn.to_out.weight", "attn.fn.to_out.bias", "attn.fn.rel_pos_emb.weight", "conv.net.0.weight",
+            "conv.net.0.bias", "conv.net.2.weight", "conv.net.2.bias", "conv.net.4.conv.weight",
+            "conv.net.4.conv.bias", "conv.net.5.weight", "conv.net.5.bias", "conv.net.5.running_mean",
+            "conv.net.5.running_var", "conv.net.7.weight", "conv.net.7.bias", "post_norm.weight", "post_norm.bias"})
+        if (need(h, B + k)) return 1;
+      if (fold_bn(h, B + "conv.net.5.", h->C2, h->blk[b].bn_scale, h->blk[b].bn_shift, s)) return 1;
+      const FT& dw = h->f[B + "conv.net.4.conv.weight"];
+      if (dw.n != (size_t)h->C2 * h->ck)
+        return fail("afx_finalize: depthwise kernel has %zu elements, expected %d x %d", dw.n, h->C2, h->ck);
+      const FT& rp = h->f[B + "attn.fn.rel_pos_emb.weight"];
+      if (rp.n != (size_t)1025 * h->dh) return fail("afx_finalize: rel_pos_emb must be (1025, %d)", h->dh);
+    }
+    // BatchNorm2d(1): four scalars -> host (one-off synchronisation)
+    float w, b, m, v;
+    HIP_OK(hipStreamSynchronize(s));
+    HIP_OK(hipMemcpy(&w, h->F("first_bn.weight"), 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&b, h->F("first_bn.bias"), 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&m, h->F("first_bn.running_mean"), 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&v, h->F("first_bn.running_var"), 4, hipMemcpyDeviceToHost));
+    h->conf_bn_scale = w / sqrtf(v + kBnEps);
+    h->conf_bn_shift = b - m * h->conf_bn_scale;
+  } else if (h->cfg.arch == AFX_ARCH_XLSR_AASIST) {
+    if (const char* m = aasist_finalize(
+            h->aw, [&](const std::string& k) { return h->F(k); }, [&](size_t bytes) { return h->dalloc(bytes); }, s))
+      return fail("afx_finalize: %s", m);
+  }
+  h->finalized = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// workspace carving (identical walk for sizing and for the real call)
+// ---------------------------------------------------------------------------------
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  void* take(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+struct Ws {
+  int T[7];
+  void *bufA, *bufB, *feats_h, *xpad, *hbuf, *qkv, *att, *ff, *ssl_h;
+  float *tmp32, *x, *ssl_f;
+  // Conformer
+  float *ll32, *xc, *qkv32, *glu32;
+  void *hc, *hid, *ao, *u;
+  // AASIST
+  AasistWs aa;
+};
+
+static size_t carve(const afx_engine* e, int B, int L, int Tfeat, void* base, Ws* w) {
+  Carver c(base);
+  const size_t hs = 2;
+  int T = Tfeat;
+  if (L > 0) {
+    conv_lengths(L, w->T);
+    T = w->T[6];
+    const size_t n0 = (size_t)B * w->T[0] * kC, n1 = (size_t)B * w->T[1] * kC;
+    w->bufA = c.take(n0 * hs);
+    w->bufB = c.take(n1 * hs);
+    w->tmp32 = (float*)c.take(n1 * 4);
+    w->feats_h = c.take((size_t)B * T * kC * hs);
+    w->x = (float*)c.take((size_t)B * T * kD * 4);
+    w->xpad = c.take((size_t)B * (T + kPosK) * kD * hs);
+    w->hbuf = c.take((size_t)B * T * kD * hs);
+    w->qkv = c.take((size_t)B * T * 3 * kD * hs);
+    w->att = c.take((size_t)B * T * kD * hs);
+    w->ff = c.take((size_t)B * T * kF * hs);
+  }
+  w->ssl_f = (float*)c.take((size_t)B * T * kD * 4);
+  w->ssl_h = c.take((size_t)B * T * kD * hs);
+  if (e->cfg.arch == AFX_ARCH_CONFORMER) {
+    const size_t M = (size_t)B * (T + 1);
+    w->ll32 = (float*)c.take((size_t)B * T * e->E * 4);
+    w->xc = (float*)c.take(M * e->E * 4);
+    w->qkv32 = (float*)c.take(M * 3 * e->inner * 4);
+    w->glu32 = (float*)c.take(M * 2 * e->C2 * 4);
+    w->hc = c.take(M * e->Ep * hs);
+    w->hid = c.take(M * e->FFp * hs);
+    w->ao = c.take(M * e->Ep * hs);
+    w->u = c.take(M * e->C2p * hs);
+  } else if (e->cfg.arch == AFX_ARCH_XLSR_AASIST) {
+    aasist_carve(B, T, [&](size_t bytes) { return c.take(bytes); }, &w->aa);
+  }
+  return c.off + 256;
+}
+
+extern "C" int afx_num_frames(int n) {
+  int T[7];
+  conv_lengths(n, T);
+  return T[6];
+}
+
+extern "C" size_t afx_workspace_bytes(afx_handle h, int B, int L) {
+  if (!h || B <= 0 || L <= 0) return 0;
+  Ws w;
+  return carve(h, B, L, 0, nullptr, &w);
+}
+
+// ---------------------------------------------------------------------------------
+// taps (debug): engine-owned fp32 copies of intermediates
+// ---------------------------------------------------------------------------------
+__global__ void half_to_f32_kernel(const uint16_t* in, float* out, size_t n, int is_bf16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (is_bf16) {
+      out[i] = __uint_as_float((unsigned)in[i] << 16);
+    } else {
+      _Float16 hv;
+      memcpy(&hv, &in[i], 2);
+      out[i] = (float)hv;
+    }
+  }
+}
+static int tap(afx_engine* e, const char* name, const void* src, size_t n, bool is_half, hipStream_t s) {
+  if (!e->taps_on) return 0;
+  TapRec& t = e->taps[name];
+  if (t.cap < n) {
+    if (t.p) (void)hipFree(t.p);
+    HIP_OK(hipMalloc((void**)&t.p, n * 4));
+    t.cap = n;
+  }
+  t.n = n;
+  if (is_half) {
+    hipLaunchKernelGGL(half_to_f32_kernel, dim3(1024), dim3(256), 0, s, (const uint16_t*)src, t.p, n,
+                       e->dt == AFX_DT_BF16 ? 1 : 0);
+    HIP_OK(hipGetLastError());
+  } else {
+    HIP_OK(hipMemcpyAsync(t.p, src, n * 4, hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
+}
+extern "C" int afx_tap(afx_handle h, const char* name, float* out, size_t cap, size_t* n_out, void* stream) {
+  if (!h || !name) return fail("afx_tap: null argument");
+  auto it = h->taps.find(name);
+  if (it == h->taps.end()) return fail("afx_tap: no tap named '%s' (enable taps and run a forward first)", name);
+  if (n_out) *n_out = it->second.n;
+  if (out) {
+    if (cap < it->second.n) return fail("afx_tap: buffer too small (%zu < %zu)", cap, it->second.n);
+    HIP_OK(hipMemcpyAsync(out, it->second.p, it->second.n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// forward pieces
+// ---------------------------------------------------------------------------------
+static GemmArgs plain_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, int K) {
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.A = A; g.W = W; g.M = M; g.N = N; g.K = K;
+  g.rpb = M; g.a_batch = 0; g.a_row = lda;
+  g.kchunk = K; g.kchunk_stride = 0; g.ldw = ldw;
+  g.alpha = 1.f; g.act = ACT_NONE;
+  g.o_batch_rows = M; g.oh_batch_rows = M;
+  return g;
+}
+
+static RowNormArgs plain_norm(const float* x, long ldx, int rows, int C, const float* g, const float* b) {
+  RowNormArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.ldx = ldx; a.rows = rows; a.C = C; a.gamma = g; a.beta = b; a.eps = kLnEps; a.act = ACT_NONE;
+  a.rpb = rows; a.o_batch_rows = rows;
+  return a;
+}
+
+static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipStream_t s) {
+  const int dt = e->dt;
+  const int* T = w.T;
+  if (T[6] < 1) return fail("afx_forward: %d samples are too few for one output frame (need >= 400)", L);
+  auto cf = [&](int i, const char* leaf) {
+    return e->F("ssl.feature_extractor.conv_layers." + std::to_string(i) + leaf);
+  };
+  // layer 0: waveform -> (B,T0,512) operand type, LN + GELU fused
+  KOK(launch_conv0(wave, B, L, T[0], cf(0, ".0.weight"), cf(0, ".0.bias"), cf(0, ".2.1.weight"), cf(0, ".2.1.bias"),
+                   e->cfg.pre_emphasis, e->cfg.pre_emphasis_coef, w.bufA, dt, s));
+  // layers 1..6: conv-as-GEMM (fp32 out) then LayerNorm + GELU
+  void* in = w.bufA;
+  void* out = w.bufB;
+  for (int i = 1; i < 7; ++i) {
+    const int M = B * T[i], K = kConvK[i] * kC;
+    GemmArgs g = plain_gemm(in, 0, e->convw[i], K, M, kC, K);
+    g.rpb = T[i]; g.a_batch = (long)T[i - 1] * kC; g.a_row = (long)kConvS[i] * kC;
+    g.o_batch_rows = T[i]; g.oh_batch_rows = T[i];
+    g.bias = cf(i, ".0.bias");
+    g.out_f = w.tmp32; g.ldo_f = kC;
+    KOK(launch_gemm(g, dt, 1, s));
+    RowNormArgs n = plain_norm(w.tmp32, kC, M, kC, cf(i, ".2.1.weight"), cf(i, ".2.1.bias"));
+    n.act = ACT_GELU;
+    if (i < 6) {
+      n.out_h = out; n.ldo_h = kC;
+    } else {
+      n.out_f = w.tmp32; n.ldo_f = kC;  // in place: a row is register-resident before it is written
+    }
+    KOK(launch_rownorm(n, dt, s));
+    void* t = in; in = out; out = t;
+  }
+  const int Tt = T[6], M = B * Tt;
+  if (tap(e, "conv", w.tmp32, (size_t)M * kC, false, s)) return 1;
+  // feature LayerNorm(512) -> operand type
+  {
+    RowNormArgs n = plain_norm(w.tmp32, kC, M, kC, e->F("ssl.layer_norm.weight"), e->F("ssl.layer_norm.bias"));
+    n.out_h = w.feats_h; n.ldo_h = kC;
+    KOK(launch_rownorm(n, dt, s));
+  }
+  // post_extract_proj: fp32 residual stream x + operand copy into the time-padded buffer
+  {
+    GemmArgs g = plain_gemm(w.feats_h, kC, e->projw, kC, M, kD, kC);
+    g.rpb = Tt; g.a_batch = (long)Tt * kC; g.a_row = kC;
+    g.bias = e->F("ssl.post_extract_proj.bias");
+    g.out_f = w.x; g.ldo_f = kD; g.o_batch_rows = Tt; g.o_row_off = 0;
+    g.out_h = w.xpad; g.ldo_h = kD; g.oh_batch_rows = Tt + kPosK; g.oh_row_off = kPosPad;
+    KOK(launch_gemm(g, dt, 1, s));
+    KOK(launch_zero_pad_rows(w.xpad, B, Tt, kD, kPosPad, kPosK - kPosPad, s));
+  }
+  if (tap(e, "proj", w.x, (size_t)M * kD, false, s)) return 1;
+  // positional conv (grouped, k=128) + GELU, added to x in place
+  {
+    const int cpg = kD / kPosG;
+    GemmArgs g = plain_gemm(w.xpad, 0, e->posw, (long)cpg * kPosK, M, cpg, cpg * kPosK);
+    g.rpb = Tt; g.a_batch = (long)(Tt + kPosK) * kD; g.a_row = kD;
+    g.kchunk = cpg; g.kchunk_stride = kD;
+    g.g_a = cpg; g.g_w = (long)cpg * cpg * kPosK; g.g_n = cpg;
+    g.bias = e->F("ssl.encoder.pos_conv.0.bias");
+    g.act = ACT_GELU;
+    g.resid = w.x; g.ldr = kD;
+    g.out_f = w.x; g.ldo_f = kD; g.o_batch_rows = Tt; g.oh_batch_rows = Tt;
+    KOK(launch_gemm(g, dt, kPosG, s));
+  }
+  if (tap(e, "pos", w.x, (size_t)M * kD, false, s)) return 1;
+  // transformer layers (pre-LN)
+  for (int l = 0; l < e->cfg.n_layers; ++l) {
+    const std::string P = "ssl.encoder.layers." + std::to_string(l) + ".";
+    RowNormArgs n1 = plain_norm(w.x, kD, M, kD, e->F(P + "self_attn_layer_norm.weight"), e->F(P + "self_attn_layer_norm.bias"));
+    n1.out_h = w.hbuf; n1.ldo_h = kD;
+    KOK(launch_rownorm(n1, dt, s));
+    GemmArgs q = plain_gemm(w.hbuf, kD, e->wqkv[l], kD, M, 3 * kD, kD);
+    q.bias = e->bqkv[l];
+    q.out_h = w.qkv; q.ldo_h = 3 * kD;
+    KOK(launch_gemm(q, dt, 1, s));
+    KOK(launch_mhsa(w.qkv, w.att, B, Tt, kH, dt, s));
+    GemmArgs o = plain_gemm(w.att, kD, e->wo[l], kD, M, kD, kD);
+    o.bias = e->F(P + "self_attn.out_proj.bias");
+    o.resid = w.x; o.ldr = kD; o.out_f = w.x; o.ldo_f = kD;
+    KOK(launch_gemm(o, dt, 1, s));
+    RowNormArgs n2 = plain_norm(w.x, kD, M, kD, e->F(P + "final_layer_norm.weight"), e->F(P + "final_layer_norm.bias"));
+    n2.out_h = w.hbuf; n2.ldo_h = kD;
+    KOK(launch_rownorm(n2, dt, s));
+    GemmArgs f1 = plain_gemm(w.hbuf, kD, e->w1[l], kD, M, kF, kD);
+    f1.bias = e->F(P + "fc1.bias"); f1.act = ACT_GELU;
+    f1.out_h = w.ff; f1.ldo_h = kF;
+    KOK(launch_gemm(f1, dt, 1, s));
+    GemmArgs f2 = plain_gemm(w.ff, kF, e->w2[l], kF, M, kD, kF);
+    f2.bias = e->F(P + "fc2.bias");
+    f2.resid = w.x; f2.ldr = kD; f2.out_f = w.x; f2.ldo_f = kD;
+    KOK(launch_gemm(f2, dt, 1, s));
+    if (e->taps_on) {
+      const std::string nm = "layer" + std::to_string(l);
+      if (tap(e, nm.c_str(), w.x, (size_t)M * kD, false, s)) return 1;
+    }
+  }
+  // final encoder LayerNorm -> fp32 features (API output / AASIST input) + operand copy (LL GEMM)
+  RowNormArgs nf = plain_norm(w.x, kD, M, kD, e->F("ssl.encoder.layer_norm.weight"), e->F("ssl.encoder.layer_norm.bias"));
+  nf.out_f = w.ssl_f; nf.ldo_f = kD;
+  nf.out_h = w.ssl_h; nf.ldo_h = kD;
+  KOK(launch_rownorm(nf, dt, s));
+  if (tap(e, "ssl", w.ssl_f, (size_t)M * kD, false, s)) return 1;
+  return 0;
+}
+
+// Conformer head from SSL features already in w.ssl_h (operand type)
+static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipStream_t s) {
+  const int dt = e->dt, E = e->E, Ep = e->Ep, N = T + 1, M = B * N;
+  // LL -> BatchNorm2d(1) -> SELU -> class token
+  GemmArgs ll = plain_gemm(w.ssl_h, kD, e->conf_ll, kD, B * T, E, kD);
+  ll.bias = e->F("LL.bias");
+  ll.out_f = w.ll32; ll.ldo_f = E;
+  KOK(launch_gemm(ll, dt, 1, s));
+  KOK(launch_conf_tokens(w.ll32, e->F("conformer.class_token"), e->conf_bn_scale, e->conf_bn_shift, B, T, E, w.xc, s));
+  if (tap(e, "tokens", w.xc, (size_t)M * E, false, s)) return 1;
+  // K-padding columns of the operand buffers must read as zero
+  HIP_OK(hipMemsetAsync(w.hc, 0, (size_t)M * Ep * 2, s));
+  HIP_OK(hipMemsetAsync(w.ao, 0, (size_t)M * Ep * 2, s));
+  HIP_OK(hipMemsetAsync(w.u, 0, (size_t)M * e->C2p * 2, s));
+  if (e->FFp != e->FF) HIP_OK(hipMemsetAsync(w.hid, 0, (size_t)M * e->FFp * 2, s));
+  for (int b = 0; b < e->nblk; ++b) {
+    const std::string P = "conformer.encoder_blocks." + std::to_string(b) + ".";
+    ConfBlock& K = e->blk[b];
+    auto norm_to_h = [&](const char* nm) -> const char* {
+      RowNormArgs n = plain_norm(w.xc, E, M, E, e->F(P + nm + ".weight"), e->F(P + nm + ".bias"));
+      n.out_h = w.hc; n.ldo_h = Ep;
+      return launch_rownorm(n, dt, s);
+    };
+    auto feed_forward = [&](const char* ff, void* w1, void* w2) -> const char* {
+      if (const char* m = norm_to_h((std::string(ff) + ".fn.norm").c_str())) return m;
+      GemmArgs a = plain_gemm(w.hc, Ep, w1, Ep, M, e->FF, Ep);
+      a.bias = e->F(P + ff + ".fn.fn.net.0.bias"); a.act = ACT_SWISH;
+      a.out_h = w.hid; a.ldo_h = e->FFp;
+      if (const char* m = launch_gemm(a, dt, 1, s)) return m;
+      GemmArgs c = plain_gemm(w.hid, e->FFp, w2, e->FFp, M, E, e->FFp);
+      c.bias = e->F(P + ff + ".fn.fn.net.3.bias"); c.alpha = 0.5f;
+      c.resid = w.xc; c.ldr = E; c.out_f = w.xc; c.ldo_f = E;
+      return launch_gemm(c, dt, 1, s);
+    };
+    KOK(feed_forward("ff1", K.ff1_w1, K.ff1_w2));
+    // attention
+    KOK(norm_to_h("attn.norm"));
+    GemmArgs q = plain_gemm(w.hc, Ep, K.wqkv, Ep, M, 3 * e->inner, Ep);
+    q.out_f = w.qkv32; q.ldo_f = 3 * e->inner;
+    KOK(launch_gemm(q, dt, 1, s));
+    KOK(launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
+                         e->F(P + "attn.fn.rel_pos_emb.weight"), 512, B, N, e->heads, e->dh, w.ao, Ep, dt, s));
+    GemmArgs o = plain_gemm(w.ao, Ep, K.wout, Ep, M, E, Ep);
+    o.bias = e->F(P + "attn.fn.to_out.bias");
+    o.resid = w.xc; o.ldr = E; o.out_f = w.xc; o.ldo_f = E;
+    KOK(launch_gemm(o, dt, 1, s));
+    // conv module
+    KOK(norm_to_h("conv.net.0"));
+    GemmArgs p1 = plain_gemm(w.hc, Ep, K.pw1, Ep, M, 2 * e->C2, Ep);
+    p1.bias = e->F(P + "conv.net.2.bias");
+    p1.out_f = w.glu32; p1.ldo_f = 2 * e->C2;
+    KOK(launch_gemm(p1, dt, 1, s));
+    KOK(launch_conf_dwconv(w.glu32, 2 * e->C2, e->F(P + "conv.net.4.conv.weight"), e->F(P + "conv.net.4.conv.bias"),
+                           K.bn_scale, K.bn_shift, B, N, e->C2, e->ck, w.u, e->C2p, dt, s));
+    GemmArgs p2 = plain_gemm(w.u, e->C2p, K.pw2, e->C2p, M, E, e->C2p);
+    p2.bias = e->F(P + "conv.net.7.bias");
+    p2.resid = w.xc; p2.ldr = E; p2.out_f = w.xc; p2.ldo_f = E;
+    KOK(launch_gemm(p2, dt, 1, s));
+    KOK(feed_forward("ff2", K.ff2_w1, K.ff2_w2));
+    RowNormArgs pn = plain_norm(w.xc, E, M, E, e->F(P + "post_norm.weight"), e->F(P + "post_norm.bias"));
+    pn.out_f = w.xc; pn.ldo_f = E;
+    KOK(launch_rownorm(pn, dt, s));
+    if (e->taps_on) {
+      const std::string nm = "block" + std::to_string(b);
+      if (tap(e, nm.c_str(), w.xc, (size_t)M * E, false, s)) return 1;
+    }
+  }
+  KOK(launch_small_linear(w.xc, (long)N * E, B, E, e->F("conformer.fc5.weight"), e->F("conformer.fc5.bias"), 2, logits, s));
+  return 0;
+}
+
+static int run_head(afx_engine* e, int B, int T, Ws& w, float* logits, hipStream_t s) {
+  if (e->cfg.arch == AFX_ARCH_CONFORMER) return run_conformer(e, B, T, w, logits, s);
+  if (e->cfg.arch == AFX_ARCH_XLSR_AASIST) {
+    if (const char* m = aasist_forward(e->aw, w.ssl_f, B, T, w.aa, logits, s)) return fail("%s", m);
+    if (e->taps_on) {
+      if (tap(e, "e_S", w.aa.eS, (size_t)B * 42 * 64, false, s)) return 1;
+      if (tap(e, "e_T", w.aa.eT, (size_t)B * (T / 3) * 64, false, s)) return 1;
+      if (tap(e, "hidden", w.aa.hidden, (size_t)B * 160, false, s)) return 1;
+    }
+    return 0;
+  }
+  return fail("afx_forward: this handle is an SSL feature extractor; use afx_ssl_forward");
+}
+
+static int check_call(afx_handle h, const void* in, int B, int L, const void* out, void* ws) {
+  if (!h || !in || !out || !ws) return fail("afx: null argument");
+  if (!h->finalized) return fail("afx: weights not finalized (call afx_finalize after afx_load_weight)");
+  if (B <= 0 || L <= 0) return fail("afx: empty batch (B=%d, L=%d)", B, L);
+  return 0;
+}
+
+extern "C" int afx_forward(afx_handle h, const float* wave, int B, int L, float* logits, void* ws, size_t ws_bytes,
+                           void* stream) {
+  if (check_call(h, wave, B, L, logits, ws)) return 1;
+  Ws w;
+  const size_t needb = carve(h, B, L, 0, ws, &w);
+  if (ws_bytes < needb) return fail("afx_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
+  hipStream_t s = (hipStream_t)stream;
+  if (run_trunk(h, wave, B, L, w, s)) return 1;
+  return run_head(h, B, w.T[6], w, logits, s);
+}
+
+extern "C" int afx_ssl_forward(afx_handle h, const float* wave, int B, int L, float* feats, void* ws, size_t ws_bytes,
+                               void* stream) {
+  if (check_call(h, wave, B, L, feats, ws)) return 1;
+  Ws w;
+  const size_t needb = carve(h, B, L, 0, ws, &w);
+  if (ws_bytes < needb) return fail("afx_ssl_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
+  hipStream_t s = (hipStream_t)stream;
+  if (run_trunk(h, wave, B, L, w, s)) return 1;
+  HIP_OK(hipMemcpyAsync(feats, w.ssl_f, (size_t)B * w.T[6] * kD * 4, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+__global__ void f32_to_half_kernel(const float* in, uint16_t* out, size_t n, int is_bf16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (is_bf16) {
+      __bf16 v = (__bf16)in[i];
+      memcpy(&out[i], &v, 2);
+    } else {
+      _Float16 v = (_Float16)in[i];
+      memcpy(&out[i], &v, 2);
+    }
+  }
+}
+
+extern "C" int afx_head_forward(afx_handle h, const float* feats, int B, int T, float* logits, void* ws,
+                                size_t ws_bytes, void* stream) {
+  if (check_call(h, feats, B, T, logits, ws)) return 1;
+  if (h->cfg.arch == AFX_ARCH_SSL) return fail("afx_head_forward: this handle has no back-end");
+  Ws w;
+  memset(&w, 0, sizeof w);
+  const size_t needb = carve(h, B, 0, T, ws, &w);
+  if (ws_bytes < needb) return fail("afx_head_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)B * T * kD;
+  HIP_OK(hipMemcpyAsync(w.ssl_f, feats, n * 4, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(f32_to_half_kernel, dim3(1024), dim3(256), 0, s, feats, (uint16_t*)w.ssl_h, n,
+                     h->dt == AFX_DT_BF16 ? 1 : 0);
+  HIP_OK(hipGetLastError());
+  return run_head(h, B, T, w, logits, s);
+}
+
+extern "C" size_t afx_head_workspace_bytes(afx_handle h, int B, int T) {
+  if (!h || B <= 0 || T <= 0) return 0;
+  Ws w;
+  memset(&w, 0, sizeof w);
+  return carve(h, B, 0, T, nullptr, &w);
+}
+
+// ---------------------------------------------------------------------------------
+// single-kernel entry points
+// ---------------------------------------------------------------------------------
+#define KRET(expr)                       \
+  do {                                   \
+    const char* m_ = (expr);             \
+    return m_ ? fail("%s", m_) : 0;      \
+  } while (0)
+
+extern "C" int afx_k_gemm(int dtype, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                          const float* bias, int act, float alpha, const float* resid, long ldr, float* out_f,
+                          long ldo_f, void* out_h, long ldo_h, void* stream) {
+  GemmArgs g = plain_gemm(A, lda, W, ldw, M, N, K);
+  g.bias = bias; g.act = act; g.alpha = alpha; g.resid = resid; g.ldr = ldr;
+  g.out_f = out_f; g.ldo_f = ldo_f; g.out_h = out_h; g.ldo_h = ldo_h;
+  KRET(launch_gemm(g, dtype, 1, (hipStream_t)stream));
+}
+extern "C" int afx_k_conv_gemm(int dtype, const void* in_h, const void* Wp, int B, int Tin, int Tout, int Cin, int k,
+                               int s_, int N, const float* bias, float* out_f, void* stream) {
+  GemmArgs g = plain_gemm(in_h, 0, Wp, (long)k * Cin, B * Tout, N, k * Cin);
+  g.rpb = Tout; g.a_batch = (long)Tin * Cin; g.a_row = (long)s_ * Cin;
+  g.o_batch_rows = Tout; g.oh_batch_rows = Tout;
+  g.bias = bias; g.out_f = out_f; g.ldo_f = N;
+  KRET(launch_gemm(g, dtype, 1, (hipStream_t)stream));
+}
+extern "C" int afx_k_pack_linear(int dtype, const float* w, int N, int K, int Kpad, void* out_h, void* stream) {
+  KRET(launch_pack_linear(w, N, K, Kpad, out_h, dtype, (hipStream_t)stream));
+}
+extern "C" int afx_k_pack_conv(int dtype, const float* w, int N, int Cin, int k, void* out_h, void* stream) {
+  KRET(launch_pack_conv(w, N, Cin, k, out_h, dtype, (hipStream_t)stream));
+}
+extern "C" int afx_k_conv0(int dtype, const float* wave, int B, int L, const float* w, const float* bias,
+                           const float* gamma, const float* beta, int pre_emph, float coef, void* out_h,
+                           void* stream) {
+  KRET(launch_conv0(wave, B, L, (L - 10) / 5 + 1, w, bias, gamma, beta, pre_emph, coef, out_h, dtype,
+                    (hipStream_t)stream));
+}
+extern "C" int afx_k_rownorm(int dtype, const float* x, long ldx, int rows, int C, const float* gamma,
+                             const float* beta, float eps, int act, float* out_f, long ldo_f, void* out_h, long ldo_h,
+                             void* stream) {
+  RowNormArgs a = plain_norm(x, ldx, rows, C, gamma, beta);
+  a.eps = eps; a.act = act; a.out_f = out_f; a.ldo_f = ldo_f; a.out_h = out_h; a.ldo_h = ldo_h;
+  KRET(launch_rownorm(a, dtype, (hipStream_t)stream));
+}
+extern "C" int afx_k_mhsa(int dtype, const void* qkv, void* out, int B, int T, int H, void* stream) {
+  KRET(launch_mhsa(qkv, out, B, T, H, dtype, (hipStream_t)stream));
+}
+extern "C" int afx_k_conf_attn(int dtype, const float* q, long ldq, const float* kv, long ldkv, const float* rel,
+                               int max_pos, int B, int N, int H, int dh, void* out_h, long ldo, void* stream) {
+  KRET(launch_conf_attn(q, ldq, kv, ldkv, rel, max_pos, B, N, H, dh, out_h, ldo, dtype, (hipStream_t)stream));
+}
+extern "C" int afx_k_conf_dwconv(int dtype, const float* x, long ldx, const float* w, const float* bias,
+                                 const float* bn_scale, const float* bn_shift, int B, int N, int C, int k, void* out_h,
+                                 long ldo, void* stream) {
+  KRET(launch_conf_dwconv(x, ldx, w, bias, bn_scale, bn_shift, B, N, C, k, out_h, ldo, dtype, (hipStream_t)stream));
+}

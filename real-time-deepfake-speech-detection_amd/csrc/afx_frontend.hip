@@ -1,0 +1,281 @@
+// Frontend / row kernels for gfx950: raw-waveform conv layer 0 with fused
+// LayerNorm + GELU, generic row LayerNorm, weight packing.
+#include "afx_common.h"
+#include "afx_kernels.h"
+
+namespace afx {
+
+// ---------------------------------------------------------------------------------
+// conv layer 0: Conv1d(1 -> 512, k=10, s=5, bias) ->
+// LayerNorm over the 512 channels (fp32 statistics) -> erf-GELU -> operand type.
+// HBM-bound by its 1-KB-per-frame output (256 KB of waveform in, 13 MB out per 4-s
+// utterance).  One WAVE per frame: lane l owns channels 8l..8l+7 (weights, bias,
+// gamma, beta resident in VGPRs for the whole block), the 10 input samples are LDS
+// broadcasts, LayerNorm statistics are two 64-lane shuffle reductions, and the wave
+// stores one contiguous 1-KB row (16 B per lane).  Optional pre-emphasis
+// (data/preprocess.py:16-29) is applied while the waveform window is staged in LDS.
+// ---------------------------------------------------------------------------------
+constexpr int C0_FB = 64;  // frames per workgroup
+
+template <class HT>
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wave, int L, int T0,
+                                                    const float* __restrict__ w, const float* __restrict__ bias,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    int pre_emph, float pre_coef, typename HT::T* __restrict__ out) {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+  __shared__ float xs[C0_FB * 5 + 8];
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * C0_FB;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* x = wave + (long)b * L;
+  const int s0 = f0 * 5;
+  for (int i = tid; i < C0_FB * 5 + 5; i += 256) {
+    const int gidx = s0 + i;
+    float v = 0.f;
+    if (gidx < L) {
+      v = x[gidx];
+      if (pre_emph) {
+        const int gp = gidx > 0 ? gidx - 1 : 1;  // reflect pad of one sample on the left
+        v -= pre_coef * x[gp];
+      }
+    }
+    xs[i] = v;
+  }
+  float wr[8][10], bi[8], ga[8], be[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane * 8 + i;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) wr[i][j] = w[c * 10 + j];
+    bi[i] = bias[c];
+    ga[i] = gamma[c];
+    be[i] = beta[c];
+  }
+  __syncthreads();
+  const int fend = min(C0_FB, T0 - f0);
+  for (int f = wv; f < fend; f += 4) {
+    float xv[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) xv[j] = xs[f * 5 + j];
+    float v[8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float a = bi[i];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) a = fmaf(wr[i][j], xv[j], a);
+      v[i] = a;
+      sum += a;
+    }
+    const float mean = wave_sum(sum) * (1.0f / 512.0f);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] -= mean;
+      sq = fmaf(v[i], v[i], sq);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) * (1.0f / 512.0f) + 1e-5f);
+    V8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (T)gelu_erf(fmaf(v[i] * rstd, ga[i], be[i]));
+    *(V8*)(out + ((long)b * T0 + f0 + f) * 512 + lane * 8) = o;
+  }
+}
+
+const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w, const float* bias,
+                         const float* gamma, const float* beta, int pre_emph, float pre_coef, void* out_h,
+                         int dtype, hipStream_t s) {
+  if (B <= 0 || L < 10 || T0 != (L - 10) / 5 + 1) return "conv0: bad shape";
+  dim3 grid((T0 + C0_FB - 1) / C0_FB, B);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(conv0_kernel<BF16>, grid, dim3(256), 0, s, wave, L, T0, w, bias, gamma, beta, pre_emph,
+                       pre_coef, (__bf16*)out_h);
+  else
+    hipLaunchKernelGGL(conv0_kernel<FP16>, grid, dim3(256), 0, s, wave, L, T0, w, bias, gamma, beta, pre_emph,
+                       pre_coef, (_Float16*)out_h);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------
+// Row LayerNorm (+ activation): one wave per row, C <= 1024, C % 4 == 0.  The row
+// stays in registers (float4 per lane per 256-column slab), two-pass statistics in
+// fp32 like torch.  Used for the conv-stack LayerNorm+GELU, every transformer /
+// Conformer LayerNorm and the final encoder LayerNorm.  HBM-bound.
+// ---------------------------------------------------------------------------------
+template <class HT>
+__global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
+  typedef typename HT::T T;
+  typedef typename HT::V4 V4;
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.rows) return;
+  const float* x = a.x + r * a.ldx;
+  f32x4 v[4];
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < a.C) {
+      v[it] = *(const f32x4*)(x + c);
+      sum += v[it][0] + v[it][1] + v[it][2] + v[it][3];
+    }
+  }
+  const float inv = 1.0f / (float)a.C;
+  const float mean = wave_sum(sum) * inv;
+  float sq = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    if (c < a.C) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[it][i] -= mean;
+        sq = fmaf(v[it][i], v[it][i], sq);
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv + a.eps);
+  const long orow = (r / a.rpb) * a.o_batch_rows + (r % a.rpb) + a.o_row_off;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    if (c < a.C) {
+      const f32x4 g = *(const f32x4*)(a.gamma + c);
+      const f32x4 b = *(const f32x4*)(a.beta + c);
+      f32x4 y;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = apply_act(fmaf(v[it][i] * rstd, g[i], b[i]), a.act);
+      if (a.out_f) *(f32x4*)(a.out_f + orow * a.ldo_f + c) = y;
+      if (a.out_h) {
+        V4 h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = (T)y[i];
+        *(V4*)((T*)a.out_h + orow * a.ldo_h + c) = h;
+      }
+    }
+  }
+}
+
+const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
+  if (a.rows <= 0 || a.C <= 0 || a.C > 1024 || a.C % 4) return "rownorm: need 0 < C <= 1024, C % 4 == 0";
+  if (!a.out_f && !a.out_h) return "rownorm: no output";
+  dim3 grid((a.rows + 3) / 4);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(rownorm_kernel<BF16>, grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(rownorm_kernel<FP16>, grid, dim3(256), 0, s, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------
+// zero the time-padding rows of the positional-conv operand buffer (B, pf+T+pb, C)
+// ---------------------------------------------------------------------------------
+__global__ void zero_pad_rows_kernel(uint16_t* buf, int T, int C, int pf, int pb) {
+  const int b = blockIdx.y;
+  const int rows = pf + pb;
+  const long per = (long)(pf + T + pb) * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)rows * C / 8; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 8;
+    int r = (int)(e / C);
+    const int c = (int)(e % C);
+    if (r >= pf) r += T;
+    *(u32x4*)(buf + b * per + (long)r * C + c) = u32x4{0u, 0u, 0u, 0u};
+  }
+}
+const char* launch_zero_pad_rows(void* buf_h, int B, int T, int C, int pf, int pb, hipStream_t s) {
+  if (C % 8) return "zero_pad_rows: C % 8 != 0";
+  hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(32, B), dim3(256), 0, s, (uint16_t*)buf_h, T, C, pf, pb);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------
+// weight packing (one-off): fp32 checkpoint layouts -> K-contiguous operand rows
+// ---------------------------------------------------------------------------------
+template <class HT>
+__global__ void pack_linear_kernel(const float* w, int N, int K, int Kpad, typename HT::T* out) {
+  const long total = (long)N * Kpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / Kpad), k = (int)(i % Kpad);
+    out[i] = (typename HT::T)(k < K ? w[(long)n * K + k] : 0.f);
+  }
+}
+const char* launch_pack_linear(const float* w, int N, int K, int Kpad, void* out_h, int dtype, hipStream_t s) {
+  const int blocks = (int)min((long)4096, ((long)N * Kpad + 255) / 256);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(pack_linear_kernel<BF16>, dim3(blocks), dim3(256), 0, s, w, N, K, Kpad, (__bf16*)out_h);
+  else
+    hipLaunchKernelGGL(pack_linear_kernel<FP16>, dim3(blocks), dim3(256), 0, s, w, N, K, Kpad, (_Float16*)out_h);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// Conv1d weight [N][Cin][k] -> [N][j*Cin + c]: tap-major K so that, with channel-last
+// activations, a conv row is one contiguous slice of the input.
+template <class HT>
+__global__ void pack_conv_kernel(const float* w, int N, int Cin, int k, typename HT::T* out) {
+  const long total = (long)N * Cin * k;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / ((long)Cin * k));
+    const int rem = (int)(i % ((long)Cin * k));
+    const int j = rem / Cin, c = rem % Cin;
+    out[i] = (typename HT::T)w[((long)n * Cin + c) * k + j];
+  }
+}
+const char* launch_pack_conv(const float* w, int N, int Cin, int k, void* out_h, int dtype, hipStream_t s) {
+  const int blocks = (int)min((long)4096, ((long)N * Cin * k + 255) / 256);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(pack_conv_kernel<BF16>, dim3(blocks), dim3(256), 0, s, w, N, Cin, k, (__bf16*)out_h);
+  else
+    hipLaunchKernelGGL(pack_conv_kernel<FP16>, dim3(blocks), dim3(256), 0, s, w, N, Cin, k, (_Float16*)out_h);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// Positional conv: weight_v [C][cpg][k] (+ weight_g [k], weight-norm over dims (0,1))
+// -> [C][j*cpg + c] with the per-tap scale g[j] / ||v[:,:,j]|| folded in.
+__global__ void posconv_norm_kernel(const float* v, int C, int cpg, int k, float* norm) {
+  const int j = blockIdx.x;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < (long)C * cpg; i += blockDim.x) {
+    const float x = v[i * k + j];
+    s = fmaf(x, x, s);
+  }
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) norm[j] = sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+template <class HT>
+__global__ void pack_posconv_kernel(const float* v, const float* g, const float* norm, int C, int cpg, int k,
+                                    typename HT::T* out) {
+  const long total = (long)C * cpg * k;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int o = (int)(i / ((long)cpg * k));
+    const int rem = (int)(i % ((long)cpg * k));
+    const int j = rem / cpg, c = rem % cpg;
+    float x = v[((long)o * cpg + c) * k + j];
+    if (g) x = x * g[j] / norm[j];
+    out[i] = (typename HT::T)x;
+  }
+}
+const char* launch_pack_posconv(const float* v, const float* g, int C, int cpg, int k, float* norm_tmp, void* out_h,
+                                int dtype, hipStream_t s) {
+  if (g) hipLaunchKernelGGL(posconv_norm_kernel, dim3(k), dim3(256), 0, s, v, C, cpg, k, norm_tmp);
+  const int blocks = (int)min((long)4096, ((long)C * cpg * k + 255) / 256);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(pack_posconv_kernel<BF16>, dim3(blocks), dim3(256), 0, s, v, g, norm_tmp, C, cpg, k,
+                       (__bf16*)out_h);
+  else
+    hipLaunchKernelGGL(pack_posconv_kernel<FP16>, dim3(blocks), dim3(256), 0, s, v, g, norm_tmp, C, cpg, k,
+                       (_Float16*)out_h);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+}  // namespace afx

@@ -1,0 +1,94 @@
+// Host-visible launchers of the gfx950 kernels (internal to libafx; the public
+// C ABI is include/afx.h).  Every launcher is asynchronous on the given stream,
+// allocates nothing, and returns nullptr on success or a static error string.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace afx {
+
+enum DType { DT_BF16 = 0, DT_FP16 = 1 };
+
+struct GemmArgs {
+  const void* A;  // matrix-core operand type (bf16/fp16), K contiguous
+  const void* W;  // [N][K] (nn.Linear layout), K contiguous
+  int M, N, K;    // N is per group; K % 64 == 0
+  // A row m starts at (m / rpb) * a_batch + (m % rpb) * a_row   (elements)
+  int rpb;
+  long a_batch, a_row;
+  // k -> (k / kchunk) * kchunk_stride + (k % kchunk); plain GEMM: kchunk = K
+  int kchunk;
+  long kchunk_stride;
+  long ldw;
+  // grid.z groups: element offsets per group into A and W; column offset per group
+  long g_a, g_w;
+  int g_n;
+  const float* bias;  // [groups * N] or null
+  int act;
+  float alpha;
+  const float* resid;  // fp32, indexed like the output, or null
+  long ldr;
+  float* out_f;  // fp32 output or null
+  long ldo_f;
+  void* out_h;  // operand-type output or null
+  long ldo_h;
+  // output row of A-row m: (m / rpb) * o_batch_rows + (m % rpb) + o_row_off
+  // (out_f and resid use o_*, out_h uses oh_* -- e.g. the fp32 residual stream is
+  // unpadded while the operand copy feeds the time-padded positional-conv buffer)
+  int o_batch_rows, o_row_off;
+  int oh_batch_rows, oh_row_off;
+};
+const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
+
+// ---- frontend / row kernels (afx_frontend.hip) ---------------------------------
+// conv layer 0 (Cin=1,k=10,s=5) + LayerNorm(512) + erf-GELU; optional pre-emphasis.
+const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w /*[512][10]*/,
+                         const float* bias, const float* gamma, const float* beta, int pre_emph,
+                         float pre_coef, void* out_h, int dtype, hipStream_t s);
+// rows x C fp32 -> LayerNorm (optional activation) -> fp32 and/or operand-type outputs.
+// Output row r goes to (r / rpb) * o_batch_rows + (r % rpb) + o_row_off (row strides ld*).
+struct RowNormArgs {
+  const float* x;
+  long ldx;
+  int rows, C;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int act;
+  float* out_f;
+  long ldo_f;
+  void* out_h;
+  long ldo_h;
+  int rpb, o_batch_rows, o_row_off;
+};
+const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s);
+// zero the time padding rows of the positional-conv operand buffer (B, T+128, C)
+const char* launch_zero_pad_rows(void* buf_h, int B, int T, int C, int pad_front, int pad_back, hipStream_t s);
+// fp32 -> operand type conversion with optional layout permutes (weight packing)
+const char* launch_pack_linear(const float* w, int N, int K, int Kpad, void* out_h, int dtype, hipStream_t s);
+const char* launch_pack_conv(const float* w, int N, int Cin, int k, void* out_h, int dtype, hipStream_t s);
+const char* launch_pack_posconv(const float* v, const float* g, int C, int cpg, int k, float* norm_tmp /*[k]*/,
+                                void* out_h, int dtype, hipStream_t s);
+
+// ---- transformer self-attention (afx_attn.hip) -----------------------------------
+// qkv: (B*T, 3*H*64) operand type [q | k | v]; out: (B*T, H*64) operand type.
+const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t s);
+
+// ---- Conformer student head (afx_conformer.hip) ----------------------------------
+// y = selu(bn(x)) for rows 1..T of each utterance, row 0 = class token; x is the LL
+// output (B*T, E) fp32; out (B*(T+1), E) fp32 residual stream.
+const char* launch_conf_tokens(const float* ll, const float* cls, float bn_scale, float bn_shift, int B, int T,
+                               int E, float* out, hipStream_t s);
+// Shaw relative-position attention; q (B*N, H*dh) fp32, kv (B*N, 2*H*dh) fp32,
+// rel (2*max_pos+1, dh) fp32; out operand-type rows of stride ldo.
+const char* launch_conf_attn(const float* q, long ldq, const float* kv, long ldkv, const float* rel, int max_pos,
+                             int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s);
+// GLU -> depthwise conv (same pad) -> BatchNorm(eval) -> Swish.  x (B*N, 2*C) fp32.
+const char* launch_conf_dwconv(const float* x, long ldx, const float* w /*[C][k]*/, const float* bias,
+                               const float* bn_scale, const float* bn_shift, int B, int N, int C, int k,
+                               void* out_h, long ldo, int dtype, hipStream_t s);
+// logits = fc5(token0):  x (B*N, E) fp32 rows, token row = b*N.
+const char* launch_small_linear(const float* x, long row_stride, int rows, int K, const float* w, const float* b,
+                                int N, float* out, hipStream_t s);
+
+}  // namespace afx
