@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: utterances/s on 4 s @ 16 kHz clips (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward of the hot path (raw waveform -> logits -> bonafide score)
+over one batch of synthetic utterances that is already resident in HBM.  At N=1 the
+workload is BASELINE.json configs[1]: the Conformer student (XLS-R first-6 trunk +
+4 Conformer blocks, emb 144) at batch 64.  With N>1 every rank scores its own 64
+utterances (weak scaling, no data-path collective) and the scores are all-gathered
+over RCCL each step, inside the timed region.
+
+Besides the contract fields the JSON line carries
+  roofline     -- the dominant kernel (the 128x128 MFMA GEMM): algorithmic FLOPs per
+                  launch / its average launch duration, timed with hipEvents on the
+                  launch stream in a second, instrumented pass over the same K steps
+                  (the timed region itself runs un-instrumented);
+  cpu_baseline -- the CPU oracle (kind "port") timed on this box's host cores on a
+                  bounded sample of the same workload, plus the GPU-vs-oracle parity
+                  of that sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "real-time-deepfake-speech-detection_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16, MI355X_MICROARCH.md "Chip-level parameters"
+
+WORKLOADS = {
+    # name: (engine arch, oracle model name, trunk layers, GFLOP per utterance)
+    "conformer_student": ("conformer", "ConformerModel", 6, 55.29),
+    "xlsr_aasist": ("xlsr_aasist", "XLSR_AASIST", 24, 148.67),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="conformer_student", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (default 64 / 16)")
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--dtype", default=os.environ.get("AFX_DTYPE", "fp16"), choices=["fp16", "bf16"])
+    ap.add_argument("--cpu-sample", type=int, default=16, help="utterances timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X-native path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+
+    from afx import engine, synth
+    from afx.dist import all_gather_scores
+
+    arch, oname, n_layers, gflop = WORKLOADS[args.workload]
+    B = args.batch or (64 if args.workload == "conformer_student" else 16)
+    L = int(args.seconds * 16000)
+    sd = synth.model_state_dict(oname, n_layers=n_layers)
+    eng = engine.Engine(arch, n_layers=n_layers, dtype=args.dtype)
+    eng.load_state_dict(sd)
+    wave = synth.waveforms(B, L, batch_idx=rank).cuda()  # resident in HBM before the timed region
+    idx = torch.arange(rank * B, (rank + 1) * B, dtype=torch.int32, device="cuda")
+
+    def step():
+        logits = eng.forward(wave)
+        scores = logits[:, 1]
+        if world > 1:
+            return all_gather_scores(idx, scores, world)
+        return idx, scores
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        out = step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+        assert out[0].numel() == world * B
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    # ---- instrumented pass: per-kernel-class time from hipEvents on the launch stream ----
+    eng.profile_begin()
+    for _ in range(args.steps):
+        eng.forward(wave)
+    prof = eng.profile_end()
+    g = prof["gemm_kernel<128x128>"]
+    gemm_tflops = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+    roofline = {
+        "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(gemm_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "kernel": f"afx::gemm_kernel<{args.dtype},128,128>",
+        "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
+        "launches_per_step": g["launches"] // args.steps,
+        "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
+    }
+    breakdown = {k: round(v["ms"] / args.steps, 4) for k, v in prof.items() if v["launches"]}
+
+    result = {
+        "metric": "utterances/sec (4 s @ 16 kHz)", "value": round(value, 2), "unit": "utterances/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {oname} ({n_layers}-layer XLS-R trunk), batch {B} per GPU, "
+                               f"{args.seconds:g} s clips @ 16 kHz, random-init weights",
+                   "global_batch": world * B, "samples_per_utterance": L,
+                   "parallelism": f"dp{world} (utterance sharding, RCCL score all-gather)" if world > 1 else "single GPU"},
+        "model_tflops": round(value * gflop / 1e3, 1),
+        "device_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 3),
+        "roofline": roofline,
+        "kernel_ms_per_step": breakdown,
+    }
+
+    # ---- CPU baseline: the oracle on this box's host cores, bounded sample (rank 0, N=1) ----
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        from oracle import models as omodels
+        n = min(args.cpu_sample, B)
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        fwd = omodels.conformer_forward if arch == "conformer" else omodels.xlsr_aasist_forward
+        cpu_wave = wave[:n].cpu()
+        fwd(sd, cpu_wave[:1])  # warm the thread pool
+        t0 = time.perf_counter()
+        ref = fwd(sd, cpu_wave)
+        cpu_s = time.perf_counter() - t0
+        got = eng.forward(wave)[:n].cpu()
+        result["cpu_baseline"] = {
+            "value": round(n / cpu_s, 3), "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} of the same 4 s utterances, one batched fp32 forward of the CPU oracle (PyTorch CPU, "
+                      f"{cpu_s:.1f} s)",
+        }
+        result["parity"] = {"max_abs_dlogit_vs_oracle": float((got - ref).abs().max()), "tolerance": 1e-3,
+                            "utterances": n}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,15 @@ int afx_enable_taps(afx_handle h, int on);
  * "block<N>", "e_S", "e_T", "hidden".  Returns the element count through n_out. */
 int afx_tap(afx_handle h, const char* name, float* out, size_t cap_elems, size_t* n_out, void* stream);
 
+/* ---- per-kernel-class timing (hipEvents on the launch stream around every launch of
+ * the forwards issued between begin and end; off otherwise).  afx_profile_end waits
+ * for the recorded events and returns, per class, summed milliseconds, algorithmic
+ * FLOPs and launch counts (arrays of afx_profile_num_classes() entries). ------------ */
+int afx_profile_begin(afx_handle h);
+int afx_profile_end(afx_handle h, int n_classes, double* ms, double* flops, long long* launches);
+int afx_profile_num_classes(void);
+const char* afx_profile_class_name(int cls);
+
 /* ---- single-kernel entry points (unit parity tests; operand pointers are bf16 or
  * fp16 device arrays according to `dtype`) ---------------------------------------- */
 int afx_k_gemm(int dtype, const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
@@ -105,6 +114,21 @@ int afx_k_conf_attn(int dtype, const float* q, long ldq, const float* kv, long l
                     int B, int N, int H, int dh, void* out_h, long ldo, void* stream);
 int afx_k_conf_dwconv(int dtype, const float* x, long ldx, const float* w, const float* bias, const float* bn_scale,
                       const float* bn_shift, int B, int N, int C, int k, void* out_h, long ldo, void* stream);
+
+/* ---- AASIST graph modules alone (models/aasist_modules.py:17-110, 112-294, 296-338);
+ * all fp32, BatchNorm passed folded (scale = w/sqrt(var+eps), shift = b - mean*scale).
+ * Supported (in,out) dims: (64,64), (64,32), (32,32); N <= 80 nodes. ------------------ */
+const char* afx_aasist_error(void);
+int afx_k_gat(const float* x, int B, int N, int din, int dout, const float* att_w, const float* att_b,
+              const float* att_vec, const float* w1, const float* b1, const float* w2, const float* b2,
+              const float* bn_scale, const float* bn_shift, float temp, float* y, void* stream);
+/* wts: t1w t1b t2w t2b att_w att_b attM_w attM_b v11 v22 v12 vM w1 b1 w2 b2 w1M b1M w2M b2M bn_scale bn_shift
+ * master == NULL -> mean of the projected nodes; xp_scratch: B*(n1+n2)*din + B*din floats */
+int afx_k_hgat(const float* x1, int n1, const float* x2, int n2, int B, int din, int dout, const float* const* wts,
+               float temp, const float* master, long master_bstride, float* xp_scratch, float* y1, float* y2,
+               float* mout, void* stream);
+int afx_k_graph_pool(const float* h, int B, int N, int D, int keep, const float* w, const float* b, float* out,
+                     void* stream);
 
 #ifdef __cplusplus
 }

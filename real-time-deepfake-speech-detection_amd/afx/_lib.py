@@ -43,6 +43,10 @@ SIGNATURES = {
     "afx_head_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
     "afx_enable_taps": (_I, [_P, _I]),
     "afx_tap": (_I, [_P, C.c_char_p, _P, _Z, C.POINTER(_Z), _P]),
+    "afx_profile_begin": (_I, [_P]),
+    "afx_profile_end": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "afx_profile_num_classes": (_I, []),
+    "afx_profile_class_name": (C.c_char_p, [_I]),
     "afx_k_gemm": (_I, [_I, _P, _L, _P, _L, _I, _I, _I, _P, _I, _F, _P, _L, _P, _L, _P, _L, _P]),
     "afx_k_conv_gemm": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "afx_k_pack_linear": (_I, [_I, _P, _I, _I, _I, _P, _P]),
@@ -52,6 +56,10 @@ SIGNATURES = {
     "afx_k_mhsa": (_I, [_I, _P, _P, _I, _I, _I, _P]),
     "afx_k_conf_attn": (_I, [_I, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "afx_k_conf_dwconv": (_I, [_I, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
+    "afx_aasist_error": (C.c_char_p, []),
+    "afx_k_gat": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
+    "afx_k_hgat": (_I, [_P, _I, _P, _I, _I, _I, _I, C.POINTER(_P), _F, _P, _L, _P, _P, _P, _P, _P]),
+    "afx_k_graph_pool": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
 }
 
 _lib = None

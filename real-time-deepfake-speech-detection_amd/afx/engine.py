@@ -104,6 +104,18 @@ class Engine:
         check(l.afx_head_forward(self._h, ptr(f), B, T, ptr(out), ptr(ws), ws.numel(), stream_ptr()))
         return out
 
+    # ---- per-kernel-class timing (bench.py roofline leg) -----------------------------
+    def profile_begin(self):
+        check(lib().afx_profile_begin(self._h))
+
+    def profile_end(self):
+        """-> {class name: dict(ms=..., flops=..., launches=...)} summed since profile_begin."""
+        l = lib()
+        n = l.afx_profile_num_classes()
+        ms, fl, la = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
+        check(l.afx_profile_end(self._h, n, ms, fl, la))
+        return {l.afx_profile_class_name(i).decode(): dict(ms=ms[i], flops=fl[i], launches=la[i]) for i in range(n)}
+
     # ---- debug taps ----------------------------------------------------------------
     def enable_taps(self, on=True):
         check(lib().afx_enable_taps(self._h, 1 if on else 0))

@@ -85,3 +85,62 @@ def conf_dwconv(dtype, x, w, bias, bn_scale, bn_shift, B, N, Cc, k):
     check(lib().afx_k_conf_dwconv(DTYPES[dtype], ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(bn_scale), ptr(bn_shift),
                                   B, N, Cc, k, ptr(out), Cc, stream_ptr()))
     return out
+
+
+# ---- AASIST graph modules (fp32) ----------------------------------------------------
+def _check_aasist(rc):
+    if rc != 0:
+        from ._lib import AfxError
+        raise AfxError(lib().afx_aasist_error().decode())
+
+
+def bn_fold(weight, bias, mean, var, eps=1e-5):
+    """Eval BatchNorm as (scale, shift).  Parameter preparation, not hot-path compute."""
+    scale = weight / torch.sqrt(var + eps)
+    return scale.contiguous(), (bias - mean * scale).contiguous()
+
+
+def gat(x, p, temp):
+    """GraphAttentionLayer (models/aasist_modules.py:17-110).  p: dict of CUDA fp32
+    tensors att_w, att_b, att_vec, w1, b1, w2, b2, bn_scale, bn_shift."""
+    B, N, din = x.shape
+    dout = p["att_w"].shape[0]
+    y = torch.empty(B, N, dout, dtype=torch.float32, device=x.device)
+    _check_aasist(lib().afx_k_gat(ptr(x), B, N, din, dout, ptr(p["att_w"]), ptr(p["att_b"]), ptr(p["att_vec"]),
+                                  ptr(p["w1"]), ptr(p["b1"]), ptr(p["w2"]), ptr(p["b2"]), ptr(p["bn_scale"]),
+                                  ptr(p["bn_shift"]), temp, ptr(y), stream_ptr()))
+    return y
+
+
+HGAT_ORDER = ["t1w", "t1b", "t2w", "t2b", "att_w", "att_b", "attM_w", "attM_b", "v11", "v22", "v12", "vM",
+              "w1", "b1", "w2", "b2", "w1M", "b1M", "w2M", "b2M", "bn_scale", "bn_shift"]
+
+
+def hgat(x1, x2, p, temp, master=None):
+    """HtrgGraphAttentionLayer (models/aasist_modules.py:112-294)."""
+    import ctypes as C
+    B, n1, din = x1.shape
+    n2 = x2.shape[1]
+    dout = p["att_w"].shape[0]
+    dev = x1.device
+    y1 = torch.empty(B, n1, dout, dtype=torch.float32, device=dev)
+    y2 = torch.empty(B, n2, dout, dtype=torch.float32, device=dev)
+    mo = torch.empty(B, 1, dout, dtype=torch.float32, device=dev)
+    scratch = torch.empty(B * (n1 + n2) * din + B * din, dtype=torch.float32, device=dev)
+    arr = (C.c_void_p * len(HGAT_ORDER))(*[p[k].data_ptr() for k in HGAT_ORDER])
+    mstride = 0
+    if master is not None:
+        master = master.contiguous()
+        mstride = 0 if master.shape[0] == 1 else din  # a (1,1,D) parameter is shared by the batch
+    _check_aasist(lib().afx_k_hgat(ptr(x1), n1, ptr(x2), n2, B, din, dout, arr, temp, ptr(master), mstride,
+                                   ptr(scratch), ptr(y1), ptr(y2), ptr(mo), stream_ptr()))
+    return y1, y2, mo
+
+
+def graph_pool(h, w, b, k):
+    """GraphPool (models/aasist_modules.py:296-338)."""
+    B, N, D = h.shape
+    keep = max(int(N * k), 1)
+    out = torch.empty(B, keep, D, dtype=torch.float32, device=h.device)
+    _check_aasist(lib().afx_k_graph_pool(ptr(h), B, N, D, keep, ptr(w), ptr(b), ptr(out), stream_ptr()))
+    return out

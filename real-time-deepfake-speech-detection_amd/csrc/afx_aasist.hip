@@ -559,7 +559,7 @@ void aasist_carve(int B, int T, const Alloc& take, AasistWs* ws) {
   ws->gT = (float*)take((size_t)B * (wd > 0 ? wd : 1) * 64 * 4);
   ws->oS = (float*)take((size_t)B * AAS_F * 64 * 4);
   ws->oT = (float*)take((size_t)B * (wd > 0 ? wd : 1) * 64 * 4);
-  ws->br = (float*)take((size_t)B * 2 * 16 * (AAS_F + (wd > 0 ? wd : 1) + 8) * 64 * 4);
+  ws->br = (float*)take(((size_t)B * 2 * 3 * (AAS_F + (wd > 0 ? wd : 1) + 16) * 64 + 2 * 10 * 64) * 4);
   ws->hidden = (float*)take((size_t)B * 160 * 4);
 }
 
@@ -613,8 +613,13 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
     g.img = img; g.wp = wp; g.hout = AAS_F; g.wd = wd; g.out = X; g.ldo = K.cout; g.o_off = wp + 1;
     AOK(launch_f32_gemm(g, s));
   }
+  const size_t head_bytes = (size_t)(wp + 1) * 64 * 4;  // first padded row + 1 pixel, 64 channels
   for (int i = 1; i < 6; ++i) {
     const AasistWeights::Block& K = w.blk[i];
+    if (K.cin != K.cout) {  // Y and D switch to the wider channel-last layout: re-zero their borders
+      HOK(hipMemsetAsync(Y, 0, head_bytes, s));
+      HOK(hipMemsetAsync(D, 0, head_bytes, s));
+    }
     F32GemmArgs g;
     memset(&g, 0, sizeof g);  // conv1 (pad (1,1)) on X -> bn2 -> selu -> Y, 43 rows
     g.A = X; g.lda = K.cin; g.nch = 2; g.kc = 3 * K.cin; g.chunk_stride = (long)wp * K.cin;
@@ -628,26 +633,20 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
       g.bias = K.bd; g.img = img; g.wp = wp; g.hout = AAS_F; g.wd = wd; g.out = D; g.ldo = K.cout; g.o_off = wp + 1;
       AOK(launch_f32_gemm(g, s));
       resid = D;
+      // X is about to be re-used with cout channels per pixel: its first padded row + 1
+      // pixel are never touched by the shifted store and still hold cin-channel data
+      HOK(hipMemsetAsync(X, 0, head_bytes, s));
     }
-    // conv2 (pad (0,1)) on Y + residual -> Z (written over X when the widths agree)
-    float* Z = K.wd ? X : X;
-    if (K.wd) {  // X held cin channels; its storage is re-used with cout channels only after D is complete
-      Z = X;
-    }
+    // conv2 (pad (0,1)) on Y + residual, written over X (each element is read, as the
+    // residual, by the same thread that then overwrites it)
     memset(&g, 0, sizeof g);
     g.A = Y + (long)wp * K.cout; g.lda = K.cout; g.nch = 2; g.kc = 3 * K.cout; g.chunk_stride = (long)wp * K.cout;
     g.W = K.w2; g.M = M; g.N = K.cout; g.bias = K.b2; g.resid = resid;
     if (i == 5) {  // first_bn1 + SELU close the encoder (models/xlsr_aasist.py:100-101)
       g.bn_scale = w.bn1_scale; g.bn_shift = w.bn1_shift; g.post = 1;
     }
-    g.img = img; g.wp = wp; g.hout = AAS_F; g.wd = wd; g.out = Z; g.ldo = K.cout; g.o_off = wp + 1;
-    if (K.wd) {
-      // channel count of X changes (32 -> 64): the first row + 1 pixels of the new
-      // image are never written by the shifted store, so clear them explicitly
-      AOK(launch_f32_gemm(g, s));
-    } else {
-      AOK(launch_f32_gemm(g, s));
-    }
+    g.img = img; g.wp = wp; g.hout = AAS_F; g.wd = wd; g.out = X; g.ldo = K.cout; g.o_off = wp + 1;
+    AOK(launch_f32_gemm(g, s));
   }
   // ---- attention maps: 1x1 convs over the padded image --------------------------------
   {
@@ -734,3 +733,75 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
 }
 
 }  // namespace afx
+
+// ===================================================================================
+// single-module C entry points (unit parity against the reference's own modules)
+// ===================================================================================
+namespace afx {
+__global__ void node_mean_kernel(const float* x, int N, int D, float* out) {
+  const int b = blockIdx.x, d = threadIdx.x;
+  if (d >= D) return;
+  float a = 0.f;
+  for (int j = 0; j < N; ++j) a += x[((long)b * N + j) * D + d];
+  out[(long)b * D + d] = a / (float)N;
+}
+const char* aasist_last = nullptr;
+}  // namespace afx
+
+extern "C" const char* afx_aasist_error(void) { return afx::aasist_last ? afx::aasist_last : ""; }
+
+extern "C" int afx_k_gat(const float* x, int B, int N, int din, int dout, const float* att_w, const float* att_b,
+                         const float* att_vec, const float* w1, const float* b1, const float* w2, const float* b2,
+                         const float* bn_scale, const float* bn_shift, float temp, float* y, void* stream) {
+  using namespace afx;
+  GatArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.N = N; a.n1 = N; a.att_w = att_w; a.att_b = att_b; a.v11 = a.v22 = a.v12 = att_vec;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.temp = temp;
+  a.y1 = y; a.y2 = y;
+  aasist_last = launch_gat(a, B, din, dout, (hipStream_t)stream);
+  return aasist_last ? 1 : 0;
+}
+
+extern "C" int afx_k_hgat(const float* x1, int n1, const float* x2, int n2, int B, int din, int dout,
+                          const float* const* wts /* 22 pointers, order below */, float temp, const float* master,
+                          long master_bstride, float* xp_scratch /* B*(n1+n2)*din + B*din */, float* y1, float* y2,
+                          float* mout, void* stream) {
+  using namespace afx;
+  // wts: t1w t1b t2w t2b att_w att_b attM_w attM_b v11 v22 v12 vM w1 b1 w2 b2 w1M b1M w2M b2M bn_scale bn_shift
+  hipStream_t s = (hipStream_t)stream;
+  const int N = n1 + n2;
+  hipLaunchKernelGGL(rowlin_kernel, dim3((B * n1 + 3) / 4), dim3(256), 0, s, x1, (long)din, B * n1, din, wts[0], wts[1],
+                     din, xp_scratch, (long)din, n1, N, 0);
+  hipLaunchKernelGGL(rowlin_kernel, dim3((B * n2 + 3) / 4), dim3(256), 0, s, x2, (long)din, B * n2, din, wts[2], wts[3],
+                     din, xp_scratch, (long)din, n2, N, n1);
+  if (!master) {  // models/aasist_modules.py:167-168: mean of the projected nodes
+    float* mean = xp_scratch + (long)B * N * din;
+    hipLaunchKernelGGL(node_mean_kernel, dim3(B), dim3(64), 0, s, xp_scratch, N, din, mean);
+    master = mean;
+    master_bstride = din;
+  }
+  GatArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = xp_scratch; a.N = N; a.n1 = n1; a.att_w = wts[4]; a.att_b = wts[5]; a.attM_w = wts[6]; a.attM_b = wts[7];
+  a.v11 = wts[8]; a.v22 = wts[9]; a.v12 = wts[10]; a.vM = wts[11];
+  a.w1 = wts[12]; a.b1 = wts[13]; a.w2 = wts[14]; a.b2 = wts[15];
+  a.w1M = wts[16]; a.b1M = wts[17]; a.w2M = wts[18]; a.b2M = wts[19];
+  a.bn_scale = wts[20]; a.bn_shift = wts[21]; a.temp = temp; a.y1 = y1; a.y2 = y2;
+  a.master = master; a.master_bstride = master_bstride; a.master_out = mout;
+  aasist_last = launch_gat(a, B, din, dout, s);
+  return aasist_last ? 1 : 0;
+}
+
+extern "C" int afx_k_graph_pool(const float* h, int B, int N, int D, int keep, const float* w, const float* b,
+                                float* out, void* stream) {
+  using namespace afx;
+  if (N < 1 || N > 128 || keep < 1 || keep > N) {
+    aasist_last = "graph_pool: need 1 <= keep <= N <= 128";
+    return 1;
+  }
+  hipLaunchKernelGGL(graph_pool_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, h, N, D, keep, w, b, out);
+  hipError_t e = hipGetLastError();
+  aasist_last = e == hipSuccess ? nullptr : hipGetErrorString(e);
+  return aasist_last ? 1 : 0;
+}

@@ -135,6 +135,7 @@ struct afx_engine {
 // ---------------------------------------------------------------------------------
 // lifecycle
 // ---------------------------------------------------------------------------------
+static void prof_forget(afx_engine* e);
 extern "C" const char* afx_last_error(void) { return g_err; }
 extern "C" const char* afx_version(void) { return "afx 0.1 (gfx950)"; }
 
@@ -212,6 +213,7 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
 
 extern "C" void afx_destroy(afx_handle h) {
   if (!h) return;
+  prof_forget(h);
   for (void* p : h->allocs) (void)hipFree(p);
   for (auto& t : h->taps)
     if (t.second.p) (void)hipFree(t.second.p);
@@ -580,6 +582,88 @@ extern "C" int afx_tap(afx_handle h, const char* name, float* out, size_t cap, s
 }
 
 // ---------------------------------------------------------------------------------
+// per-kernel-class timing (bench.py's roofline leg): when profiling is on, every
+// launch of the forward is bracketed by hipEvents on the launch stream and summed per
+// class afterwards.  Off by default: the normal forward records nothing.
+// ---------------------------------------------------------------------------------
+enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_CONV0, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV, PC_MISC,
+                 PC_AASIST, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"gemm_kernel<128x128>", "gemm_kernel<128x64>", "conv0_kernel",
+                                           "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel", "conf_dwconv_kernel",
+                                           "misc", "aasist_head"};
+struct ProfRec { int cls; hipEvent_t a, b; double flops; };
+struct Profiler {
+  bool on = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  hipEvent_t ev() {
+    if (used == pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+};
+static std::unordered_map<afx_engine*, Profiler> g_prof;
+static thread_local Profiler* t_prof = nullptr;
+static void prof_forget(afx_engine* e) {
+  auto it = g_prof.find(e);
+  if (it == g_prof.end()) return;
+  for (hipEvent_t ev : it->second.pool) (void)hipEventDestroy(ev);
+  g_prof.erase(it);
+}
+
+template <class F>
+static const char* timed(int cls, double flops, hipStream_t s, F&& f) {
+  Profiler* p = t_prof;
+  if (!p || !p->on) return f();
+  hipEvent_t a = p->ev(), b = p->ev();
+  if (!a || !b) return "profiler: hipEventCreate failed";
+  (void)hipEventRecord(a, s);
+  const char* m = f();
+  (void)hipEventRecord(b, s);
+  p->recs.push_back({cls, a, b, flops});
+  return m;
+}
+static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) {
+  const double fl = 2.0 * g.M * g.N * (g.k_algo ? g.k_algo : g.K) * groups;
+  return timed(gemm_is_narrow(g.N) ? PC_GEMM64 : PC_GEMM128, fl, s, [&] { return launch_gemm(g, dt, groups, s); });
+}
+static const char* P_rownorm(const RowNormArgs& a, int dt, hipStream_t s) {
+  return timed(PC_ROWNORM, 0, s, [&] { return launch_rownorm(a, dt, s); });
+}
+
+extern "C" int afx_profile_begin(afx_handle h) {
+  if (!h) return fail("afx_profile_begin: null handle");
+  Profiler& p = g_prof[h];
+  p.on = true;
+  p.recs.clear();
+  p.used = 0;
+  return 0;
+}
+extern "C" int afx_profile_end(afx_handle h, int n, double* ms, double* flops, long long* launches) {
+  if (!h || n < PC_COUNT || !ms || !flops || !launches) return fail("afx_profile_end: need %d slots", (int)PC_COUNT);
+  Profiler& p = g_prof[h];
+  for (int i = 0; i < n; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
+  for (const ProfRec& r : p.recs) {
+    HIP_OK(hipEventSynchronize(r.b));
+    float t = 0;
+    HIP_OK(hipEventElapsedTime(&t, r.a, r.b));
+    ms[r.cls] += t;
+    flops[r.cls] += r.flops;
+    launches[r.cls] += 1;
+  }
+  p.on = false;
+  p.recs.clear();
+  p.used = 0;
+  return 0;
+}
+extern "C" int afx_profile_num_classes(void) { return PC_COUNT; }
+extern "C" const char* afx_profile_class_name(int c) { return c >= 0 && c < PC_COUNT ? kProfNames[c] : ""; }
+
+// ---------------------------------------------------------------------------------
 // forward pieces
 // ---------------------------------------------------------------------------------
 static GemmArgs plain_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, int K) {
@@ -601,6 +685,9 @@ static RowNormArgs plain_norm(const float* x, long ldx, int rows, int C, const f
   return a;
 }
 
+#define launch_gemm P_gemm
+#define launch_rownorm P_rownorm
+
 static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipStream_t s) {
   const int dt = e->dt;
   const int* T = w.T;
@@ -609,8 +696,10 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     return e->F("ssl.feature_extractor.conv_layers." + std::to_string(i) + leaf);
   };
   // layer 0: waveform -> (B,T0,512) operand type, LN + GELU fused
-  KOK(launch_conv0(wave, B, L, T[0], cf(0, ".0.weight"), cf(0, ".0.bias"), cf(0, ".2.1.weight"), cf(0, ".2.1.bias"),
-                   e->cfg.pre_emphasis, e->cfg.pre_emphasis_coef, w.bufA, dt, s));
+  KOK(timed(PC_CONV0, 2.0 * B * T[0] * kC * kConvK[0], s, [&] {
+    return launch_conv0(wave, B, L, T[0], cf(0, ".0.weight"), cf(0, ".0.bias"), cf(0, ".2.1.weight"),
+                        cf(0, ".2.1.bias"), e->cfg.pre_emphasis, e->cfg.pre_emphasis_coef, w.bufA, dt, s);
+  }));
   // layers 1..6: conv-as-GEMM (fp32 out) then LayerNorm + GELU
   void* in = w.bufA;
   void* out = w.bufB;
@@ -648,7 +737,7 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     g.out_f = w.x; g.ldo_f = kD; g.o_batch_rows = Tt; g.o_row_off = 0;
     g.out_h = w.xpad; g.ldo_h = kD; g.oh_batch_rows = Tt + kPosK; g.oh_row_off = kPosPad;
     KOK(launch_gemm(g, dt, 1, s));
-    KOK(launch_zero_pad_rows(w.xpad, B, Tt, kD, kPosPad, kPosK - kPosPad, s));
+    KOK(timed(PC_MISC, 0, s, [&] { return launch_zero_pad_rows(w.xpad, B, Tt, kD, kPosPad, kPosK - kPosPad, s); }));
   }
   if (tap(e, "proj", w.x, (size_t)M * kD, false, s)) return 1;
   // positional conv (grouped, k=128) + GELU, added to x in place
@@ -675,7 +764,7 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     q.bias = e->bqkv[l];
     q.out_h = w.qkv; q.ldo_h = 3 * kD;
     KOK(launch_gemm(q, dt, 1, s));
-    KOK(launch_mhsa(w.qkv, w.att, B, Tt, kH, dt, s));
+    KOK(timed(PC_MHSA, 4.0 * B * kH * (double)Tt * Tt * 64, s, [&] { return launch_mhsa(w.qkv, w.att, B, Tt, kH, dt, s); }));
     GemmArgs o = plain_gemm(w.att, kD, e->wo[l], kD, M, kD, kD);
     o.bias = e->F(P + "self_attn.out_proj.bias");
     o.resid = w.x; o.ldr = kD; o.out_f = w.x; o.ldo_f = kD;
@@ -713,7 +802,9 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
   ll.bias = e->F("LL.bias");
   ll.out_f = w.ll32; ll.ldo_f = E;
   KOK(launch_gemm(ll, dt, 1, s));
-  KOK(launch_conf_tokens(w.ll32, e->F("conformer.class_token"), e->conf_bn_scale, e->conf_bn_shift, B, T, E, w.xc, s));
+  KOK(timed(PC_MISC, 0, s, [&] {
+    return launch_conf_tokens(w.ll32, e->F("conformer.class_token"), e->conf_bn_scale, e->conf_bn_shift, B, T, E, w.xc, s);
+  }));
   if (tap(e, "tokens", w.xc, (size_t)M * E, false, s)) return 1;
   // K-padding columns of the operand buffers must read as zero
   HIP_OK(hipMemsetAsync(w.hc, 0, (size_t)M * Ep * 2, s));
@@ -731,10 +822,12 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     auto feed_forward = [&](const char* ff, void* w1, void* w2) -> const char* {
       if (const char* m = norm_to_h((std::string(ff) + ".fn.norm").c_str())) return m;
       GemmArgs a = plain_gemm(w.hc, Ep, w1, Ep, M, e->FF, Ep);
+      a.k_algo = E;
       a.bias = e->F(P + ff + ".fn.fn.net.0.bias"); a.act = ACT_SWISH;
       a.out_h = w.hid; a.ldo_h = e->FFp;
       if (const char* m = launch_gemm(a, dt, 1, s)) return m;
       GemmArgs c = plain_gemm(w.hid, e->FFp, w2, e->FFp, M, E, e->FFp);
+      c.k_algo = e->FF;
       c.bias = e->F(P + ff + ".fn.fn.net.3.bias"); c.alpha = 0.5f;
       c.resid = w.xc; c.ldr = E; c.out_f = w.xc; c.ldo_f = E;
       return launch_gemm(c, dt, 1, s);
@@ -743,23 +836,32 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     // attention
     KOK(norm_to_h("attn.norm"));
     GemmArgs q = plain_gemm(w.hc, Ep, K.wqkv, Ep, M, 3 * e->inner, Ep);
+    q.k_algo = E;
     q.out_f = w.qkv32; q.ldo_f = 3 * e->inner;
     KOK(launch_gemm(q, dt, 1, s));
-    KOK(launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
-                         e->F(P + "attn.fn.rel_pos_emb.weight"), 512, B, N, e->heads, e->dh, w.ao, Ep, dt, s));
+    KOK(timed(PC_CONF_ATTN, 6.0 * B * e->heads * (double)N * N * e->dh, s, [&] {
+      return launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
+                              e->F(P + "attn.fn.rel_pos_emb.weight"), 512, B, N, e->heads, e->dh, w.ao, Ep, dt, s);
+    }));
     GemmArgs o = plain_gemm(w.ao, Ep, K.wout, Ep, M, E, Ep);
+    o.k_algo = e->inner;
     o.bias = e->F(P + "attn.fn.to_out.bias");
     o.resid = w.xc; o.ldr = E; o.out_f = w.xc; o.ldo_f = E;
     KOK(launch_gemm(o, dt, 1, s));
     // conv module
     KOK(norm_to_h("conv.net.0"));
     GemmArgs p1 = plain_gemm(w.hc, Ep, K.pw1, Ep, M, 2 * e->C2, Ep);
+    p1.k_algo = E;
     p1.bias = e->F(P + "conv.net.2.bias");
     p1.out_f = w.glu32; p1.ldo_f = 2 * e->C2;
     KOK(launch_gemm(p1, dt, 1, s));
-    KOK(launch_conf_dwconv(w.glu32, 2 * e->C2, e->F(P + "conv.net.4.conv.weight"), e->F(P + "conv.net.4.conv.bias"),
-                           K.bn_scale, K.bn_shift, B, N, e->C2, e->ck, w.u, e->C2p, dt, s));
+    KOK(timed(PC_CONF_DWCONV, 2.0 * B * N * e->C2 * e->ck, s, [&] {
+      return launch_conf_dwconv(w.glu32, 2 * e->C2, e->F(P + "conv.net.4.conv.weight"),
+                                e->F(P + "conv.net.4.conv.bias"), K.bn_scale, K.bn_shift, B, N, e->C2, e->ck, w.u,
+                                e->C2p, dt, s);
+    }));
     GemmArgs p2 = plain_gemm(w.u, e->C2p, K.pw2, e->C2p, M, E, e->C2p);
+    p2.k_algo = e->C2;
     p2.bias = e->F(P + "conv.net.7.bias");
     p2.resid = w.xc; p2.ldr = E; p2.out_f = w.xc; p2.ldo_f = E;
     KOK(launch_gemm(p2, dt, 1, s));
@@ -772,14 +874,18 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
       if (tap(e, nm.c_str(), w.xc, (size_t)M * E, false, s)) return 1;
     }
   }
-  KOK(launch_small_linear(w.xc, (long)N * E, B, E, e->F("conformer.fc5.weight"), e->F("conformer.fc5.bias"), 2, logits, s));
+  KOK(timed(PC_MISC, 0, s, [&] {
+    return launch_small_linear(w.xc, (long)N * E, B, E, e->F("conformer.fc5.weight"), e->F("conformer.fc5.bias"), 2,
+                               logits, s);
+  }));
   return 0;
 }
 
 static int run_head(afx_engine* e, int B, int T, Ws& w, float* logits, hipStream_t s) {
   if (e->cfg.arch == AFX_ARCH_CONFORMER) return run_conformer(e, B, T, w, logits, s);
   if (e->cfg.arch == AFX_ARCH_XLSR_AASIST) {
-    if (const char* m = aasist_forward(e->aw, w.ssl_f, B, T, w.aa, logits, s)) return fail("%s", m);
+    if (const char* m = timed(PC_AASIST, 2.0 * B * 1.399e9 / 2, s, [&] { return aasist_forward(e->aw, w.ssl_f, B, T, w.aa, logits, s); }))
+      return fail("%s", m);
     if (e->taps_on) {
       if (tap(e, "e_S", w.aa.eS, (size_t)B * 42 * 64, false, s)) return 1;
       if (tap(e, "e_T", w.aa.eT, (size_t)B * (T / 3) * 64, false, s)) return 1;
@@ -789,6 +895,9 @@ static int run_head(afx_engine* e, int B, int T, Ws& w, float* logits, hipStream
   }
   return fail("afx_forward: this handle is an SSL feature extractor; use afx_ssl_forward");
 }
+
+#undef launch_gemm
+#undef launch_rownorm
 
 static int check_call(afx_handle h, const void* in, int B, int L, const void* out, void* ws) {
   if (!h || !in || !out || !ws) return fail("afx: null argument");
@@ -804,6 +913,7 @@ extern "C" int afx_forward(afx_handle h, const float* wave, int B, int L, float*
   const size_t needb = carve(h, B, L, 0, ws, &w);
   if (ws_bytes < needb) return fail("afx_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   hipStream_t s = (hipStream_t)stream;
+  t_prof = g_prof.count(h) ? &g_prof[h] : nullptr;
   if (run_trunk(h, wave, B, L, w, s)) return 1;
   return run_head(h, B, w.T[6], w, logits, s);
 }
@@ -815,6 +925,7 @@ extern "C" int afx_ssl_forward(afx_handle h, const float* wave, int B, int L, fl
   const size_t needb = carve(h, B, L, 0, ws, &w);
   if (ws_bytes < needb) return fail("afx_ssl_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   hipStream_t s = (hipStream_t)stream;
+  t_prof = g_prof.count(h) ? &g_prof[h] : nullptr;
   if (run_trunk(h, wave, B, L, w, s)) return 1;
   HIP_OK(hipMemcpyAsync(feats, w.ssl_f, (size_t)B * w.T[6] * kD * 4, hipMemcpyDeviceToDevice, s));
   return 0;
@@ -846,6 +957,7 @@ extern "C" int afx_head_forward(afx_handle h, const float* feats, int B, int T, 
   hipLaunchKernelGGL(f32_to_half_kernel, dim3(1024), dim3(256), 0, s, feats, (uint16_t*)w.ssl_h, n,
                      h->dt == AFX_DT_BF16 ? 1 : 0);
   HIP_OK(hipGetLastError());
+  t_prof = g_prof.count(h) ? &g_prof[h] : nullptr;
   return run_head(h, B, T, w, logits, s);
 }
 

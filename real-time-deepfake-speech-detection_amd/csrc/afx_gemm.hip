@@ -178,10 +178,12 @@ static const char* check_gemm(const GemmArgs& p) {
   return nullptr;
 }
 
+bool gemm_is_narrow(int N) { return N <= 64 || (N > 128 && N < 256 && N % 128 != 0); }
+
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s) {
   if (const char* e = check_gemm(p)) return e;
   hipError_t err;
-  const bool narrow = p.N <= 64 || (p.N > 128 && p.N < 256 && p.N % 128 != 0);
+  const bool narrow = gemm_is_narrow(p.N);
   if (dtype == DT_BF16)
     err = narrow ? launch_gemm_t<BF16, 128, 64>(p, groups, s) : launch_gemm_t<BF16, 128, 128>(p, groups, s);
   else

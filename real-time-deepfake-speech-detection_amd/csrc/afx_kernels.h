@@ -13,6 +13,7 @@ struct GemmArgs {
   const void* A;  // matrix-core operand type (bf16/fp16), K contiguous
   const void* W;  // [N][K] (nn.Linear layout), K contiguous
   int M, N, K;    // N is per group; K % 64 == 0
+  int k_algo;     // un-padded K for FLOP accounting (0: same as K); ignored by the kernel
   // A row m starts at (m / rpb) * a_batch + (m % rpb) * a_row   (elements)
   int rpb;
   long a_batch, a_row;
@@ -39,6 +40,7 @@ struct GemmArgs {
   int oh_batch_rows, oh_row_off;
 };
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
+bool gemm_is_narrow(int N);  // true: the 128x64 tile instance serves this N
 
 // ---- frontend / row kernels (afx_frontend.hip) ---------------------------------
 // conv layer 0 (Cin=1,k=10,s=5) + LayerNorm(512) + erf-GELU; optional pre-emphasis.
