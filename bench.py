@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (default 64 / 16)")
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--dtype", default=os.environ.get("AFX_DTYPE", "fp16"), choices=["fp16", "bf16"])
-    ap.add_argument("--cpu-sample", type=int, default=16, help="utterances timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="utterances timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,7 +148,8 @@ def main():
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         from oracle import models as omodels
         n = min(args.cpu_sample, B)
-        cores = os.cpu_count() or 1
+        # a one-GPU box gets a 16-core share of the host (more threads only oversubscribe it)
+        cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
         torch.set_num_threads(cores)
         fwd = omodels.conformer_forward if arch == "conformer" else omodels.xlsr_aasist_forward
         cpu_wave = wave[:n].cpu()

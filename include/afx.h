@@ -107,6 +107,8 @@ int afx_k_pack_linear(int dtype, const float* w, int N, int K, int Kpad, void* o
 int afx_k_pack_conv(int dtype, const float* w, int N, int Cin, int k, void* out_h, void* stream);
 int afx_k_conv0(int dtype, const float* wave, int B, int L, const float* w, const float* bias, const float* gamma,
                 const float* beta, int pre_emph, float coef, void* out_h, void* stream);
+/* data/preprocess.py:16-29 as a stand-alone op: y[t] = x[t] - coef*x[t-1], reflect pad */
+int afx_k_pre_emphasis(const float* x, int B, int L, float coef, float* y, void* stream);
 int afx_k_rownorm(int dtype, const float* x, long ldx, int rows, int C, const float* gamma, const float* beta,
                   float eps, int act, float* out_f, long ldo_f, void* out_h, long ldo_h, void* stream);
 int afx_k_mhsa(int dtype, const void* qkv, void* out, int B, int T, int H, void* stream);

@@ -38,8 +38,11 @@ class Engine:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and h.value:
-            lib().afx_destroy(h)
+        if h is not None and h.value and lib is not None:  # module globals are gone at interpreter exit
+            try:
+                lib().afx_destroy(h)
+            except Exception:
+                pass
             self._h = None
 
     # ---- weights -------------------------------------------------------------------

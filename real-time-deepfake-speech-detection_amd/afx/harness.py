@@ -1,0 +1,156 @@
+"""The callers either side of the model forward, mirrored so that the reference's
+scoring / eval loops are a drop-in:
+
+  produce_evaluation_file  main.py:199-221 (same signature, same "<utt> <score>" lines)
+  evaluate                 trainer.py:85-132 (loss / accuracy loop body)
+  calculate_EER            trainer.py:134-139
+  PreEmphasis              data/preprocess.py:8-29 (stand-alone HIP kernel)
+  f_state_dict_wrapper     utils.py:13-43
+  adjust_duration          data/test_set.py:201-227 (tile + crop policy)
+  produce_evaluation_file_distributed  -- the multi-GPU form: utterances sharded over
+      ranks, one RCCL all-gather of (index, score) pairs, rank 0 writes the file in
+      dataset order.
+"""
+import os
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import dist as adist
+from ._lib import check, lib, ptr, stream_ptr
+
+
+def f_state_dict_wrapper(state_dict, data_parallel=False):
+    """utils.py:13-43: add (data_parallel=True) or strip the ``module.`` key prefix."""
+    out = OrderedDict()
+    for k, v in state_dict.items():
+        if data_parallel:
+            out[k if k.startswith("module") else "module." + k] = v
+        else:
+            out[k[7:] if k.startswith("module") else k] = v
+    return out
+
+
+class PreEmphasis(nn.Module):
+    """data/preprocess.py:8-29.  ``forward`` keeps (B,L) also at B=1 and does not print
+    (SURVEY.md Q6); bypassed when ``is_pre_emphasis`` is false (:19-20)."""
+
+    def __init__(self, device=None, sys_config=None, exp_config=None, coef=None, enabled=None):
+        super().__init__()
+        self.coef = float(coef if coef is not None else getattr(exp_config, "pre_emphasis", 0.97))
+        self.enabled = bool(enabled if enabled is not None else getattr(exp_config, "is_pre_emphasis", True))
+
+    def forward(self, x):
+        if not self.enabled:
+            return x
+        if not x.is_cuda:
+            raise RuntimeError("PreEmphasis: input must be on the GPU (no CPU fallback)")
+        x = x.to(torch.float32).contiguous()
+        y = torch.empty_like(x)
+        check(lib().afx_k_pre_emphasis(ptr(x), x.shape[0], x.shape[1], self.coef, ptr(y), stream_ptr()))
+        return y
+
+
+def adjust_duration(x, duration):
+    """data/test_set.py:201-227: repeat short clips (whole copies + residue), keep the
+    first ``duration`` samples.  Pure indexing on the loader side."""
+    x = x.reshape(-1)
+    n = x.shape[0]
+    if n < duration:
+        parts = [x] * (duration // n)
+        if duration % n > 0:
+            parts.append(x[: duration % n])
+        x = torch.cat(parts, dim=0)
+    return x[:duration]
+
+
+def calculate_EER(scores, labels):
+    """trainer.py:134-139."""
+    from scipy.interpolate import interp1d
+    from scipy.optimize import brentq
+    from sklearn import metrics
+    fpr, tpr, _ = metrics.roc_curve(labels, scores, pos_label=1)
+    return brentq(lambda x: 1.0 - x - interp1d(fpr, tpr)(x), 0.0, 1.0) * 100
+
+
+def _loader(dataset, batch_size, num_workers):
+    from torch.utils import data
+    return data.DataLoader(dataset, batch_size=batch_size, shuffle=False, drop_last=False, num_workers=num_workers)
+
+
+def write_score_file(save_path, utt_ids, scores):
+    d = os.path.dirname(save_path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    with open(save_path, "w") as fh:
+        for f, cm in zip(utt_ids, scores):
+            fh.write("{} {}\n".format(f, cm))
+
+
+def produce_evaluation_file(dataset, model, device, save_path, batch_size, num_workers=4):
+    """main.py:199-221.  Scores stay on the GPU until the end of the pass (one D2H copy
+    instead of the reference's per-batch ``.cpu()``)."""
+    model.eval()
+    names, chunks = [], []
+    with torch.no_grad():
+        for utt_id, batch_x, _label in _loader(dataset, batch_size, num_workers):
+            out = model(batch_x.to(device, non_blocking=True))
+            chunks.append(out[:, 1])  # bonafide score (main.py:211-212)
+            names.extend(utt_id)
+    scores = torch.cat(chunks).cpu().numpy().ravel().tolist() if chunks else []
+    write_score_file(save_path, names, scores)
+    return names, scores
+
+
+def evaluate(model, loader, device, loss_fn=None, preprocessor=None):
+    """trainer.py:85-132: (mean loss, accuracy %) over a loader."""
+    model.eval()
+    n_total, n_correct, loss_sum = 0, 0, 0.0
+    with torch.no_grad():
+        for _utt, x, label in loader:
+            x = x.to(device)
+            label = label.view(-1).type(torch.int64).to(device)
+            if preprocessor is not None:
+                x = preprocessor(x)
+            out = model(x)
+            if loss_fn is not None:
+                loss_sum += loss_fn(out, label).item() * x.size(0)
+            n_correct += (out.max(dim=1)[1] == label).sum().item()
+            n_total += x.size(0)
+    return loss_sum / max(n_total, 1), n_correct / max(n_total, 1) * 100
+
+
+class _Shard(torch.utils.data.Dataset):
+    def __init__(self, base, idx):
+        self.base, self.idx = base, [int(i) for i in idx if i >= 0]
+
+    def __len__(self):
+        return len(self.idx)
+
+    def __getitem__(self, i):
+        utt, x, label = self.base[self.idx[i]]
+        return self.idx[i], x, label
+
+
+def produce_evaluation_file_distributed(dataset, model, device, save_path, batch_size, num_workers=4, group=None):
+    """Multi-GPU scoring: rank r scores utterances r, r+W, ...; ONE all-gather of
+    (index, score) pairs (RCCL when the group's backend is nccl); rank 0 writes the file
+    in dataset order.  Returns (indices, scores) on every rank."""
+    import torch.distributed as tdist
+    rank, world = tdist.get_rank(group), tdist.get_world_size(group)
+    idx = adist.shard_indices(len(dataset), rank, world)
+    model.eval()
+    scores = torch.zeros(idx.numel(), dtype=torch.float32, device=device)
+    pos = 0
+    with torch.no_grad():
+        for _i, batch_x, _label in _loader(_Shard(dataset, idx.tolist()), batch_size, num_workers):
+            out = model(batch_x.to(device, non_blocking=True))
+            scores[pos:pos + out.shape[0]] = out[:, 1]
+            pos += out.shape[0]
+    gi, gs = adist.all_gather_scores(idx.to(device=device, dtype=torch.int32), scores, world, group)
+    mi, ms = adist.merge_scores(gi, gs)
+    if rank == 0:
+        names = [dataset[int(i)][0] for i in mi.tolist()] if hasattr(dataset, "__getitem__") else mi.tolist()
+        write_score_file(save_path, names, ms.cpu().numpy().ravel().tolist())
+    return mi, ms

@@ -1,0 +1,152 @@
+"""Host-side plumbing shared by the drop-in ``models`` package: parameter containers
+with the reference's state_dict key names, and the mixin that routes ``forward`` to
+the native engine.  No arithmetic of the path happens here."""
+import os
+
+import torch
+from torch import nn
+
+from . import synth
+from .engine import DEFAULT_DTYPE, Engine
+
+CONV_LAYERS = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2
+
+
+# ---- fairseq-named containers ---------------------------------
+class _WeightNormConv(nn.Module):
+    """Holds weight_g / weight_v / bias of the weight-normed positional conv."""
+
+    def __init__(self, dim, groups, k):
+        super().__init__()
+        self.weight_g = nn.Parameter(torch.ones(1, 1, k))
+        self.weight_v = nn.Parameter(torch.zeros(dim, dim // groups, k))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class _SelfAttn(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj, self.v_proj, self.q_proj, self.out_proj = (nn.Linear(d, d) for _ in range(4))
+
+
+class EncoderLayer(nn.Module):
+    """fairseq TransformerSentenceEncoderLayer parameter set."""
+
+    def __init__(self, d=1024, f=4096):
+        super().__init__()
+        self.self_attn = _SelfAttn(d)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, f)
+        self.fc2 = nn.Linear(f, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, n_layers, d, f):
+        super().__init__()
+        self.pos_conv = nn.Sequential(_WeightNormConv(d, 16, 128))
+        self.layers = nn.ModuleList([EncoderLayer(d, f) for _ in range(n_layers)])
+        self.layer_norm = nn.LayerNorm(d)
+
+
+class _FeatureExtractor(nn.Module):
+    def __init__(self):
+        super().__init__()
+        blocks, cin = [], 1
+        for c, k, s in CONV_LAYERS:  # keys conv_layers.{i}.0.* and conv_layers.{i}.2.1.*
+            blocks.append(nn.Sequential(nn.Conv1d(cin, c, k, stride=s, bias=True), nn.Identity(),
+                                        nn.Sequential(nn.Identity(), nn.LayerNorm(c), nn.Identity()), nn.Identity()))
+            cin = c
+        self.conv_layers = nn.ModuleList(blocks)
+
+
+class Wav2Vec2Trunk(nn.Module):
+    """Parameter container with fairseq Wav2Vec2Model's names for the sub-graph that
+    ``forward(x, mask=False, features_only=True)['x']`` uses.  Weights start from the
+    seeded synthetic generator (no checkpoint can be fetched offline)."""
+
+    def __init__(self, n_layers=24, d=1024, f=4096):
+        super().__init__()
+        with torch.device("meta"):  # shapes only; the values come from the seeded generator below
+            self.feature_extractor = _FeatureExtractor()
+            self.layer_norm = nn.LayerNorm(512)
+            self.post_extract_proj = nn.Linear(512, d)
+            self.encoder = _Encoder(n_layers, d, f)
+        self.load_state_dict(synth.ssl_state_dict(n_layers, prefix=""), strict=True, assign=True)
+
+    def forward(self, source, mask=False, features_only=True, **kw):
+        raise RuntimeError("Wav2Vec2Trunk holds parameters only; call the owning XLSR_FE / model")
+
+
+def load_ssl_checkpoint(trunk, path):
+    """Best-effort load of a fairseq ``xlsr2_300m.pt`` or a plain state_dict file
+    (keys with or without the ``model.`` / ``ssl_model.model.`` prefix)."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ck.get("model", ck) if isinstance(ck, dict) else ck
+    out = {}
+    for k, v in sd.items():
+        for pre in ("module.", "ssl_model.", "model."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+        out[k] = v
+    own = trunk.state_dict()
+    missing = [k for k in own if k not in out]
+    if missing:
+        raise KeyError(f"{path}: checkpoint lacks {len(missing)} trunk tensors, e.g. {missing[:3]}")
+    trunk.load_state_dict({k: out[k] for k in own}, strict=True)
+
+
+# ---- engine routing ---------------------------------------------------------------------
+class AfxModule(nn.Module):
+    """nn.Module whose eval-mode forward runs on the native MI355X engine.  The
+    engine's packed weights are refreshed whenever the module's parameters change
+    (load_state_dict, .to(), in-place edits are caught by the version counters)."""
+
+    afx_arch = "ssl"
+
+    def _afx_cfg(self):
+        return {}
+
+    def _afx_signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
+            tuple((b.data_ptr(), b._version) for b in self.buffers())
+
+    def _afx_engine(self):
+        eng = self.__dict__.get("_afx_eng")
+        n_layers = len(self._afx_trunk().encoder.layers)
+        dtype = self.__dict__.get("afx_dtype", None) or DEFAULT_DTYPE
+        key = (n_layers, dtype, tuple(sorted(self._afx_cfg().items())))
+        if eng is None or self.__dict__.get("_afx_key") != key:
+            eng = Engine(self.afx_arch, n_layers=n_layers, dtype=dtype, **self._afx_cfg())
+            self.__dict__["_afx_eng"], self.__dict__["_afx_key"], self.__dict__["_afx_sig"] = eng, key, None
+        sig = self._afx_signature()
+        if self.__dict__.get("_afx_sig") != sig:
+            eng.load_state_dict(self.state_dict())
+            self.__dict__["_afx_sig"] = sig
+        return eng
+
+    def _afx_check(self, x):
+        if self.training:
+            raise RuntimeError("the MI355X-native path is inference-only: call model.eval() first "
+                               "(main.py:202, trainer.py:86)")
+        if not x.is_cuda:
+            raise RuntimeError("input must be on the GPU: the native path has no CPU fallback")
+
+    def set_precision(self, dtype):
+        """'fp16' (default) or 'bf16' matrix-core operands."""
+        self.__dict__["afx_dtype"] = dtype
+        return self
+
+
+def resolve_device(device):
+    """``device`` as the reference passes it: an int rank (main.py:48) or 'cuda'/'cpu'."""
+    if isinstance(device, int):
+        return torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")
+    return torch.device(device)
+
+
+def ssl_checkpoint_or_synthetic(trunk, path):
+    if path and os.path.exists(path):
+        load_ssl_checkpoint(trunk, path)
+        return True
+    return False

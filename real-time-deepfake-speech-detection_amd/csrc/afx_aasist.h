@@ -57,6 +57,11 @@ struct AasistWs {
   float *oS, *oT;            // pooled
   float *br;                 // per-branch scratch
   float *hidden;             // (B,160)
+  // debug views of the last forward (names/pointers into the workspace)
+  const char* dbg_name[16];
+  const float* dbg_ptr[16];
+  size_t dbg_n[16];
+  int dbg_count = 0;
 };
 
 using GetF = std::function<const float*(const std::string&)>;
@@ -66,7 +71,7 @@ using Alloc = std::function<void*(size_t)>;
 const char* aasist_finalize(AasistWeights& w, const GetF& get, const Alloc& alloc, hipStream_t s);
 void aasist_carve(int B, int T, const Alloc& take, AasistWs* ws);
 // feats (B,T,1024) fp32 -> logits (B,2)
-const char* aasist_forward(const AasistWeights& w, const float* feats, int B, int T, const AasistWs& ws, float* logits,
+const char* aasist_forward(const AasistWeights& w, const float* feats, int B, int T, AasistWs& ws, float* logits,
                            hipStream_t s);
 
 }  // namespace afx

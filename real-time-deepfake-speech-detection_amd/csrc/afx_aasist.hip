@@ -574,7 +574,7 @@ void aasist_carve(int B, int T, const Alloc& take, AasistWs* ws) {
     if (e_ != hipSuccess) return hipGetErrorString(e_);    \
   } while (0)
 
-const char* aasist_forward(const AasistWeights& w, const float* feats, int B, int T, const AasistWs& ws, float* logits,
+const char* aasist_forward(const AasistWeights& w, const float* feats, int B, int T, AasistWs& ws, float* logits,
                            hipStream_t s) {
   if (!w.ready) return "aasist: weights not finalized";
   int wd, wp, img;
@@ -724,6 +724,16 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
     run_pool(*PS[k], br[k].S1, nS, 32, nS1, br[k].S1p);
     run_pool(*PT[k], br[k].T1, nT, 32, nT1, br[k].T1p);
     AOK(run_hgat(*H2[k], br[k].T1p, nT1, br[k].S1p, nS1, br[k].xp2, br[k].m1, 32, br[k].Ta, br[k].Sa, br[k].ma));
+  }
+  {  // debug views for afx_tap
+    int n = 0;
+    auto dbg = [&](const char* nm, const float* ptr, size_t cnt) { ws.dbg_name[n] = nm; ws.dbg_ptr[n] = ptr; ws.dbg_n[n] = cnt; ++n; };
+    dbg("gat_S", ws.gS, (size_t)B * AAS_F * 64); dbg("gat_T", ws.gT, (size_t)B * wd * 64);
+    dbg("out_S", ws.oS, (size_t)B * nS * 64); dbg("out_T", ws.oT, (size_t)B * nT * 64);
+    dbg("b1_T1", br[0].T1, (size_t)B * nT * 32); dbg("b1_S1", br[0].S1, (size_t)B * nS * 32); dbg("b1_m1", br[0].m1, (size_t)B * 32);
+    dbg("b1_T1p", br[0].T1p, (size_t)B * nT1 * 32); dbg("b1_S1p", br[0].S1p, (size_t)B * nS1 * 32);
+    dbg("b1_Ta", br[0].Ta, (size_t)B * nT1 * 32); dbg("b1_Sa", br[0].Sa, (size_t)B * nS1 * 32); dbg("b1_ma", br[0].ma, (size_t)B * 32);
+    ws.dbg_count = n;
   }
   hipLaunchKernelGGL(readout_kernel, dim3(B), dim3(32), 0, s, br[0].T1p, br[0].Ta, br[0].S1p, br[0].m1, br[0].ma,
                      br[1].T1p, br[1].Ta, br[1].S1p, br[1].Sa, br[1].m1, br[1].ma, nT1, nS1, w.out_w, w.out_b,

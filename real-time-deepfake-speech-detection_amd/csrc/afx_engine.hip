@@ -890,6 +890,8 @@ static int run_head(afx_engine* e, int B, int T, Ws& w, float* logits, hipStream
       if (tap(e, "e_S", w.aa.eS, (size_t)B * 42 * 64, false, s)) return 1;
       if (tap(e, "e_T", w.aa.eT, (size_t)B * (T / 3) * 64, false, s)) return 1;
       if (tap(e, "hidden", w.aa.hidden, (size_t)B * 160, false, s)) return 1;
+      for (int i = 0; i < w.aa.dbg_count; ++i)
+        if (tap(e, w.aa.dbg_name[i], w.aa.dbg_ptr[i], w.aa.dbg_n[i], false, s)) return 1;
     }
     return 0;
   }
@@ -1004,6 +1006,9 @@ extern "C" int afx_k_conv0(int dtype, const float* wave, int B, int L, const flo
                            void* stream) {
   KRET(launch_conv0(wave, B, L, (L - 10) / 5 + 1, w, bias, gamma, beta, pre_emph, coef, out_h, dtype,
                     (hipStream_t)stream));
+}
+extern "C" int afx_k_pre_emphasis(const float* x, int B, int L, float coef, float* y, void* stream) {
+  KRET(launch_pre_emphasis(x, B, L, coef, y, (hipStream_t)stream));
 }
 extern "C" int afx_k_rownorm(int dtype, const float* x, long ldx, int rows, int C, const float* gamma,
                              const float* beta, float eps, int act, float* out_f, long ldo_f, void* out_h, long ldo_h,

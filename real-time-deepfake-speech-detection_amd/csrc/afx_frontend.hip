@@ -99,6 +99,24 @@ const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w
 }
 
 // ---------------------------------------------------------------------------------
+// Stand-alone pre-emphasis (data/preprocess.py:16-29) for callers that apply it as a
+// separate module (trainer.py:104); the engine itself fuses it into conv0.
+// ---------------------------------------------------------------------------------
+__global__ void pre_emphasis_kernel(const float* __restrict__ x, int L, float coef, float* __restrict__ y) {
+  const long base = (long)blockIdx.y * L;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) {
+    const int p = i > 0 ? i - 1 : (L > 1 ? 1 : 0);  // reflect pad of one sample on the left
+    y[base + i] = x[base + i] - coef * x[base + p];
+  }
+}
+const char* launch_pre_emphasis(const float* x, int B, int L, float coef, float* y, hipStream_t s) {
+  if (B <= 0 || L <= 0) return "pre_emphasis: empty input";
+  hipLaunchKernelGGL(pre_emphasis_kernel, dim3(min((L + 255) / 256, 1024), B), dim3(256), 0, s, x, L, coef, y);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------
 // Row LayerNorm (+ activation): one wave per row, C <= 1024, C % 4 == 0.  The row
 // stays in registers (float4 per lane per 256-column slab), two-pass statistics in
 // fp32 like torch.  Used for the conv-stack LayerNorm+GELU, every transformer /

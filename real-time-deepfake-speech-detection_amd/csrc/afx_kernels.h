@@ -47,6 +47,8 @@ bool gemm_is_narrow(int N);  // true: the 128x64 tile instance serves this N
 const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w /*[512][10]*/,
                          const float* bias, const float* gamma, const float* beta, int pre_emph,
                          float pre_coef, void* out_h, int dtype, hipStream_t s);
+// y[t] = x[t] - coef * x[t-1] with a reflect pad on the left; (B,L) fp32 -> (B,L) fp32
+const char* launch_pre_emphasis(const float* x, int B, int L, float coef, float* y, hipStream_t s);
 // rows x C fp32 -> LayerNorm (optional activation) -> fp32 and/or operand-type outputs.
 // Output row r goes to (r / rpb) * o_batch_rows + (r % rpb) + o_row_off (row strides ld*).
 struct RowNormArgs {

@@ -120,7 +120,13 @@ def gen_backend():
     from models.xlsr_aasist import XLSR_AASIST  # the reference's own class
     sys.path.pop(0)
     model = XLSR_AASIST(device="cpu").eval()
-    head = synth.aasist_head_state_dict()
+    # "lively" head: the seeded synthetic head with its matrices scaled by 1.5 so that graph
+    # nodes differ from each other and the GraphPool scores spread over (0.05, 0.9) instead
+    # of sitting within 1e-6 of one another (top-k order would then be rounding noise).
+    head = {}
+    for k, v in synth.aasist_head_state_dict().items():
+        lively = (k.endswith(".weight") and v.ndim >= 2 and not k.startswith("LL")) or "att_weight" in k
+        head[k] = v * 1.5 if lively else v
     missing, unexpected = model.load_state_dict(head, strict=False)
     assert not unexpected and not missing, (missing, unexpected)
     out = {f"sd.{k}": v.numpy() for k, v in head.items()}
@@ -128,12 +134,31 @@ def gen_backend():
     model.GAT_layer_S.register_forward_hook(lambda mod, i, o: taps.__setitem__("e_S", i[0].detach().clone()))
     model.GAT_layer_T.register_forward_hook(lambda mod, i, o: taps.__setitem__("e_T", i[0].detach().clone()))
     model.out_layer.register_forward_hook(lambda mod, i, o: taps.__setitem__("hidden", i[0].detach().clone()))
+    gaps = []
+
+    def pool_hook(mod, i, o):  # smallest score gap that decides membership / order of the kept nodes
+        s = torch.sigmoid(mod.proj(i[0])).squeeze(-1)
+        v, _ = torch.sort(s, dim=1, descending=True)
+        n = o.shape[1]
+        gaps.append((v[:, :n] - v[:, 1:n + 1]).min().item())
+    for nm in ("pool_S", "pool_T", "pool_hS1", "pool_hT1", "pool_hS2", "pool_hT2"):
+        getattr(model, nm).register_forward_hook(pool_hook)
     for tag, B, T in (("t199", 2, 199), ("t49", 2, 49), ("t201", 1, 201)):
-        g = torch.Generator().manual_seed(100 + T)
-        feats = torch.randn(B, T, 1024, generator=g)
-        _StubSSL.feats = feats
-        with torch.no_grad():
-            logits = model(torch.zeros(B, 16))
+        # GraphPool is discontinuous: keep fixtures whose every top-k decision has a margin
+        # (>= 3e-5, ~30x the 1e-6 score error of an fp32 re-implementation) above fp32 summation-order noise, so the test pins arithmetic, not luck
+        for seed in range(100 + T, 100 + T + 4000, 7):
+            g = torch.Generator().manual_seed(seed)
+            feats = torch.randn(B, T, 1024, generator=g)
+            _StubSSL.feats = feats
+            gaps.clear()
+            with torch.no_grad():
+                logits = model(torch.zeros(B, 16))
+            if min(gaps) >= 3e-5:
+                break
+        else:
+            raise RuntimeError("no well-conditioned fixture found")
+        print(tag, "seed", seed, "min top-k margin %.2e" % min(gaps))
+        out[f"{tag}.margin"] = np.float64(min(gaps))
         out[f"{tag}.feats"] = feats.numpy()
         out[f"{tag}.logits"] = logits.numpy()
         for k, v in taps.items():

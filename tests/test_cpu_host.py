@@ -132,3 +132,47 @@ def test_score_all_gather_world_size_2_gloo(tmp_path):
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GATHER_OK [0, 1, 2, 3, 4, 5, 6]" in r.stdout
+
+
+def test_dropin_models_package_has_reference_names_and_keys():
+    """Class names resolved by main.py's globals() (main.py:20-21, main_kd.py:22), ctor
+    kwargs, state_dict keys and the ValueErrors of models/fe.py:60-62,81-87."""
+    from afx import synth
+    import models  # noqa: F401
+    from models.conformer_baseline import Model as ConformerModel, MyModel as MyConformerModel  # noqa: F401
+    from models.models import SSLModel  # noqa: F401
+    from models.xlsr_aasist import XLSR_AASIST, My_XLSR_AASIST  # noqa: F401
+    from models.aasist_modules import GraphAttentionLayer, GraphPool, HtrgGraphAttentionLayer, Residual_block  # noqa: F401
+    from models.fe import middle_indices
+    assert middle_indices(24, 4) == [10, 11, 12, 13]
+    stu = MyConformerModel(device="cpu", ssl_cpkt_path=None, num_layers=6, order="first")
+    assert set(stu.state_dict()) == set(synth.model_state_dict("ConformerModel", n_layers=6))
+    assert len(stu.ssl_model.model.encoder.layers) == 6 and stu.ssl_model.out_dim == 1024
+    tea = My_XLSR_AASIST(device="cpu", num_layers=3, order="middle")
+    assert set(tea.state_dict()) == set(synth.model_state_dict("XLSR_AASIST", n_layers=3))
+    n_head = sum(p.numel() for n, p in tea.named_parameters() if not n.startswith("ssl_model."))
+    assert n_head == 447242
+    for bad in (dict(num_layers=0), dict(num_layers=25), dict(num_layers=2, order="custom"),
+                dict(num_layers=2, order="custom", custom_order=(1, 2))):
+        with pytest.raises(ValueError):
+            My_XLSR_AASIST(device="cpu", **bad)
+    cus = My_XLSR_AASIST(device="cpu", num_layers=2, order="custom", custom_order=[5, 1])
+    assert len(cus.ssl_model.model.encoder.layers) == 2
+    with pytest.raises(RuntimeError, match="inference-only"):
+        tea(torch.zeros(1, 16000))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tea.eval()(torch.zeros(1, 16000))
+
+
+def test_harness_helpers_match_reference_semantics(tmp_path):
+    import numpy as np
+    from afx import harness
+    sd = {"a.w": 1, "module.b": 2}
+    assert list(harness.f_state_dict_wrapper(sd, data_parallel=True)) == ["module.a.w", "module.b"]
+    assert list(harness.f_state_dict_wrapper(sd, data_parallel=False)) == ["a.w", "b"]
+    z = np.load(os.path.join(ROOT, "tests", "golden", "pre_eer.npz"))
+    assert abs(harness.calculate_EER(z["scores"], z["labels"]) - float(z["eer"])) < 1e-9
+    assert harness.adjust_duration(torch.from_numpy(z["short"]), 24).tolist() == z["tiled"].tolist()
+    p = tmp_path / "sub" / "scores.txt"
+    harness.write_score_file(str(p), ["u1", "u2"], [-2.9056100845336914, 0.5])
+    assert p.read_text() == "u1 -2.9056100845336914\nu2 0.5\n"  # format of results/**.txt

@@ -89,15 +89,72 @@ def test_backend_vs_reference_forward(tag, T):
     np.testing.assert_allclose(got, z[tag + ".logits"], rtol=0, atol=1e-3)
 
 
-def test_teacher_model_scores_match_oracle():
-    """XLSR_AASIST end to end (2-layer trunk to keep the CPU oracle quick), B=5."""
+def test_teacher_model_end_to_end():
+    """XLSR_AASIST end to end (2-layer trunk to keep the CPU oracle quick), B=8.
+
+    Contract, in three parts (DESIGN.md "Numerics"):
+      1. the fp32 back-end is exact: fed the ORACLE's SSL features it reproduces the
+         oracle logits to 1e-5 (so every top-k decision agrees);
+      2. the fp16 trunk is within 2e-3 relative L2 of the fp32 trunk;
+      3. end to end the scores are within 1e-3 wherever no GraphPool decision flips.  The
+         reference's top-k is discontinuous and, with a random-init head, node scores sit
+         ~1e-5 apart, so the 8e-4 trunk rounding flips a decision on some utterances and
+         moves a logit by ~1e-2 there: bounded at 3e-2, and the median must hold 1e-3.
+    """
     from afx import engine, synth
     from oracle import models
     sd = synth.model_state_dict("XLSR_AASIST", n_layers=2)
-    wave = synth.waveforms(5, 64000, batch_idx=2)
-    ref = models.xlsr_aasist_forward(sd, wave)
+    wave = synth.waveforms(8, 64000, batch_idx=2)
+    taps = {}
+    ref = models.xlsr_aasist_forward(sd, wave, taps=taps)
     eng = engine.Engine("xlsr_aasist", n_layers=2, dtype="fp16")
     eng.load_state_dict(sd)
+    eng.enable_taps()
+    exact = eng.head(taps["ssl"].cuda()).cpu()
+    assert (exact - ref).abs().max().item() <= 1e-5
     got = eng.forward(wave.cuda()).cpu()
-    err = (got - ref).abs().max().item()
-    assert err <= 1e-3, f"max |dlogit| {err:.3e}\n{got}\n{ref}"
+    ssl = eng.tap("ssl").cpu().reshape(taps["ssl"].shape)
+    assert ((ssl - taps["ssl"]).norm() / taps["ssl"].norm()).item() < 2e-3
+    err = (got - ref).abs().max(dim=1)[0]
+    print("teacher per-utterance |dlogit|:", [f"{e:.1e}" for e in err.tolist()])
+    assert err.median().item() <= 1e-3
+    assert err.max().item() <= 3e-2
+
+
+def test_dropin_models_package_teacher_and_student():
+    """The reference-named classes: construct, load a reference-format state_dict (with
+    the DDP 'module.' prefix handled as utils.py:13-43 does), eval forward on the GPU."""
+    from afx import synth
+    from afx.harness import f_state_dict_wrapper
+    from models.conformer_baseline import MyModel
+    from models.xlsr_aasist import My_XLSR_AASIST
+    from oracle import models as omodels
+    wave = synth.waveforms(3, 16000, batch_idx=5)
+    # student: first-2 trunk + 2 Conformer blocks
+    stu = MyModel(device="cuda", ssl_cpkt_path=None, num_layers=2, order="first", n_encoders=2).to("cuda").eval()
+    sd = synth.model_state_dict("ConformerModel", n_layers=2, n_encoders=2)
+    ck = {"module." + k: v for k, v in sd.items()}  # as saved from a DDP-wrapped model (main.py:176-179)
+    stu.load_state_dict(f_state_dict_wrapper(ck, data_parallel=False))
+    with torch.no_grad():
+        got = stu(wave.cuda()).cpu()
+        got3 = stu(wave.cuda().unsqueeze(-1)).cpu()
+    ref = omodels.conformer_forward(sd, wave)
+    assert (got - ref).abs().max().item() <= 1e-3
+    assert torch.equal(got, got3)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        stu.train()(wave.cuda())
+    # teacher with a truncated trunk; weights are whatever the constructor drew (default
+    # torch init for the head, like the reference) -> compare against the oracle on ITS state_dict
+    tea = My_XLSR_AASIST(device="cuda", num_layers=1, order="last").to("cuda").eval()
+    assert len(tea.ssl_model.model.encoder.layers) == 1 and tea.ssl_model.out_dim == 1024
+    own = {k: v.detach().cpu() for k, v in tea.state_dict().items()}
+    with torch.no_grad():
+        feats = tea.ssl_model.extract_feat(wave.cuda()).cpu()
+        got = tea(wave.cuda()).cpu()
+    ssl, head = omodels.split(own)
+    from oracle import aasist as oa, ssl_trunk as ot
+    ref_feats = ot.ssl_forward(ssl, wave)
+    assert ((feats - ref_feats).norm() / ref_feats.norm()).item() < 2e-3
+    assert got.shape == (3, 2) and bool(torch.isfinite(got).all())
+    exact = tea._afx_engine().head(ref_feats.cuda()).cpu()
+    assert (exact - oa.aasist_backend(head, ref_feats)).abs().max().item() <= 1e-5
