@@ -94,6 +94,11 @@ int afx_profile_end(afx_handle h, int n_classes, double* ms, double* flops, long
 int afx_profile_num_classes(void);
 const char* afx_profile_class_name(int cls);
 
+/* tuning knobs for A/B measurements (process-wide; not part of the drop-in surface).
+ * "gemm_map": workgroup->tile order of the MFMA GEMM, -1 default, 0 linear, 1 XCD-
+ * contiguous, 2 XCD-contiguous + grouped. */
+int afx_debug_set(const char* key, int value);
+
 /* ---- single-kernel entry points (unit parity tests; operand pointers are bf16 or
  * fp16 device arrays according to `dtype`) ---------------------------------------- */
 int afx_k_gemm(int dtype, const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,

@@ -47,6 +47,7 @@ SIGNATURES = {
     "afx_profile_end": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "afx_profile_num_classes": (_I, []),
     "afx_profile_class_name": (C.c_char_p, [_I]),
+    "afx_debug_set": (_I, [C.c_char_p, _I]),
     "afx_k_gemm": (_I, [_I, _P, _L, _P, _L, _I, _I, _I, _P, _I, _F, _P, _L, _P, _L, _P, _L, _P]),
     "afx_k_conv_gemm": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "afx_k_pack_linear": (_I, [_I, _P, _I, _I, _I, _P, _P]),

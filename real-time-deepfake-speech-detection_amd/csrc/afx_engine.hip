@@ -586,11 +586,11 @@ extern "C" int afx_tap(afx_handle h, const char* name, float* out, size_t cap, s
 // launch of the forward is bracketed by hipEvents on the launch stream and summed per
 // class afterwards.  Off by default: the normal forward records nothing.
 // ---------------------------------------------------------------------------------
-enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_CONV0, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV, PC_MISC,
-                 PC_AASIST, PC_COUNT };
-static const char* kProfNames[PC_COUNT] = {"gemm_kernel<128x128>", "gemm_kernel<128x64>", "conv0_kernel",
-                                           "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel", "conf_dwconv_kernel",
-                                           "misc", "aasist_head"};
+enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_CONV0, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV,
+                 PC_MISC, PC_AASIST, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"gemm_kernel<128x128>", "gemm_kernel<128x64>", "gemm_kernel<256x256>",
+                                           "conv0_kernel", "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel",
+                                           "conf_dwconv_kernel", "misc", "aasist_head"};
 struct ProfRec { int cls; hipEvent_t a, b; double flops; };
 struct Profiler {
   bool on = false;
@@ -629,7 +629,8 @@ static const char* timed(int cls, double flops, hipStream_t s, F&& f) {
 }
 static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) {
   const double fl = 2.0 * g.M * g.N * (g.k_algo ? g.k_algo : g.K) * groups;
-  return timed(gemm_is_narrow(g.N) ? PC_GEMM64 : PC_GEMM128, fl, s, [&] { return launch_gemm(g, dt, groups, s); });
+  static const int cls[3] = {PC_GEMM128, PC_GEMM64, PC_GEMM256};
+  return timed(cls[gemm_tile_of(g, groups)], fl, s, [&] { return launch_gemm(g, dt, groups, s); });
 }
 static const char* P_rownorm(const RowNormArgs& a, int dt, hipStream_t s) {
   return timed(PC_ROWNORM, 0, s, [&] { return launch_rownorm(a, dt, s); });
@@ -1006,6 +1007,18 @@ extern "C" int afx_k_conv0(int dtype, const float* wave, int B, int L, const flo
                            void* stream) {
   KRET(launch_conv0(wave, B, L, (L - 10) / 5 + 1, w, bias, gamma, beta, pre_emph, coef, out_h, dtype,
                     (hipStream_t)stream));
+}
+extern "C" int afx_debug_set(const char* key, int value) {
+  if (!key) return fail("afx_debug_set: null key");
+  if (!strcmp(key, "gemm_map")) {
+    gemm_set_map_mode(value);
+    return 0;
+  }
+  if (!strcmp(key, "gemm_tile")) {
+    gemm_set_tile(value);
+    return 0;
+  }
+  return fail("afx_debug_set: unknown key '%s'", key);
 }
 extern "C" int afx_k_pre_emphasis(const float* x, int B, int L, float coef, float* y, void* stream) {
   KRET(launch_pre_emphasis(x, B, L, coef, y, (hipStream_t)stream));

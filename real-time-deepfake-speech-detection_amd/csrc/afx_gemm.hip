@@ -23,22 +23,51 @@
 
 namespace afx {
 
-template <class HT, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+// WR x WC waves per workgroup; each wave owns a (BM/WR) x (BN/WC) block of the tile.
+template <class HT, int BM, int BN, int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
   typedef typename HT::V4 V4;
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int NW = WR * WC;
+  constexpr int WM = BM / WR, WN = BN / WC;
   constexpr int MT = WM / 16, NT = WN / 16;
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
-  constexpr int AI = BM / 32, WI = BN / 32;  // LDS-DMA instructions per thread per tile
+  constexpr int AI = BM / (8 * NW), WI = BN / (8 * NW);  // LDS-DMA instructions per thread per tile
+  static_assert(AI >= 1 && WI >= 1, "tile too small for the wave count");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WC, wc = wave % WC;
   const int g = blockIdx.z;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // ---- workgroup -> tile mapping (speed only; any mapping is correct) ----------------
+  // Workgroups are dealt round-robin over the 8 XCDs (private 4-MB L2 each).  map 1/2
+  // give every XCD a contiguous run of the logical tile order, so tiles that share an A
+  // row-panel (all N-tiles of one M-tile) or a W panel meet in ONE L2 instead of being
+  // re-fetched by up to 8 of them; map 2 additionally walks the tiles in GROUP_M x nN
+  // super-tiles so both panels of the working set stay L2-resident.
+  int pm, pn;
+  {
+    const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
+    const int nwg = nM * nN;
+    int L = blockIdx.x;
+    if (p.map_mode >= 1) {
+      const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);  // bijective for any nwg
+    }
+    if (p.map_mode == 2) {
+      constexpr int GM = 8;
+      const int width = GM * nN, grp = L / width, first = grp * GM;
+      const int gsz = nM - first < GM ? nM - first : GM;
+      pm = first + (L % width) % gsz;
+      pn = (L % width) / gsz;
+    } else {
+      pm = L / nN;
+      pn = L % nN;
+    }
+  }
+  const int m0 = pm * BM, n0 = pn * BN;
 
   const T* Ag = (const T*)p.A + (long)g * p.g_a;
   const T* Wg = (const T*)p.W + (long)g * p.g_w;
@@ -48,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const T* w_src[WI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    const int row = (i * 4 + wave) * 8 + (lane >> 3);
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
@@ -56,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
-    const int row = (i * 4 + wave) * 8 + (lane >> 3);
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     int n = n0 + row;
     n = n < p.N ? n : p.N - 1;
@@ -78,12 +107,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < AI; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + ka),
-                                       (__attribute__((address_space(3))) void*)(base + (i * 4 + wave) * 1024),
+                                       (__attribute__((address_space(3))) void*)(base + (i * NW + wave) * 1024),
                                        16, 0, 0);
 #pragma unroll
     for (int i = 0; i < WI; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + (i * 4 + wave) * 1024),
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + (i * NW + wave) * 1024),
                                        16, 0, 0);
   };
 
@@ -107,10 +136,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
 #pragma unroll
       for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
     }
   }
 
@@ -152,20 +183,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
-template <class HT, int BM, int BN>
+template <class HT, int BM, int BN, int WR, int WC>
 static hipError_t launch_gemm_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<HT, BM, BN>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<HT, BM, BN, WR, WC>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, groups);
-  hipLaunchKernelGGL((gemm_kernel<HT, BM, BN>), grid, dim3(256), lds, s, p);
+  dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
+  hipLaunchKernelGGL((gemm_kernel<HT, BM, BN, WR, WC>), grid, dim3(64 * WR * WC), lds, s, p);
   return hipGetLastError();
 }
+
+// tuning knobs for A/B runs (tools/bench_gemm.py); -1 = use the defaults below
+static int g_map_override = -1;
+static int g_tile_override = -1;  // 0: 128x128 / 4 waves, 1: 256x256 / 8 waves
+void gemm_set_map_mode(int m) { g_map_override = m; }
+void gemm_set_tile(int t) { g_tile_override = t; }
 
 // Host-side shape contract; anything else is a programming error in the caller.
 static const char* check_gemm(const GemmArgs& p) {
@@ -180,14 +217,30 @@ static const char* check_gemm(const GemmArgs& p) {
 
 bool gemm_is_narrow(int N) { return N <= 64 || (N > 128 && N < 256 && N % 128 != 0); }
 
-const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s) {
-  if (const char* e = check_gemm(p)) return e;
+// Which tile instance serves a problem: 0 = 128x128, 1 = 128x64, 2 = 256x256.
+// 256x256 tiles halve the operand bytes per FLOP (the per-CU L2->LDS rate is what bounds
+// this kernel) but quantise badly at M = B*199: measured faster only for the conv layers
+// (huge M, N = 512) and the K = 4096 FFN product (tools/bench_gemm.py, profiles/).
+int gemm_tile_of(const GemmArgs& p, int groups) {
+  if (gemm_is_narrow(p.N)) return 1;
+  const bool big_auto = p.N <= 1024 && (long)p.M * p.K >= 12736L * 2048;
+  const bool big = groups == 1 && (g_tile_override >= 0 ? g_tile_override == 1 : big_auto);
+  return big ? 2 : 0;
+}
+
+const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t s) {
+  if (const char* e = check_gemm(p_in)) return e;
+  GemmArgs p = p_in;
+  p.map_mode = g_map_override >= 0 ? g_map_override : 2;
   hipError_t err;
-  const bool narrow = gemm_is_narrow(p.N);
+  const int tile = gemm_tile_of(p, groups);
+  const bool narrow = tile == 1, big = tile == 2;
   if (dtype == DT_BF16)
-    err = narrow ? launch_gemm_t<BF16, 128, 64>(p, groups, s) : launch_gemm_t<BF16, 128, 128>(p, groups, s);
+    err = narrow ? launch_gemm_t<BF16, 128, 64, 2, 2>(p, groups, s)
+                 : big ? launch_gemm_t<BF16, 256, 256, 2, 4>(p, groups, s) : launch_gemm_t<BF16, 128, 128, 2, 2>(p, groups, s);
   else
-    err = narrow ? launch_gemm_t<FP16, 128, 64>(p, groups, s) : launch_gemm_t<FP16, 128, 128>(p, groups, s);
+    err = narrow ? launch_gemm_t<FP16, 128, 64, 2, 2>(p, groups, s)
+                 : big ? launch_gemm_t<FP16, 256, 256, 2, 4>(p, groups, s) : launch_gemm_t<FP16, 128, 128, 2, 2>(p, groups, s);
   return err == hipSuccess ? nullptr : hipGetErrorString(err);
 }
 

@@ -38,9 +38,13 @@ struct GemmArgs {
   // unpadded while the operand copy feeds the time-padded positional-conv buffer)
   int o_batch_rows, o_row_off;
   int oh_batch_rows, oh_row_off;
+  int map_mode;  // workgroup->tile order, set by launch_gemm (0 linear, 1 XCD-contiguous, 2 + grouped)
 };
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
 bool gemm_is_narrow(int N);  // true: the 128x64 tile instance serves this N
+int gemm_tile_of(const GemmArgs& p, int groups);  // 0: 128x128, 1: 128x64, 2: 256x256 instance
+void gemm_set_map_mode(int m);  // A/B knob: -1 default, else force map_mode
+void gemm_set_tile(int t);      // A/B knob: -1 default, 0: 128x128 tile, 1: 256x256 tile
 
 // ---- frontend / row kernels (afx_frontend.hip) ---------------------------------
 // conv layer 0 (Cin=1,k=10,s=5) + LayerNorm(512) + erf-GELU; optional pre-emphasis.

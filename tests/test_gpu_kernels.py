@@ -54,6 +54,29 @@ def test_gemm_epilogues(K, dtype, M, N, K_):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("tile", [0, 1])
+def test_gemm_tile_variants_agree_with_reference(K, dtype, tile):
+    """Both tile instances (128x128 / 4 waves, 256x256 / 8 waves) and every workgroup->tile
+    mapping must give the same numbers; M, N tails included."""
+    from afx._lib import check, lib
+    g = torch.Generator().manual_seed(11)
+    M, N, K_ = 1000, 768, 1536
+    A = torch.randn(M, K_, generator=g).to(_td(dtype))
+    W = (torch.randn(N, K_, generator=g) / math.sqrt(K_)).to(_td(dtype))
+    bias = torch.randn(N, generator=g)
+    ref = F.gelu(A.float() @ W.float().t() + bias)
+    try:
+        check(lib().afx_debug_set(b"gemm_tile", tile))
+        for mode in (0, 1, 2):
+            check(lib().afx_debug_set(b"gemm_map", mode))
+            of, _ = K.gemm(dtype, A.cuda(), W.cuda(), bias=bias.cuda(), act="gelu")
+            _close(of, ref, 1e-4, 1e-4)
+    finally:
+        check(lib().afx_debug_set(b"gemm_tile", -1))
+        check(lib().afx_debug_set(b"gemm_map", -1))
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_gemm_asymmetric_identity_catches_transposes(K, dtype):
     # A = I, asymmetric W: C must equal W^T exactly (cdna guide: A=I check with asymmetric B)
     n = 128

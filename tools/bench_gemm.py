@@ -1,0 +1,75 @@
+"""Micro-benchmark of the MFMA GEMM on the shapes the path launches (B=64 student
+batch), for A/B-ing kernel variants in ONE process with interleaved rounds
+(cdna guide rule 24).  Prints TFLOP/s per shape and variant (median of rounds)."""
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "real-time-deepfake-speech-detection_amd")]
+from afx import kernels as K  # noqa: E402
+from afx._lib import lib, check  # noqa: E402
+
+DT = os.environ.get("AFX_DTYPE", "fp16")
+TD = torch.float16 if DT == "fp16" else torch.bfloat16
+B = 64
+# name, kind, dims
+SHAPES = [
+    ("conv1 M=409536 K=1536 N=512", "conv", (B, 12799, 3, 2)),
+    ("conv3 M=102336 K=1536 N=512", "conv", (B, 3199, 3, 2)),
+    ("conv5 M=25536  K=1024 N=512", "conv", (B, 799, 2, 2)),
+    ("qkv   M=12736 K=1024 N=3072", "lin", (12736, 3072, 1024)),
+    ("out   M=12736 K=1024 N=1024", "lin", (12736, 1024, 1024)),
+    ("fc1   M=12736 K=1024 N=4096", "lin", (12736, 4096, 1024)),
+    ("fc2   M=12736 K=4096 N=1024", "lin", (12736, 1024, 4096)),
+    ("teacher fc1 M=3184 K=1024 N=4096", "lin", (3184, 4096, 1024)),
+]
+VARIANTS = [("128x128", ("gemm_tile", 0)), ("256x256", ("gemm_tile", 1))]
+
+
+def make(kind, dims):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    if kind == "conv":
+        Bb, Tin, k, s = dims
+        x = torch.randn(Bb, Tin, 512, generator=g, device="cuda").to(TD)
+        wp = (torch.randn(512, k * 512, generator=g, device="cuda") * 0.03).to(TD)
+        bias = torch.randn(512, generator=g, device="cuda")
+        Tout = (Tin - k) // s + 1
+        flops = 2.0 * Bb * Tout * 512 * k * 512
+        return (lambda: K.conv_gemm(DT, x, wp, k, s, bias)), flops
+    M, N, Kk = dims
+    a = torch.randn(M, Kk, generator=g, device="cuda").to(TD)
+    w = (torch.randn(N, Kk, generator=g, device="cuda") * 0.03).to(TD)
+    bias = torch.randn(N, generator=g, device="cuda")
+    return (lambda: K.gemm(DT, a, w, bias=bias, act="gelu", out_f=False, out_h=True)), 2.0 * M * N * Kk
+
+
+def main():
+    rounds, reps = 5, 10
+    for name, kind, dims in SHAPES:
+        fn, flops = make(kind, dims)
+        times = {v: [] for v, _ in VARIANTS}
+        for _ in range(2):
+            fn()
+        for _ in range(rounds):
+            for v, (key, val) in VARIANTS:
+                check(lib().afx_debug_set(key.encode(), val))
+                fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                times[v].append(e0.elapsed_time(e1) / reps)
+        row = "  ".join(f"{v}: {flops / (statistics.median(t) * 1e-3) / 1e12:7.1f} TF ({statistics.median(t) * 1e3:7.1f} us)"
+                        for v, t in times.items())
+        print(f"{name:36s} {row}", flush=True)
+    for key in {k for _, (k, _) in VARIANTS}:
+        check(lib().afx_debug_set(key.encode(), -1))
+
+
+if __name__ == "__main__":
+    main()
