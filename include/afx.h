@@ -96,7 +96,8 @@ const char* afx_profile_class_name(int cls);
 
 /* tuning knobs for A/B measurements (process-wide; not part of the drop-in surface).
  * "gemm_map": workgroup->tile order of the MFMA GEMM, -1 default, 0 linear, 1 XCD-
- * contiguous, 2 XCD-contiguous + grouped. */
+ * contiguous, 2 XCD-contiguous + grouped.  "gemm_tile": -1 auto, 0 128x128, 1 256x256.
+ * "fuse_conv_ln": 1 (default) conv layers 1-6 use the fused LayerNorm epilogue, 0 two kernels. */
 int afx_debug_set(const char* key, int value);
 
 /* ---- single-kernel entry points (unit parity tests; operand pointers are bf16 or
@@ -108,6 +109,11 @@ int afx_k_gemm(int dtype, const void* A, long lda, const void* W, long ldw, int 
  * the tap-major packed weight [N][k*Cin]; out_f (B,Tout,N) fp32 */
 int afx_k_conv_gemm(int dtype, const void* in_h, const void* Wp, int B, int Tin, int Tout, int Cin, int k, int s,
                     int N, const float* bias, float* out_f, void* stream);
+/* the same conv with LayerNorm over the 512 output channels + activation fused into the GEMM
+ * epilogue (row-complete tile); N is fixed at 512; out_f and/or out_h (B,Tout,512) */
+int afx_k_conv_ln_act(int dtype, const void* in_h, const void* Wp, int B, int Tin, int Tout, int Cin, int k, int s,
+                      const float* bias, const float* gamma, const float* beta, float eps, int act, float* out_f,
+                      void* out_h, void* stream);
 int afx_k_pack_linear(int dtype, const float* w, int N, int K, int Kpad, void* out_h, void* stream);
 int afx_k_pack_conv(int dtype, const float* w, int N, int Cin, int k, void* out_h, void* stream);
 int afx_k_conv0(int dtype, const float* wave, int B, int L, const float* w, const float* bias, const float* gamma,

@@ -46,6 +46,17 @@ def conv_gemm(dtype, x_h, wp, k, s, bias=None):
     return out
 
 
+def conv_ln_act(dtype, x_h, wp, k, s, bias, gamma, beta, act="gelu", eps=1e-5, out_f=False, out_h=True):
+    """Conv1d(512->512,k,s) + LayerNorm(512) + activation in one kernel; x_h (B,Tin,512) half."""
+    B, Tin, Cin = x_h.shape
+    Tout = (Tin - k) // s + 1
+    of = torch.empty(B, Tout, 512, dtype=torch.float32, device=x_h.device) if out_f else None
+    oh = torch.empty(B, Tout, 512, dtype=torch_dtype(dtype), device=x_h.device) if out_h else None
+    check(lib().afx_k_conv_ln_act(DTYPES[dtype], ptr(x_h), ptr(wp), B, Tin, Tout, Cin, k, s, ptr(bias), ptr(gamma),
+                                  ptr(beta), eps, ACTS[act], ptr(of), ptr(oh), stream_ptr()))
+    return of, oh
+
+
 def conv0(dtype, wave, w, bias, gamma, beta, pre_emph=False, coef=0.97):
     B, L = wave.shape
     T0 = (L - 10) // 5 + 1

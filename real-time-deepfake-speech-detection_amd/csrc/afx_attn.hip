@@ -7,8 +7,10 @@
 //                 query row (lane&15) and keys 16*kt + 4*(lane>>4) + 0..3;
 //   softmax       in registers: lane-local max/sum + two xor-shuffles (lanes 16/32
 //                 apart share the row); masked keys contribute exactly 0;
-//   O = P V       the S^T accumulator layout is re-used directly as the A-operand
-//                 (k-slots permuted identically on the V^T side), no LDS round trip.
+//   O^T = V^T P^T the S^T accumulator layout is re-used directly as the B-operand
+//                 (k-slots permuted identically on the V^T side), no LDS round trip;
+//                 the lane keeps its query row, so normalisation is lane-local and the
+//                 output leaves as 16-B stores.
 // Q never touches LDS (each wave reads its own 16 rows as 16-B fragments).
 #include "afx_common.h"
 #include "afx_kernels.h"
@@ -124,18 +126,31 @@ __global__ __launch_bounds__(256) void mhsa_kernel(const typename HT::T* __restr
           vf[r] = lo[r];
           vf[4 + r] = hi[r];
         }
-        o[nt] = HT::mfma(pf, vf, o[nt]);
+        o[nt] = HT::mfma(vf, pf, o[nt]);  // O^T = V^T P^T: the lane keeps ONE query row
       }
     }
-    // o[nt][r] = O[q0 + 4g + r][16nt + ql]; the row's 1/sum lives in lane (4g + r)
+    // o[nt][r] = O[q0 + ql][16nt + 4g + r]: 4 consecutive head dims of the lane's own query row,
+    // so the row's 1/sum is already local.  v_permlane16_swap pairs the two 16-column tiles
+    // (as in the GEMM epilogue) -> each lane stores 8 consecutive dims (16 B).
+    const int q = q0 + ql;
+    const int cb = (g & 1) * 16 + (g >> 1) * 8;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float ri = __shfl(rinv, g * 4 + r, 64);
-      const int q = q0 + g * 4 + r;
+    for (int np = 0; np < 2; ++np) {
+      f32x4 va = o[2 * np] * rinv, vb = o[2 * np + 1] * rinv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va[r]), __float_as_uint(vb[r]), false, false);
+        va[r] = __uint_as_float(sw[0]);
+        vb[r] = __uint_as_float(sw[1]);
+      }
       if (q < T) {
-        Tt* orow = out + ((long)b * T + q) * (H * 64) + h * 64 + ql;
+        V8 hv;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) orow[nt * 16] = (Tt)(o[nt][r] * ri);
+        for (int r = 0; r < 4; ++r) {
+          hv[r] = (Tt)va[r];
+          hv[4 + r] = (Tt)vb[r];
+        }
+        *(V8*)(out + ((long)b * T + q) * (H * 64) + h * 64 + np * 32 + cb) = hv;
       }
     }
   }

@@ -40,14 +40,34 @@ constexpr float kSeluScale = 1.0507009873554805f;
 // branchy library erff -- the activation sits on 0.4 G elements per utterance of the
 // conv stack, where it decided whether those kernels are VALU- or HBM-bound.
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.7071067811865476f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.23164189f, 1.0f));  // 1 / (1 + p |x| / sqrt 2), raw v_rcp (1 ulp)
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
   p = fmaf(p, t, 0.254829592f);
-  const float q = p * t * __expf(-z * z);  // erfc(|x| / sqrt 2) in (0, 1]
+  const float q = p * t * __builtin_amdgcn_exp2f(ax * ax * -0.7213475204444817f);  // erfc(|x|/sqrt 2) in (0,1]
   return 0.5f * x * (x >= 0.f ? 2.0f - q : q);  // no cancellation on the negative tail
+}
+// The same on two values at once: everything but the two transcendentals is packed fp32
+// (v_pk_fma_f32 / v_pk_mul_f32), which halves the VALU issue slots of the GEMM epilogues.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+  const f32x2_t ax = __builtin_elementwise_abs(x);
+  const f32x2_t d = __builtin_elementwise_fma(ax, (f32x2_t)(0.23164189f), (f32x2_t)(1.0f));
+  const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2_t p = __builtin_elementwise_fma(t, (f32x2_t)(1.061405429f), (f32x2_t)(-1.453152027f));
+  p = __builtin_elementwise_fma(p, t, (f32x2_t)(1.421413741f));
+  p = __builtin_elementwise_fma(p, t, (f32x2_t)(-0.284496736f));
+  p = __builtin_elementwise_fma(p, t, (f32x2_t)(0.254829592f));
+  const f32x2_t zz = ax * ax * -0.7213475204444817f;
+  const f32x2_t e = {__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};
+  const f32x2_t q = p * t * e;
+  const f32x2_t hx = x * 0.5f;
+  f32x2_t sel;
+  sel[0] = x[0] >= 0.f ? 2.0f - q[0] : q[0];
+  sel[1] = x[1] >= 0.f ? 2.0f - q[1] : q[1];
+  return hx * sel;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }

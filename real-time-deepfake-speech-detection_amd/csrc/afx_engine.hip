@@ -586,10 +586,10 @@ extern "C" int afx_tap(afx_handle h, const char* name, float* out, size_t cap, s
 // launch of the forward is bracketed by hipEvents on the launch stream and summed per
 // class afterwards.  Off by default: the normal forward records nothing.
 // ---------------------------------------------------------------------------------
-enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_CONV0, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV,
+enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_CONV0, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV,
                  PC_MISC, PC_AASIST, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm_kernel<128x128>", "gemm_kernel<128x64>", "gemm_kernel<256x256>",
-                                           "conv0_kernel", "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel",
+                                           "gemm_kernel<128x512,rowLN>", "conv0_kernel", "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel",
                                            "conf_dwconv_kernel", "misc", "aasist_head"};
 struct ProfRec { int cls; hipEvent_t a, b; double flops; };
 struct Profiler {
@@ -608,6 +608,7 @@ struct Profiler {
 };
 static std::unordered_map<afx_engine*, Profiler> g_prof;
 static thread_local Profiler* t_prof = nullptr;
+static int g_fuse_conv_ln = 1;  // conv layers 1-6: LayerNorm+GELU in the GEMM epilogue (A/B knob)
 static void prof_forget(afx_engine* e) {
   auto it = g_prof.find(e);
   if (it == g_prof.end()) return;
@@ -629,7 +630,7 @@ static const char* timed(int cls, double flops, hipStream_t s, F&& f) {
 }
 static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) {
   const double fl = 2.0 * g.M * g.N * (g.k_algo ? g.k_algo : g.K) * groups;
-  static const int cls[3] = {PC_GEMM128, PC_GEMM64, PC_GEMM256};
+  static const int cls[4] = {PC_GEMM128, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN};
   return timed(cls[gemm_tile_of(g, groups)], fl, s, [&] { return launch_gemm(g, dt, groups, s); });
 }
 static const char* P_rownorm(const RowNormArgs& a, int dt, hipStream_t s) {
@@ -701,7 +702,8 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     return launch_conv0(wave, B, L, T[0], cf(0, ".0.weight"), cf(0, ".0.bias"), cf(0, ".2.1.weight"),
                         cf(0, ".2.1.bias"), e->cfg.pre_emphasis, e->cfg.pre_emphasis_coef, w.bufA, dt, s);
   }));
-  // layers 1..6: conv-as-GEMM (fp32 out) then LayerNorm + GELU
+  // layers 1..6: conv-as-GEMM on a row-complete tile, LayerNorm(512) + GELU fused into the
+  // epilogue (the pre-norm fp32 activations never leave the registers)
   void* in = w.bufA;
   void* out = w.bufB;
   for (int i = 1; i < 7; ++i) {
@@ -710,16 +712,28 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     g.rpb = T[i]; g.a_batch = (long)T[i - 1] * kC; g.a_row = (long)kConvS[i] * kC;
     g.o_batch_rows = T[i]; g.oh_batch_rows = T[i];
     g.bias = cf(i, ".0.bias");
-    g.out_f = w.tmp32; g.ldo_f = kC;
-    KOK(launch_gemm(g, dt, 1, s));
-    RowNormArgs n = plain_norm(w.tmp32, kC, M, kC, cf(i, ".2.1.weight"), cf(i, ".2.1.bias"));
-    n.act = ACT_GELU;
-    if (i < 6) {
-      n.out_h = out; n.ldo_h = kC;
-    } else {
-      n.out_f = w.tmp32; n.ldo_f = kC;  // in place: a row is register-resident before it is written
+    g.act = ACT_GELU;
+    if (g_fuse_conv_ln) {
+      g.ln_gamma = cf(i, ".2.1.weight"); g.ln_beta = cf(i, ".2.1.bias"); g.ln_eps = kLnEps;
+      if (i < 6) {
+        g.out_h = out; g.ldo_h = kC;
+      } else {
+        g.out_f = w.tmp32; g.ldo_f = kC;  // fp32: the feature LayerNorm follows
+      }
+      KOK(launch_gemm(g, dt, 1, s));
+    } else {  // two-kernel form (kept for A/B measurements)
+      g.act = ACT_NONE;
+      g.out_f = w.tmp32; g.ldo_f = kC;
+      KOK(launch_gemm(g, dt, 1, s));
+      RowNormArgs n = plain_norm(w.tmp32, kC, M, kC, cf(i, ".2.1.weight"), cf(i, ".2.1.bias"));
+      n.act = ACT_GELU;
+      if (i < 6) {
+        n.out_h = out; n.ldo_h = kC;
+      } else {
+        n.out_f = w.tmp32; n.ldo_f = kC;  // in place: a row is register-resident before it is written
+      }
+      KOK(launch_rownorm(n, dt, s));
     }
-    KOK(launch_rownorm(n, dt, s));
     void* t = in; in = out; out = t;
   }
   const int Tt = T[6], M = B * Tt;
@@ -996,6 +1010,16 @@ extern "C" int afx_k_conv_gemm(int dtype, const void* in_h, const void* Wp, int 
   g.bias = bias; g.out_f = out_f; g.ldo_f = N;
   KRET(launch_gemm(g, dtype, 1, (hipStream_t)stream));
 }
+extern "C" int afx_k_conv_ln_act(int dtype, const void* in_h, const void* Wp, int B, int Tin, int Tout, int Cin,
+                                 int k, int s_, const float* bias, const float* gamma, const float* beta, float eps,
+                                 int act, float* out_f, void* out_h, void* stream) {
+  GemmArgs g = plain_gemm(in_h, 0, Wp, (long)k * Cin, B * Tout, 512, k * Cin);
+  g.rpb = Tout; g.a_batch = (long)Tin * Cin; g.a_row = (long)s_ * Cin;
+  g.o_batch_rows = Tout; g.oh_batch_rows = Tout;
+  g.bias = bias; g.act = act; g.ln_gamma = gamma; g.ln_beta = beta; g.ln_eps = eps;
+  g.out_f = out_f; g.ldo_f = 512; g.out_h = out_h; g.ldo_h = 512;
+  KRET(launch_gemm(g, dtype, 1, (hipStream_t)stream));
+}
 extern "C" int afx_k_pack_linear(int dtype, const float* w, int N, int K, int Kpad, void* out_h, void* stream) {
   KRET(launch_pack_linear(w, N, K, Kpad, out_h, dtype, (hipStream_t)stream));
 }
@@ -1016,6 +1040,18 @@ extern "C" int afx_debug_set(const char* key, int value) {
   }
   if (!strcmp(key, "gemm_tile")) {
     gemm_set_tile(value);
+    return 0;
+  }
+  if (!strcmp(key, "gemm_nodma")) {
+    gemm_set_nodma(value);
+    return 0;
+  }
+  if (!strcmp(key, "gemm_a_nt")) {
+    gemm_set_a_nt(value);
+    return 0;
+  }
+  if (!strcmp(key, "fuse_conv_ln")) {
+    g_fuse_conv_ln = value != 0;
     return 0;
   }
   return fail("afx_debug_set: unknown key '%s'", key);

@@ -24,7 +24,11 @@
 namespace afx {
 
 // WR x WC waves per workgroup; each wave owns a (BM/WR) x (BN/WC) block of the tile.
-template <class HT, int BM, int BN, int WR, int WC>
+// ROWLN: the tile spans the whole output row (BN == N), and the epilogue applies
+// LayerNorm over the row (two-pass fp32 statistics, partial sums exchanged through LDS
+// between the WC waves of a row) followed by the activation -- the conv feature
+// extractor's "conv -> LayerNorm(512) -> GELU" in one kernel, no fp32 round trip.
+template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
@@ -35,6 +39,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
   constexpr int AI = BM / (8 * NW), WI = BN / (8 * NW);  // LDS-DMA instructions per thread per tile
   static_assert(AI >= 1 && WI >= 1, "tile too small for the wave count");
+  constexpr bool PRELOAD = (MT + NT) <= 8;  // both k-steps' fragments fit beside the accumulators
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -104,11 +109,21 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
     const int k0 = kt << 6;
     const long ka = (long)(k0 / p.kchunk) * p.kchunk_stride + (k0 % p.kchunk);
     char* base = smem + buf * STAGE;
+    // a_nt: the A panel is read by exactly one workgroup (row-complete tile) -- stream it
+    // non-temporally so it does not evict the W panel every workgroup re-reads from L2
+    if (p.a_nt) {
 #pragma unroll
-    for (int i = 0; i < AI; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + ka),
-                                       (__attribute__((address_space(3))) void*)(base + (i * NW + wave) * 1024),
-                                       16, 0, 0);
+      for (int i = 0; i < AI; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + ka),
+                                         (__attribute__((address_space(3))) void*)(base + (i * NW + wave) * 1024),
+                                         16, 0, 2);
+    } else {
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + ka),
+                                         (__attribute__((address_space(3))) void*)(base + (i * NW + wave) * 1024),
+                                         16, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < WI; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0),
@@ -122,32 +137,243 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   const int a_off = (wr * WM + frow) * 128;
   const int w_off = A_BYTES + (wc * WN + frow) * 128;
 
+  V8 paf[2][PRELOAD ? MT : 1], pwf[2][PRELOAD ? NT : 1];  // fragment registers of the PRELOAD path
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt landed for every wave; every wave is done with tile kt-1
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    if (kt + 1 < nk && !(p.dbg_nodma & 1)) stage((kt + 1) & 1, kt + 1);  // dbg_nodma: timing-only build of the compute phase
     const char* sb = smem + (kt & 1) * STAGE;
+    if constexpr (PRELOAD) {
+      // both k-steps' fragments are requested up front: the LDS latency of step 1 hides under
+      // the MFMAs of step 0 (the compiler places counted lgkmcnt waits), so a wave exposes
+      // one LDS round trip per K-tile instead of two
+      if (!(p.dbg_nodma & 2) || kt == 0) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int slot = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
-      V8 af[MT], wf[NT];
+        for (int ks = 0; ks < 2; ++ks) {
+          const int slot = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
+          for (int i = 0; i < MT; ++i) paf[ks][i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
-      __builtin_amdgcn_s_setprio(1);
+          for (int j = 0; j < NT; ++j) pwf[ks][j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
+        }
+      }
+      if (!(p.dbg_nodma & 4)) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int ks = 0; ks < 2; ++ks) {
+          __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
-      __builtin_amdgcn_s_setprio(0);
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(pwf[ks][j], paf[ks][i], acc[i][j]);
+          __builtin_amdgcn_s_setprio(0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int slot = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
+        V8 af[MT], wf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+      }
     }
   }
 
   // epilogue: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]
+  if constexpr (ROWLN) {
+    static_assert(BN % (16 * WC) == 0, "row-complete tile");
+    __syncthreads();  // every wave is done reading the last K-tile: LDS becomes scratch
+    float* red = (float*)smem;  // [WC][BM] partial row sums
+    const int kq = lane >> 4;
+    // v = acc + bias, kept in the accumulator registers
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const f32x4 b = *(const f32x4*)(p.bias + n0 + wc * WN + j * 16 + 4 * kq);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][j] += b;
+    }
+    float mean[MT], rstd[MT];
+    const float invn = 1.0f / (float)BN;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) s += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (kq == 0) red[wc * BM + wr * WM + i * 16 + (lane & 15)] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = wr * WM + i * 16 + (lane & 15);
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < WC; ++c) s += red[c * BM + row];
+      mean[i] = s * invn;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[i][j][r] -= mean[i];
+          s = fmaf(acc[i][j][r], acc[i][j][r], s);
+        }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (kq == 0) red[wc * BM + wr * WM + i * 16 + (lane & 15)] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = wr * WM + i * 16 + (lane & 15);
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < WC; ++c) s += red[c * BM + row];
+      rstd[i] = 1.0f / sqrtf(s * invn + p.ln_eps);
+    }
+    // normalise, activate, then widen to 8 columns per lane (v_permlane16_swap, see below)
+    const int cbw = (kq & 1) * 16 + (kq >> 1) * 8;
+#pragma unroll
+    for (int jp = 0; jp < NT / 2; ++jp) {
+      const int na = n0 + wc * WN + jp * 32 + 4 * kq, nb = na + 16;
+      const f32x4 ga0 = *(const f32x4*)(p.ln_gamma + na), be0 = *(const f32x4*)(p.ln_beta + na);
+      const f32x4 ga1 = *(const f32x4*)(p.ln_gamma + nb), be1 = *(const f32x4*)(p.ln_beta + nb);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wr * WM + i * 16 + (lane & 15);
+        f32x4 va, vb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          va[r] = fmaf(acc[i][2 * jp][r] * rstd[i], ga0[r], be0[r]);
+          vb[r] = fmaf(acc[i][2 * jp + 1][r] * rstd[i], ga1[r], be1[r]);
+        }
+        if (p.act == ACT_GELU) {
+          const f32x2_t a0 = gelu_erf2(f32x2_t{va[0], va[1]}), a1 = gelu_erf2(f32x2_t{va[2], va[3]});
+          const f32x2_t b0 = gelu_erf2(f32x2_t{vb[0], vb[1]}), b1 = gelu_erf2(f32x2_t{vb[2], vb[3]});
+          va = f32x4{a0[0], a0[1], a1[0], a1[1]};
+          vb = f32x4{b0[0], b0[1], b1[0], b1[1]};
+        } else if (p.act != ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            va[r] = apply_act(va[r], p.act);
+            vb[r] = apply_act(vb[r], p.act);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va[r]), __float_as_uint(vb[r]), false, false);
+          va[r] = __uint_as_float(sw[0]);
+          vb[r] = __uint_as_float(sw[1]);
+        }
+        if (m >= p.M) continue;
+        const int n = n0 + wc * WN + jp * 32 + cbw;
+        const long orow = (long)(m / p.rpb) * p.o_batch_rows + (m % p.rpb) + p.o_row_off;
+        const long hrow = (long)(m / p.rpb) * p.oh_batch_rows + (m % p.rpb) + p.oh_row_off;
+        if (p.out_f) {
+          float* op = p.out_f + orow * p.ldo_f + n;
+          *(f32x4*)op = va;
+          *(f32x4*)(op + 4) = vb;
+        }
+        if (p.out_h) {
+          V8 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            h[r] = (T)va[r];
+            h[4 + r] = (T)vb[r];
+          }
+          *(V8*)((T*)p.out_h + hrow * p.ldo_h + n) = h;
+        }
+      }
+    }
+    return;
+  }
   const int gcol = g * p.g_n;
   const float alpha = p.alpha;
+  const int kq = lane >> 4;
+  if ((p.N & 7) == 0 && !(p.dbg_nodma & 16)) {
+    // Wide-store epilogue.  After the MFMAs a lane holds 4 consecutive columns of one row
+    // (8 B of fp16); v_permlane16_swap exchanges 16-lane rows between the registers of two
+    // adjacent 16-column tiles so that every lane ends up with 8 consecutive columns:
+    //   row-of-lane 0: tile j cols 0-7 | 1: tile j+1 cols 0-7 | 2: tile j cols 8-15 | 3: tile j+1 cols 8-15
+    // -> one 16-B store per lane (two for fp32), half the store instructions of the narrow
+    // form; the store tail of these kernels is issue-bound (cdna guide T21).
+    const int cb = (kq & 1) * 16 + (kq >> 1) * 8;  // column base of this lane inside a tile pair
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wr * WM + i * 16 + (lane & 15);
+      const bool mok = m < p.M;
+      const int mc = mok ? m : p.M - 1;
+      const long orow = (long)(mc / p.rpb) * p.o_batch_rows + (mc % p.rpb) + p.o_row_off;
+      const long hrow = (long)(mc / p.rpb) * p.oh_batch_rows + (mc % p.rpb) + p.oh_row_off;
+#pragma unroll
+      for (int jp = 0; jp < NT / 2; ++jp) {
+        const int nb = n0 + wc * WN + jp * 32;  // first column of the tile pair
+        f32x4 va = acc[i][2 * jp], vb = acc[i][2 * jp + 1];
+        if (p.bias) {
+          const int na = nb + 4 * kq, nbb = na + 16;
+          if (na < p.N) va += *(const f32x4*)(p.bias + gcol + na);
+          if (nbb < p.N) vb += *(const f32x4*)(p.bias + gcol + nbb);
+        }
+        if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
+          const f32x2_t a0 = gelu_erf2(f32x2_t{va[0], va[1]}), a1 = gelu_erf2(f32x2_t{va[2], va[3]});
+          const f32x2_t b0 = gelu_erf2(f32x2_t{vb[0], vb[1]}), b1 = gelu_erf2(f32x2_t{vb[2], vb[3]});
+          va = f32x4{a0[0], a0[1], a1[0], a1[1]};
+          vb = f32x4{b0[0], b0[1], b1[0], b1[1]};
+        } else if (p.act != ACT_NONE && !(p.dbg_nodma & 8)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            va[r] = apply_act(va[r], p.act);
+            vb[r] = apply_act(vb[r], p.act);
+          }
+        }
+        va *= alpha;
+        vb *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va[r]), __float_as_uint(vb[r]), false, false);
+          va[r] = __uint_as_float(sw[0]);
+          vb[r] = __uint_as_float(sw[1]);
+        }
+        const int n = nb + cb;  // this lane now owns columns n .. n+7 (va | vb)
+        if (!mok || n >= p.N) continue;
+        if (p.resid) {
+          const float* rp = p.resid + orow * p.ldr + gcol + n;
+          va += *(const f32x4*)rp;
+          vb += *(const f32x4*)(rp + 4);
+        }
+        if (p.out_f) {
+          float* op = p.out_f + orow * p.ldo_f + gcol + n;
+          *(f32x4*)op = va;
+          *(f32x4*)(op + 4) = vb;
+        }
+        if (p.out_h) {
+          V8 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            h[r] = (T)va[r];
+            h[4 + r] = (T)vb[r];
+          }
+          *(V8*)((T*)p.out_h + hrow * p.ldo_h + gcol + n) = h;
+        }
+      }
+    }
+    return;
+  }
+  // narrow fallback (N % 8 != 0): 4 columns per lane
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + wr * WM + i * 16 + (lane & 15);
@@ -156,22 +382,16 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
     const long hrow = (long)(m / p.rpb) * p.oh_batch_rows + (m % p.rpb) + p.oh_row_off;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
+      const int n = n0 + wc * WN + j * 16 + 4 * kq;
       if (n >= p.N) continue;
       f32x4 v = acc[i][j];
-      if (p.bias) {
-        const f32x4 b = *(const f32x4*)(p.bias + gcol + n);
-        v += b;
-      }
-      if (p.act != ACT_NONE) {
+      if (p.bias) v += *(const f32x4*)(p.bias + gcol + n);
+      if (p.act != ACT_NONE && !(p.dbg_nodma & 8)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
       }
       v *= alpha;
-      if (p.resid) {
-        const f32x4 r4 = *(const f32x4*)(p.resid + orow * p.ldr + gcol + n);
-        v += r4;
-      }
+      if (p.resid) v += *(const f32x4*)(p.resid + orow * p.ldr + gcol + n);
       if (p.out_f) *(f32x4*)(p.out_f + orow * p.ldo_f + gcol + n) = v;
       if (p.out_h) {
         V4 h;
@@ -183,18 +403,18 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   }
 }
 
-template <class HT, int BM, int BN, int WR, int WC>
+template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false>
 static hipError_t launch_gemm_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<HT, BM, BN, WR, WC>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<HT, BM, BN, WR, WC, ROWLN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
-  hipLaunchKernelGGL((gemm_kernel<HT, BM, BN, WR, WC>), grid, dim3(64 * WR * WC), lds, s, p);
+  hipLaunchKernelGGL((gemm_kernel<HT, BM, BN, WR, WC, ROWLN>), grid, dim3(64 * WR * WC), lds, s, p);
   return hipGetLastError();
 }
 
@@ -203,44 +423,59 @@ static int g_map_override = -1;
 static int g_tile_override = -1;  // 0: 128x128 / 4 waves, 1: 256x256 / 8 waves
 void gemm_set_map_mode(int m) { g_map_override = m; }
 void gemm_set_tile(int t) { g_tile_override = t; }
+static int g_ant_override = -1;  // non-temporal A loads: -1 auto (row-complete tile only), 0, 1
+void gemm_set_a_nt(int v) { g_ant_override = v; }
+static int g_nodma = 0;  // timing-only: skip the operand DMA after the first K-tile (WRONG results)
+void gemm_set_nodma(int v) { g_nodma = v; }
 
 // Host-side shape contract; anything else is a programming error in the caller.
-static const char* check_gemm(const GemmArgs& p) {
+static const char* check_gemm(const GemmArgs& p, int groups) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return "gemm: empty problem";
   if (p.K % 64) return "gemm: K must be a multiple of 64 (pad the weights)";
   if (p.N % 4) return "gemm: N must be a multiple of 4";
   if (p.kchunk <= 0 || p.kchunk % 64) return "gemm: kchunk must be a positive multiple of 64";
   if (p.rpb <= 0) return "gemm: rows-per-batch must be positive";
   if (!p.out_f && !p.out_h) return "gemm: no output";
+  if (p.ln_gamma) {
+    if (p.N != 512 || groups != 1) return "gemm: the fused LayerNorm epilogue needs N == 512 (row-complete tile)";
+    if (!p.ln_beta || !p.bias || p.resid || p.alpha != 1.f) return "gemm: fused LayerNorm epilogue: bias + LN + act only";
+  }
   return nullptr;
 }
 
 bool gemm_is_narrow(int N) { return N <= 64 || (N > 128 && N < 256 && N % 128 != 0); }
 
-// Which tile instance serves a problem: 0 = 128x128, 1 = 128x64, 2 = 256x256.
+// Which tile instance serves a problem: 0 = 128x128, 1 = 128x64, 2 = 256x256, 3 = the
+// row-complete 128x512 tile with the fused LayerNorm epilogue.
 // 256x256 tiles halve the operand bytes per FLOP (the per-CU L2->LDS rate is what bounds
 // this kernel) but quantise badly at M = B*199: measured faster only for the conv layers
 // (huge M, N = 512) and the K = 4096 FFN product (tools/bench_gemm.py, profiles/).
 int gemm_tile_of(const GemmArgs& p, int groups) {
+  if (p.ln_gamma) return 3;
   if (gemm_is_narrow(p.N)) return 1;
   const bool big_auto = p.N <= 1024 && (long)p.M * p.K >= 12736L * 2048;
   const bool big = groups == 1 && (g_tile_override >= 0 ? g_tile_override == 1 : big_auto);
   return big ? 2 : 0;
 }
 
+template <class HT>
+static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t s) {
+  switch (tile) {
+    case 1: return launch_gemm_t<HT, 128, 64, 2, 2>(p, groups, s);
+    case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
+    case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
+    default: return launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
+  }
+}
+
 const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t s) {
-  if (const char* e = check_gemm(p_in)) return e;
+  if (const char* e = check_gemm(p_in, groups)) return e;
   GemmArgs p = p_in;
   p.map_mode = g_map_override >= 0 ? g_map_override : 2;
-  hipError_t err;
   const int tile = gemm_tile_of(p, groups);
-  const bool narrow = tile == 1, big = tile == 2;
-  if (dtype == DT_BF16)
-    err = narrow ? launch_gemm_t<BF16, 128, 64, 2, 2>(p, groups, s)
-                 : big ? launch_gemm_t<BF16, 256, 256, 2, 4>(p, groups, s) : launch_gemm_t<BF16, 128, 128, 2, 2>(p, groups, s);
-  else
-    err = narrow ? launch_gemm_t<FP16, 128, 64, 2, 2>(p, groups, s)
-                 : big ? launch_gemm_t<FP16, 256, 256, 2, 4>(p, groups, s) : launch_gemm_t<FP16, 128, 128, 2, 2>(p, groups, s);
+  p.a_nt = g_ant_override >= 0 ? g_ant_override : (tile == 3 ? 1 : 0);
+  p.dbg_nodma = g_nodma;
+  const hipError_t err = dtype == DT_BF16 ? dispatch<BF16>(p, tile, groups, s) : dispatch<FP16>(p, tile, groups, s);
   return err == hipSuccess ? nullptr : hipGetErrorString(err);
 }
 

@@ -39,12 +39,21 @@ struct GemmArgs {
   int o_batch_rows, o_row_off;
   int oh_batch_rows, oh_row_off;
   int map_mode;  // workgroup->tile order, set by launch_gemm (0 linear, 1 XCD-contiguous, 2 + grouped)
+  // fused row LayerNorm epilogue (needs N == 512, one row-complete tile per M-tile):
+  // out = act(LayerNorm(acc + bias) * ln_gamma + ln_beta); null ln_gamma = off
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  int a_nt;  // 1: non-temporal LDS-DMA for the A panel (set by launch_gemm)
+  int dbg_nodma;  // timing experiments only
 };
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
 bool gemm_is_narrow(int N);  // true: the 128x64 tile instance serves this N
 int gemm_tile_of(const GemmArgs& p, int groups);  // 0: 128x128, 1: 128x64, 2: 256x256 instance
 void gemm_set_map_mode(int m);  // A/B knob: -1 default, else force map_mode
 void gemm_set_tile(int t);      // A/B knob: -1 default, 0: 128x128 tile, 1: 256x256 tile
+void gemm_set_a_nt(int v);      // A/B knob: -1 auto, 0/1 non-temporal A-panel loads
+void gemm_set_nodma(int v);     // timing-only knob: compute phase without operand DMA (wrong results)
 
 // ---- frontend / row kernels (afx_frontend.hip) ---------------------------------
 // conv layer 0 (Cin=1,k=10,s=5) + LayerNorm(512) + erf-GELU; optional pre-emphasis.

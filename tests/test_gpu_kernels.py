@@ -112,6 +112,26 @@ def test_conv_layer_as_gemm(K, dtype, k, s, Tin):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("k,s,Tin", [(3, 2, 301), (2, 2, 40)])
+def test_conv_layer_with_fused_layernorm_gelu(K, dtype, k, s, Tin):
+    """Row-complete 128x512 tile: conv + bias + LayerNorm(512) + GELU in one kernel, M tail
+    (B*Tout not a multiple of 128) included; fp32 and operand-type outputs."""
+    g = torch.Generator().manual_seed(100 + k)
+    x = torch.randn(3, Tin, 512, generator=g).to(_td(dtype))
+    w = torch.randn(512, 512, k, generator=g) / math.sqrt(512 * k)
+    bias = torch.randn(512, generator=g) * 0.5
+    ga = 1 + 0.1 * torch.randn(512, generator=g)
+    be = 0.1 * torch.randn(512, generator=g)
+    wp = K.pack_conv(dtype, w.cuda())
+    of, oh = K.conv_ln_act(dtype, x.cuda(), wp, k, s, bias.cuda(), ga.cuda(), be.cuda(), out_f=True, out_h=True)
+    ref = F.conv1d(x.float().transpose(1, 2), w.to(_td(dtype)).float(), bias, stride=s).transpose(1, 2)
+    ref = F.gelu(F.layer_norm(ref, (512,), ga, be, 1e-5))
+    assert of.shape == ref.shape
+    _close(of, ref, 2e-4, 2e-4)
+    _close(oh, ref, _eps(dtype) * 4, 1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("pre", [False, True])
 def test_conv0_layernorm_gelu(K, dtype, pre):
     from oracle import pre as opre

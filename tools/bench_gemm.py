@@ -26,11 +26,33 @@ SHAPES = [
     ("fc2   M=12736 K=4096 N=1024", "lin", (12736, 1024, 4096)),
     ("teacher fc1 M=3184 K=1024 N=4096", "lin", (3184, 4096, 1024)),
 ]
-VARIANTS = [("128x128", ("gemm_tile", 0)), ("256x256", ("gemm_tile", 1))]
+SETS = {
+    "tile": [("128x128", ("gemm_tile", 0)), ("256x256", ("gemm_tile", 1))],
+    "map": [("map0", ("gemm_map", 0)), ("map1", ("gemm_map", 1)), ("map2", ("gemm_map", 2))],
+    "nt": [("A default", ("gemm_a_nt", 0)), ("A nt", ("gemm_a_nt", 1))],
+    "nodma": [("full", ("gemm_nodma", 0)), ("compute-only", ("gemm_nodma", 1))],
+    "epi": [("narrow stores", ("gemm_nodma", 16)), ("wide stores", ("gemm_nodma", 0))],
+    "attr": [("full", ("gemm_nodma", 0)), ("-dma", ("gemm_nodma", 1)), ("-dma-lds", ("gemm_nodma", 3)),
+             ("-dma-mfma", ("gemm_nodma", 5)), ("-dma-act", ("gemm_nodma", 9)), ("-dma-lds-mfma-act", ("gemm_nodma", 15))],
+}
+VARIANTS = SETS[os.environ.get("BENCH_SET", "tile")]
+if os.environ.get("BENCH_SET") == "attr":
+    SHAPES = [SHAPES[0], SHAPES[3], SHAPES[5], SHAPES[6]]
+if os.environ.get("BENCH_SET") in ("nt", "nodma"):  # the fused conv + LayerNorm kernel (row-complete tile)
+    SHAPES = [("convln1 M=409536 K=1536", "convln", (B, 12799, 3, 2)), ("convln2 M=204736 K=1536", "convln", (B, 6399, 3, 2)),
+              ("convln3 M=102336 K=1536", "convln", (B, 3199, 3, 2)), ("convln5 M=25536 K=1024", "convln", (B, 799, 2, 2))] + SHAPES[3:]
 
 
 def make(kind, dims):
     g = torch.Generator(device="cuda").manual_seed(1)
+    if kind == "convln":
+        Bb, Tin, k, s = dims
+        x = torch.randn(Bb, Tin, 512, generator=g, device="cuda").to(TD)
+        wp = (torch.randn(512, k * 512, generator=g, device="cuda") * 0.03).to(TD)
+        bias = torch.randn(512, generator=g, device="cuda")
+        ga = torch.ones(512, device="cuda")
+        Tout = (Tin - k) // s + 1
+        return (lambda: K.conv_ln_act(DT, x, wp, k, s, bias, ga, bias)), 2.0 * Bb * Tout * 512 * k * 512
     if kind == "conv":
         Bb, Tin, k, s = dims
         x = torch.randn(Bb, Tin, 512, generator=g, device="cuda").to(TD)
@@ -64,11 +86,11 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / reps)
-        row = "  ".join(f"{v}: {flops / (statistics.median(t) * 1e-3) / 1e12:7.1f} TF ({statistics.median(t) * 1e3:7.1f} us)"
+        row = "  ".join(f"{v}: {flops / (statistics.median(t) * 1e-3) / 1e12:6.0f} TF ({statistics.median(t) * 1e3:6.1f} us)"
                         for v, t in times.items())
         print(f"{name:36s} {row}", flush=True)
     for key in {k for _, (k, _) in VARIANTS}:
-        check(lib().afx_debug_set(key.encode(), -1))
+        check(lib().afx_debug_set(key.encode(), 0 if key == "gemm_nodma" else -1))
 
 
 if __name__ == "__main__":
