@@ -77,32 +77,48 @@ __global__ __launch_bounds__(256) void conf_attn_kernel(const float* __restrict_
     qv[d] = t[0] * scale; qv[d + 1] = t[1] * scale; qv[d + 2] = t[2] * scale; qv[d + 3] = t[3] * scale;
     o[d] = o[d + 1] = o[d + 2] = o[d + 3] = 0.f;
   }
+  // keys are walked 4 at a time: four independent score chains (ILP for the single wave a
+  // SIMD hosts here), one running-max update and one rescale of o per group
   float m = -1e30f, l = 0.f;
-  for (int j = 0; j < N; ++j) {
-    const float* kr = Ks + j * DH;
-    const float* er = Es + (i - j + N - 1) * DH;
-    float s = 0.f;
+  for (int j0 = 0; j0 < N; j0 += 4) {
+    float sc[4];
 #pragma unroll
-    for (int d = 0; d < DH; d += 4) {
-      const f32x4 kk = *(const f32x4*)(kr + d);
-      const f32x4 ee = *(const f32x4*)(er + d);
-      s = fmaf(qv[d], kk[0] + ee[0], s);
-      s = fmaf(qv[d + 1], kk[1] + ee[1], s);
-      s = fmaf(qv[d + 2], kk[2] + ee[2], s);
-      s = fmaf(qv[d + 3], kk[3] + ee[3], s);
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u < N ? j0 + u : N - 1;
+      const float* kr = Ks + j * DH;
+      const float* er = Es + (i - j + N - 1) * DH;
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; d += 4) {
+        const f32x4 kk = *(const f32x4*)(kr + d);
+        const f32x4 ee = *(const f32x4*)(er + d);
+        s0 = fmaf(qv[d], kk[0] + ee[0], s0);
+        s1 = fmaf(qv[d + 1], kk[1] + ee[1], s1);
+        s0 = fmaf(qv[d + 2], kk[2] + ee[2], s0);
+        s1 = fmaf(qv[d + 3], kk[3] + ee[3], s1);
+      }
+      sc[u] = j0 + u < N ? s0 + s1 : -1e30f;
     }
-    const float mn = fmaxf(m, s);
+    const float mn = fmaxf(fmaxf(m, fmaxf(sc[0], sc[1])), fmaxf(sc[2], sc[3]));
     const float corr = __expf(m - mn);
-    const float p = __expf(s - mn);
-    l = fmaf(l, corr, p);
-    const float* vr = Vs + j * DH;
+    float pr[4];
 #pragma unroll
-    for (int d = 0; d < DH; d += 4) {
-      const f32x4 vv = *(const f32x4*)(vr + d);
-      o[d] = fmaf(o[d], corr, p * vv[0]);
-      o[d + 1] = fmaf(o[d + 1], corr, p * vv[1]);
-      o[d + 2] = fmaf(o[d + 2], corr, p * vv[2]);
-      o[d + 3] = fmaf(o[d + 3], corr, p * vv[3]);
+    for (int u = 0; u < 4; ++u) pr[u] = __expf(sc[u] - mn);
+    l = fmaf(l, corr, (pr[0] + pr[1]) + (pr[2] + pr[3]));
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] *= corr;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u < N ? j0 + u : N - 1;  // masked keys have pr == 0
+      const float* vr = Vs + j * DH;
+#pragma unroll
+      for (int d = 0; d < DH; d += 4) {
+        const f32x4 vv = *(const f32x4*)(vr + d);
+        o[d] = fmaf(pr[u], vv[0], o[d]);
+        o[d + 1] = fmaf(pr[u], vv[1], o[d + 1]);
+        o[d + 2] = fmaf(pr[u], vv[2], o[d + 2]);
+        o[d + 3] = fmaf(pr[u], vv[3], o[d + 3]);
+      }
     }
     m = mn;
   }

@@ -78,7 +78,11 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
     const float rstd = 1.0f / sqrtf(wave_sum(sq) * (1.0f / 512.0f) + 1e-5f);
     V8 o;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (T)gelu_erf(fmaf(v[i] * rstd, ga[i], be[i]));
+    for (int i = 0; i < 8; i += 2) {  // two channels per packed-math GELU
+      const f32x2_t y = gelu_erf2(f32x2_t{fmaf(v[i] * rstd, ga[i], be[i]), fmaf(v[i + 1] * rstd, ga[i + 1], be[i + 1])});
+      o[i] = (T)y[0];
+      o[i + 1] = (T)y[1];
+    }
     *(V8*)(out + ((long)b * T0 + f0 + f) * 512 + lane * 8) = o;
   }
 }

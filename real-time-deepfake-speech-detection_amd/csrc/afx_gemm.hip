@@ -453,9 +453,18 @@ bool gemm_is_narrow(int N) { return N <= 64 || (N > 128 && N < 256 && N % 128 !=
 int gemm_tile_of(const GemmArgs& p, int groups) {
   if (p.ln_gamma) return 3;
   if (gemm_is_narrow(p.N)) return 1;
-  const bool big_auto = p.N <= 1024 && (long)p.M * p.K >= 12736L * 2048;
-  const bool big = groups == 1 && (g_tile_override >= 0 ? g_tile_override == 1 : big_auto);
-  return big ? 2 : 0;
+  if (groups != 1) return 0;
+  if (g_tile_override == 2) return 4;  // 256x128 / 8 waves (A/B only: slower everywhere measured)
+  if (g_tile_override >= 0) return g_tile_override == 1 ? 2 : 0;
+  // Wave-quantisation model fitted to tools/bench_gemm.py (profiles/r01_gemm_tile_ab*.txt):
+  // a 256x256 tile is ~10 % faster per FLOP (half the operand bytes) but runs one workgroup
+  // per CU, a 128x128 tile two; pick the better fill of the 256 CUs.
+  const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const long b256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  if (b128 < 384) return 1;  // small batches: halve the tile to spread over the chip
+  const double e128 = (double)b128 / (double)(((b128 + 511) / 512) * 512);
+  const double e256 = 1.10 * (double)b256 / (double)(((b256 + 255) / 256) * 256);
+  return e256 > e128 ? 2 : 0;
 }
 
 template <class HT>
@@ -464,6 +473,7 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 1: return launch_gemm_t<HT, 128, 64, 2, 2>(p, groups, s);
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
+    case 4: return launch_gemm_t<HT, 256, 128, 4, 2>(p, groups, s);
     default: return launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
   }
 }

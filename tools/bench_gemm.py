@@ -27,7 +27,7 @@ SHAPES = [
     ("teacher fc1 M=3184 K=1024 N=4096", "lin", (3184, 4096, 1024)),
 ]
 SETS = {
-    "tile": [("128x128", ("gemm_tile", 0)), ("256x256", ("gemm_tile", 1))],
+    "tile": [("128x128", ("gemm_tile", 0)), ("256x128", ("gemm_tile", 2)), ("256x256", ("gemm_tile", 1))],
     "map": [("map0", ("gemm_map", 0)), ("map1", ("gemm_map", 1)), ("map2", ("gemm_map", 2))],
     "nt": [("A default", ("gemm_a_nt", 0)), ("A nt", ("gemm_a_nt", 1))],
     "nodma": [("full", ("gemm_nodma", 0)), ("compute-only", ("gemm_nodma", 1))],
