@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
   constexpr int AI = BM / (8 * NW), WI = BN / (8 * NW);  // LDS-DMA instructions per thread per tile
   static_assert(AI >= 1 && WI >= 1, "tile too small for the wave count");
-  constexpr bool PRELOAD = (MT + NT) <= 8;  // both k-steps' fragments fit beside the accumulators
+  constexpr bool ASM_DMA = ROWLN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -105,30 +105,48 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
 
   const int nk = p.K >> 6;
 
+  // ASM_DMA (one workgroup per CU, so a wave must overlap its own LDS reads with its MFMAs;
+  // measured +20 % on the row-complete conv tile, -5 % on the 2-workgroup-per-CU 128x128 tile):
+  // LDS-DMA through inline asm: with the builtin in the loop hipcc's waitcnt pass stops
+  // counting lgkmcnt (every ds_read group is followed by lgkmcnt(0), so a wave never overlaps
+  // its LDS reads with its MFMAs); hidden in asm, the compiler keeps fine-grained counted
+  // waits for the fragment reads, and the DMA's own completion is waited by hand (vmcnt(0)
+  // at the top of each K-tile).  M0 (the LDS destination base) is saved and restored inside
+  // the statement, as the cdna guide prescribes.
+  const unsigned lds_base = (unsigned)(size_t)smem;
+  auto dma16 = [&](const T* src, unsigned lds_off, bool nt) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + lds_off);
+    if (nt)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    else
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
   auto stage = [&](int buf, int kt) {
     const int k0 = kt << 6;
     const long ka = (long)(k0 / p.kchunk) * p.kchunk_stride + (k0 % p.kchunk);
-    char* base = smem + buf * STAGE;
+    const unsigned base = (unsigned)(buf * STAGE);
     // a_nt: the A panel is read by exactly one workgroup (row-complete tile) -- stream it
     // non-temporally so it does not evict the W panel every workgroup re-reads from L2
-    if (p.a_nt) {
+    if constexpr (ASM_DMA) {
 #pragma unroll
-      for (int i = 0; i < AI; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + ka),
-                                         (__attribute__((address_space(3))) void*)(base + (i * NW + wave) * 1024),
-                                         16, 0, 2);
+      for (int i = 0; i < AI; ++i) dma16(a_src[i] + ka, base + (i * NW + wave) * 1024, p.a_nt != 0);
+#pragma unroll
+      for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0, base + A_BYTES + (i * NW + wave) * 1024, false);
     } else {
 #pragma unroll
       for (int i = 0; i < AI; ++i)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + ka),
-                                         (__attribute__((address_space(3))) void*)(base + (i * NW + wave) * 1024),
+                                         (__attribute__((address_space(3))) void*)(smem + base + (i * NW + wave) * 1024),
+                                         16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < WI; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(smem + base + A_BYTES + (i * NW + wave) * 1024),
                                          16, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < WI; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + (i * NW + wave) * 1024),
-                                       16, 0, 0);
   };
 
   // fragment read offsets (bytes) inside a stage; the swizzle term only depends on lane
@@ -137,47 +155,23 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   const int a_off = (wr * WM + frow) * 128;
   const int w_off = A_BYTES + (wc * WN + frow) * 128;
 
-  V8 paf[2][PRELOAD ? MT : 1], pwf[2][PRELOAD ? NT : 1];  // fragment registers of the PRELOAD path
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt landed for every wave; every wave is done with tile kt-1
     if (kt + 1 < nk && !(p.dbg_nodma & 1)) stage((kt + 1) & 1, kt + 1);  // dbg_nodma: timing-only build of the compute phase
     const char* sb = smem + (kt & 1) * STAGE;
-    if constexpr (PRELOAD) {
-      // both k-steps' fragments are requested up front: the LDS latency of step 1 hides under
-      // the MFMAs of step 0 (the compiler places counted lgkmcnt waits), so a wave exposes
-      // one LDS round trip per K-tile instead of two
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int slot = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
+      V8 af[MT], wf[NT];
       if (!(p.dbg_nodma & 2) || kt == 0) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int slot = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
-#pragma unroll
-          for (int i = 0; i < MT; ++i) paf[ks][i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
-#pragma unroll
-          for (int j = 0; j < NT; ++j) pwf[ks][j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
-        }
-      }
-      if (!(p.dbg_nodma & 4)) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(pwf[ks][j], paf[ks][i], acc[i][j]);
-          __builtin_amdgcn_s_setprio(0);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int slot = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
-        V8 af[MT], wf[NT];
+        for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
 #pragma unroll
         for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
+      }
+      if (!(p.dbg_nodma & 4)) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
