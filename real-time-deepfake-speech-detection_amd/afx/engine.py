@@ -107,6 +107,31 @@ class Engine:
         check(l.afx_head_forward(self._h, ptr(f), B, T, ptr(out), ptr(ws), ws.numel(), stream_ptr()))
         return out
 
+    # ---- hipGraph replay: the ~130 launches of a forward as ONE graph launch ----------
+    def capture(self, B, L):
+        """Capture forward() for a fixed (B, L) into a hipGraph (the engine allocates nothing
+        and never synchronises inside a forward, so the whole launch sequence is capturable).
+        Returns ``run(wave) -> logits``: copies the batch into the graph's static input and
+        replays.  Worth it for small, latency-bound batches (B = 1 streaming-style calls),
+        where host launch overhead is comparable to the GPU time."""
+        static_in = torch.zeros(B, L, dtype=torch.float32, device="cuda")
+        self._workspace(lib().afx_workspace_bytes(self._h, B, L))
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):  # warm-up outside the capture (one-off attribute calls, allocations)
+            self.forward(static_in)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = self.forward(static_in)
+
+        def run(wave):
+            static_in.copy_(self._wave(wave), non_blocking=True)
+            graph.replay()
+            return static_out
+        run.graph = graph
+        return run
+
     # ---- per-kernel-class timing (bench.py roofline leg) -----------------------------
     def profile_begin(self):
         check(lib().afx_profile_begin(self._h))

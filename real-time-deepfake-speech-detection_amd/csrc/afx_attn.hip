@@ -88,8 +88,7 @@ __global__ __launch_bounds__(256) void mhsa_kernel(const typename HT::T* __restr
         s[kt][r] = v;
         mx = fmaxf(mx, v);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = rows_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
@@ -99,8 +98,7 @@ __global__ __launch_bounds__(256) void mhsa_kernel(const typename HT::T* __restr
         s[kt][r] = e;
         sum += e;
       }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = rows_sum(sum);
     const float rinv = 1.0f / sum;
 
     // O = P V : k-slot (g, jj) of step s2 <-> key 32*s2 + 16*(jj>>2) + 4g + (jj&3)

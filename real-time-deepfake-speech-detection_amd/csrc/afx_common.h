@@ -87,15 +87,68 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-// Full-wave (64-lane) butterfly reductions through DPP/permute shuffles.
+// Full-wave (64-lane) all-reduce without LDS traffic.  __shfl_xor lowers to ds_bpermute
+// (an LDS-crossbar round trip + lgkmcnt wait per step -- six of them per reduction made the
+// LayerNorm statistics the most expensive part of conv0/rownorm).  Here: four DPP steps
+// inside the 16-lane row (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then
+// v_permlane16_swap and v_permlane32_swap fold the four rows -- pure VALU.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// value of the lane 16 (resp. 32) positions away, for every lane
+__device__ __forceinline__ float xor16_partner(float v) {
+  const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  // s[0] = rows {0,0,2,2}, s[1] = rows {1,1,3,3} of v: the partner is whichever differs from v
+  const float a = __uint_as_float(s[0]), b = __uint_as_float(s[1]);
+  return ((threadIdx.x >> 4) & 1) ? a : b;
+}
+__device__ __forceinline__ float xor32_partner(float v) {
+  const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float a = __uint_as_float(s[0]), b = __uint_as_float(s[1]);  // a = {lo,lo}, b = {hi,hi}
+  return ((threadIdx.x >> 5) & 1) ? a : b;
+}
+// reduce over the 4 lanes {l, l^16, l^32, l^48} (the 16-lane rows), result in all of them
+__device__ __forceinline__ float rows_sum(float v) {
+  const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(s[0]) + __uint_as_float(s[1]);
+  const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+__device__ __forceinline__ float rows_max(float v) {
+  const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+  const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror: every lane holds its 16-lane row sum
+  {
+    const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(s[0]) + __uint_as_float(s[1]);  // rows {0+1, 0+1, 2+3, 2+3}
+  }
+  {
+    const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(s[0]) + __uint_as_float(s[1]);
+  }
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  {
+    const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+  }
+  {
+    const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+  }
   return v;
 }
 

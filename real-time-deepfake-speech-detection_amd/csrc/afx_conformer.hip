@@ -136,9 +136,13 @@ template <int DH, class HT>
 static hipError_t launch_conf_attn_t(const float* q, long ldq, const float* kv, long ldkv, const float* rel,
                                      int max_pos, int B, int N, int H, void* out, long ldo, hipStream_t s) {
   const int lds = (int)((4L * N - 1) * DH * sizeof(float));
-  hipError_t e = hipFuncSetAttribute((const void*)conf_attn_kernel<DH, HT>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return e;
+  static int lds_set = 0;  // the attribute is sticky: raise it only when a larger N arrives (graph-capture friendly)
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conf_attn_kernel<DH, HT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    lds_set = lds;
+  }
   hipLaunchKernelGGL((conf_attn_kernel<DH, HT>), dim3(H, B), dim3(256), lds, s, q, ldq, kv, ldkv, rel, max_pos, N,
                      H, (typename HT::T*)out, ldo);
   return hipGetLastError();
@@ -209,14 +213,21 @@ const char* launch_conf_dwconv(const float* x, long ldx, const float* w, const f
   const int lds = (N + k - 1 + k) * 32 * (int)sizeof(float);
   if (lds > 160 * 1024) return "conf_dwconv: sequence too long for the LDS slab";
   dim3 grid((C + 31) / 32, B);
-  hipError_t e;
+  hipError_t e = hipSuccess;
+  static int lds_set[2] = {0, 0};
   if (dtype == DT_BF16) {
-    e = hipFuncSetAttribute((const void*)conf_dwconv_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (lds > lds_set[0]) {
+      e = hipFuncSetAttribute((const void*)conf_dwconv_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) lds_set[0] = lds;
+    }
     if (e == hipSuccess)
       hipLaunchKernelGGL(conf_dwconv_kernel<BF16>, grid, dim3(256), lds, s, x, ldx, w, bias, bn_scale, bn_shift, N, C,
                          k, (__bf16*)out_h, ldo);
   } else {
-    e = hipFuncSetAttribute((const void*)conf_dwconv_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (lds > lds_set[1]) {
+      e = hipFuncSetAttribute((const void*)conf_dwconv_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) lds_set[1] = lds;
+    }
     if (e == hipSuccess)
       hipLaunchKernelGGL(conf_dwconv_kernel<FP16>, grid, dim3(256), lds, s, x, ldx, w, bias, bn_scale, bn_shift, N, C,
                          k, (_Float16*)out_h, ldo);

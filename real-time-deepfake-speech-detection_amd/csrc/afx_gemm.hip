@@ -202,8 +202,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < NT; ++j) s += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
+      s = rows_sum(s);
       if (kq == 0) red[wc * BM + wr * WM + i * 16 + (lane & 15)] = s;
     }
     __syncthreads();
@@ -226,8 +225,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
           acc[i][j][r] -= mean[i];
           s = fmaf(acc[i][j][r], acc[i][j][r], s);
         }
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
+      s = rows_sum(s);
       if (kq == 0) red[wc * BM + wr * WM + i * 16 + (lane & 15)] = s;
     }
     __syncthreads();

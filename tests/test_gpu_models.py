@@ -135,3 +135,43 @@ def test_errors_are_loud(afx_mod):
         eng.ssl(torch.zeros(1, 300, device="cuda"))
     with pytest.raises(AfxError, match="GPU"):
         eng.ssl(torch.zeros(1, 16000))
+
+
+def test_hipgraph_replay_matches_eager_and_harness_writes_scores(afx_mod, tmp_path):
+    """The forward allocates nothing and never synchronises, so it captures into a hipGraph;
+    replay must be bit-identical to the eager launch sequence.  Also the scoring loop
+    (main.py:199-221 semantics) end to end on a toy dataset."""
+    engine, synth = afx_mod
+    from afx import harness
+    sd = synth.model_state_dict("ConformerModel", n_layers=1, n_encoders=1)
+    eng = engine.Engine("conformer", n_layers=1, dtype="fp16", conf_blocks=1)
+    eng.load_state_dict(sd)
+    wave = synth.waveforms(2, 16000, batch_idx=11).cuda()
+    eager = eng.forward(wave).clone()
+    run = eng.capture(2, 16000)
+    assert torch.equal(run(wave), eager)
+    wave2 = synth.waveforms(2, 16000, batch_idx=12).cuda()
+    assert torch.equal(run(wave2), eng.forward(wave2))
+
+    class Toy(torch.utils.data.Dataset):
+        def __len__(self):
+            return 5
+
+        def __getitem__(self, i):
+            return f"utt{i}", synth.waveforms(1, 16000, batch_idx=100 + i)[0], 1
+
+    class Wrap(torch.nn.Module):
+        def forward(self, x):
+            return eng.forward(x)
+
+    path = tmp_path / "scores" / "toy.txt"
+    names, scores = harness.produce_evaluation_file(Toy(), Wrap(), "cuda", str(path), batch_size=2, num_workers=0)
+    lines = path.read_text().strip().split("\n")
+    assert names == [f"utt{i}" for i in range(5)] and len(lines) == 5
+    ref = torch.cat([eng.forward(synth.waveforms(1, 16000, batch_idx=100 + i).cuda())[:, 1] for i in range(5)]).cpu()
+    got = torch.tensor([float(l.split()[1]) for l in lines])
+    assert lines[0].split()[0] == "utt0" and (got - ref).abs().max().item() < 1e-6
+    pe = harness.PreEmphasis(coef=0.97, enabled=True)
+    from oracle import pre
+    x = synth.waveforms(3, 1000, batch_idx=5)
+    assert (pe(x.cuda()).cpu() - pre.pre_emphasis(x)).abs().max().item() < 1e-6

@@ -30,6 +30,19 @@ rc=$?
 cd "$ROOT"
 STATS=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -n 1)
 if [ -n "$STATS" ]; then head -n 25 "$STATS" | tee -a "$OUT/summary.txt"; else tail -n 20 "$OUT/prof.log" | tee -a "$OUT/summary.txt"; fi
-# keep the merge-back small: the per-dispatch trace can be large
-find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
+# per-(kernel, grid) averages from the per-dispatch trace, then drop the (large) trace itself
+python3 - "$OUT" <<'PYEOF'
+import csv, glob, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(list)
+for f in glob.glob(out + "/prof/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[(n, r["Grid_Size_X"], r["Grid_Size_Z"], r["Workgroup_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+with open(out + "/kernel_by_shape.csv", "w") as fh:
+    fh.write("kernel,grid_x_threads,grid_z,wg_size,calls,avg_us,total_ms\n")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        fh.write(f'"{k[0]}",{k[1]},{k[2]},{k[3]},{len(v)},{sum(v)/len(v)/1e3:.1f},{sum(v)/1e6:.3f}\n')
+PYEOF
+find "$OUT/prof" -name "*kernel_trace.csv" -delete 2>/dev/null
 exit 0
