@@ -23,165 +23,22 @@
 
 namespace afx {
 
-// WR x WC waves per workgroup; each wave owns a (BM/WR) x (BN/WC) block of the tile.
-// ROWLN: the tile spans the whole output row (BN == N), and the epilogue applies
-// LayerNorm over the row (two-pass fp32 statistics, partial sums exchanged through LDS
-// between the WC waves of a row) followed by the activation -- the conv feature
-// extractor's "conv -> LayerNorm(512) -> GELU" in one kernel, no fp32 round trip.
-template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false>
-__global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
+// ---------------------------------------------------------------------------------------
+// Epilogue shared by the tile kernels: acc[i][j] (16x16 tiles of the wave's block, operands
+// swapped so a lane holds 4 consecutive columns of one row) -> bias / activation / residual
+// / LayerNorm -> wide stores.
+// ---------------------------------------------------------------------------------------
+template <class HT, int BM, int BN, int WR, int WC, bool ROWLN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / WR / 16][BN / WC / 16], char* smem,
+                                              int m0, int n0, int g) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
   typedef typename HT::V4 V4;
-  constexpr int NW = WR * WC;
   constexpr int WM = BM / WR, WN = BN / WC;
   constexpr int MT = WM / 16, NT = WN / 16;
-  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
-  constexpr int AI = BM / (8 * NW), WI = BN / (8 * NW);  // LDS-DMA instructions per thread per tile
-  static_assert(AI >= 1 && WI >= 1, "tile too small for the wave count");
-  constexpr bool ASM_DMA = ROWLN;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WC, wc = wave % WC;
-  const int g = blockIdx.z;
-  // ---- workgroup -> tile mapping (speed only; any mapping is correct) ----------------
-  // Workgroups are dealt round-robin over the 8 XCDs (private 4-MB L2 each).  map 1/2
-  // give every XCD a contiguous run of the logical tile order, so tiles that share an A
-  // row-panel (all N-tiles of one M-tile) or a W panel meet in ONE L2 instead of being
-  // re-fetched by up to 8 of them; map 2 additionally walks the tiles in GROUP_M x nN
-  // super-tiles so both panels of the working set stay L2-resident.
-  int pm, pn;
-  {
-    const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
-    const int nwg = nM * nN;
-    int L = blockIdx.x;
-    if (p.map_mode >= 1) {
-      const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
-      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);  // bijective for any nwg
-    }
-    if (p.map_mode == 2) {
-      constexpr int GM = 8;
-      const int width = GM * nN, grp = L / width, first = grp * GM;
-      const int gsz = nM - first < GM ? nM - first : GM;
-      pm = first + (L % width) % gsz;
-      pn = (L % width) / gsz;
-    } else {
-      pm = L / nN;
-      pn = L % nN;
-    }
-  }
-  const int m0 = pm * BM, n0 = pn * BN;
-
-  const T* Ag = (const T*)p.A + (long)g * p.g_a;
-  const T* Wg = (const T*)p.W + (long)g * p.g_w;
-
-  // per-lane source pointers (k = 0) of the chunks this lane DMAs each K-tile
-  const T* a_src[AI];
-  const T* w_src[WI];
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int row = (i * NW + wave) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    int m = m0 + row;
-    m = m < p.M ? m : p.M - 1;
-    a_src[i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < WI; ++i) {
-    const int row = (i * NW + wave) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    int n = n0 + row;
-    n = n < p.N ? n : p.N - 1;
-    w_src[i] = Wg + (long)n * p.ldw + c * 8;
-  }
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K >> 6;
-
-  // ASM_DMA (one workgroup per CU, so a wave must overlap its own LDS reads with its MFMAs;
-  // measured +20 % on the row-complete conv tile, -5 % on the 2-workgroup-per-CU 128x128 tile):
-  // LDS-DMA through inline asm: with the builtin in the loop hipcc's waitcnt pass stops
-  // counting lgkmcnt (every ds_read group is followed by lgkmcnt(0), so a wave never overlaps
-  // its LDS reads with its MFMAs); hidden in asm, the compiler keeps fine-grained counted
-  // waits for the fragment reads, and the DMA's own completion is waited by hand (vmcnt(0)
-  // at the top of each K-tile).  M0 (the LDS destination base) is saved and restored inside
-  // the statement, as the cdna guide prescribes.
-  const unsigned lds_base = (unsigned)(size_t)smem;
-  auto dma16 = [&](const T* src, unsigned lds_off, bool nt) {
-    unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + lds_off);
-    if (nt)
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-    else
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-  };
-  auto stage = [&](int buf, int kt) {
-    const int k0 = kt << 6;
-    const long ka = (long)(k0 / p.kchunk) * p.kchunk_stride + (k0 % p.kchunk);
-    const unsigned base = (unsigned)(buf * STAGE);
-    // a_nt: the A panel is read by exactly one workgroup (row-complete tile) -- stream it
-    // non-temporally so it does not evict the W panel every workgroup re-reads from L2
-    if constexpr (ASM_DMA) {
-#pragma unroll
-      for (int i = 0; i < AI; ++i) dma16(a_src[i] + ka, base + (i * NW + wave) * 1024, p.a_nt != 0);
-#pragma unroll
-      for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0, base + A_BYTES + (i * NW + wave) * 1024, false);
-    } else {
-#pragma unroll
-      for (int i = 0; i < AI; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + ka),
-                                         (__attribute__((address_space(3))) void*)(smem + base + (i * NW + wave) * 1024),
-                                         16, 0, 0);
-#pragma unroll
-      for (int i = 0; i < WI; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0),
-                                         (__attribute__((address_space(3))) void*)(smem + base + A_BYTES + (i * NW + wave) * 1024),
-                                         16, 0, 0);
-    }
-  };
-
-  // fragment read offsets (bytes) inside a stage; the swizzle term only depends on lane
-  const int frow = lane & 15;
-  const int fsw = (frow >> 1) & 7;
-  const int a_off = (wr * WM + frow) * 128;
-  const int w_off = A_BYTES + (wc * WN + frow) * 128;
-
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile kt landed for every wave; every wave is done with tile kt-1
-    if (kt + 1 < nk && !(p.dbg_nodma & 1)) stage((kt + 1) & 1, kt + 1);  // dbg_nodma: timing-only build of the compute phase
-    const char* sb = smem + (kt & 1) * STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int slot = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
-      V8 af[MT], wf[NT];
-      if (!(p.dbg_nodma & 2) || kt == 0) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
-      }
-      if (!(p.dbg_nodma & 4)) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-      }
-    }
-  }
-
   // epilogue: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]
   if constexpr (ROWLN) {
     static_assert(BN % (16 * WC) == 0, "row-complete tile");
@@ -395,6 +252,355 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   }
 }
 
+// WR x WC waves per workgroup; each wave owns a (BM/WR) x (BN/WC) block of the tile.
+// ROWLN: the tile spans the whole output row (BN == N), and the epilogue applies
+// LayerNorm over the row (two-pass fp32 statistics, partial sums exchanged through LDS
+// between the WC waves of a row) followed by the activation -- the conv feature
+// extractor's "conv -> LayerNorm(512) -> GELU" in one kernel, no fp32 round trip.
+template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false>
+__global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+  typedef typename HT::V4 V4;
+  constexpr int NW = WR * WC;
+  constexpr int WM = BM / WR, WN = BN / WC;
+  constexpr int MT = WM / 16, NT = WN / 16;
+  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+  constexpr int AI = BM / (8 * NW), WI = BN / (8 * NW);  // LDS-DMA instructions per thread per tile
+  static_assert(AI >= 1 && WI >= 1, "tile too small for the wave count");
+  constexpr bool ASM_DMA = ROWLN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int g = blockIdx.z;
+  // ---- workgroup -> tile mapping (speed only; any mapping is correct) ----------------
+  // Workgroups are dealt round-robin over the 8 XCDs (private 4-MB L2 each).  map 1/2
+  // give every XCD a contiguous run of the logical tile order, so tiles that share an A
+  // row-panel (all N-tiles of one M-tile) or a W panel meet in ONE L2 instead of being
+  // re-fetched by up to 8 of them; map 2 additionally walks the tiles in GROUP_M x nN
+  // super-tiles so both panels of the working set stay L2-resident.
+  int pm, pn;
+  {
+    const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
+    const int nwg = nM * nN;
+    int L = blockIdx.x;
+    if (p.map_mode >= 1) {
+      const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);  // bijective for any nwg
+    }
+    if (p.map_mode == 2) {
+      constexpr int GM = 8;
+      const int width = GM * nN, grp = L / width, first = grp * GM;
+      const int gsz = nM - first < GM ? nM - first : GM;
+      pm = first + (L % width) % gsz;
+      pn = (L % width) / gsz;
+    } else {
+      pm = L / nN;
+      pn = L % nN;
+    }
+  }
+  const int m0 = pm * BM, n0 = pn * BN;
+
+  const T* Ag = (const T*)p.A + (long)g * p.g_a;
+  const T* Wg = (const T*)p.W + (long)g * p.g_w;
+
+  // per-lane source pointers (k = 0) of the chunks this lane DMAs each K-tile
+  const T* a_src[AI];
+  const T* w_src[WI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;
+    a_src[i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int n = n0 + row;
+    n = n < p.N ? n : p.N - 1;
+    w_src[i] = Wg + (long)n * p.ldw + c * 8;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K >> 6;
+
+  // ASM_DMA (one workgroup per CU, so a wave must overlap its own LDS reads with its MFMAs;
+  // measured +20 % on the row-complete conv tile, -5 % on the 2-workgroup-per-CU 128x128 tile):
+  // LDS-DMA through inline asm: with the builtin in the loop hipcc's waitcnt pass stops
+  // counting lgkmcnt (every ds_read group is followed by lgkmcnt(0), so a wave never overlaps
+  // its LDS reads with its MFMAs); hidden in asm, the compiler keeps fine-grained counted
+  // waits for the fragment reads, and the DMA's own completion is waited by hand (vmcnt(0)
+  // at the top of each K-tile).  M0 (the LDS destination base) is saved and restored inside
+  // the statement, as the cdna guide prescribes.
+  const unsigned lds_base = (unsigned)(size_t)smem;
+  auto dma16 = [&](const T* src, unsigned lds_off, bool nt) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + lds_off);
+    if (nt)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    else
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
+  auto stage = [&](int buf, int kt) {
+    const int k0 = kt << 6;
+    const long ka = (long)(k0 / p.kchunk) * p.kchunk_stride + (k0 % p.kchunk);
+    const unsigned base = (unsigned)(buf * STAGE);
+    // a_nt: the A panel is read by exactly one workgroup (row-complete tile) -- stream it
+    // non-temporally so it does not evict the W panel every workgroup re-reads from L2
+    if constexpr (ASM_DMA) {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) dma16(a_src[i] + ka, base + (i * NW + wave) * 1024, p.a_nt != 0);
+#pragma unroll
+      for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0, base + A_BYTES + (i * NW + wave) * 1024, false);
+    } else {
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + ka),
+                                         (__attribute__((address_space(3))) void*)(smem + base + (i * NW + wave) * 1024),
+                                         16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < WI; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(smem + base + A_BYTES + (i * NW + wave) * 1024),
+                                         16, 0, 0);
+    }
+  };
+
+  // fragment read offsets (bytes) inside a stage; the swizzle term only depends on lane
+  const int frow = lane & 15;
+  const int fsw = (frow >> 1) & 7;
+  const int a_off = (wr * WM + frow) * 128;
+  const int w_off = A_BYTES + (wc * WN + frow) * 128;
+
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile kt landed for every wave; every wave is done with tile kt-1
+    if (kt + 1 < nk && !(p.dbg_nodma & 1)) stage((kt + 1) & 1, kt + 1);  // dbg_nodma: timing-only build of the compute phase
+    const char* sb = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int slot = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
+      V8 af[MT], wf[NT];
+      if (!(p.dbg_nodma & 2) || kt == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
+      }
+      if (!(p.dbg_nodma & 4)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  }
+
+  gemm_epilogue<HT, BM, BN, WR, WC, ROWLN>(p, acc, smem, m0, n0, g);
+}
+
+// =======================================================================================
+// Deep-pipelined tile kernel (one workgroup of 8 waves per CU):
+//   * K advances in steps of 32 (one MFMA k-step); LDS holds a ring of FOUR stages
+//     (4 x (BM+BN) x 64 B), so the operand DMA runs THREE steps ahead of the MFMAs;
+//   * LDS-DMA is issued from inline asm and retired with COUNTED vmcnt (never 0 in the
+//     steady state) in front of a raw s_barrier -- loads stay in flight across barriers;
+//   * the fragments of step t+1 are requested into a second register set while the MFMAs of
+//     step t run (hipcc places counted lgkmcnt waits, the DMA being invisible to it), so a
+//     wave's matrix-core stream is not interrupted by LDS latency;
+//   * 64-B LDS rows, 16-B chunk index XOR-swizzled with (-(row>>2))&3: every ds_read_b128
+//     lane group {0-3,12-15,20-27}.. then covers the 16 slots of a 256-B bank row once.
+// Hazards: the DMA issued in step t overwrites the stage of tile t-1, whose fragment reads
+// were consumed (waited) by the MFMAs of step t-1, i.e. before every wave reached the
+// barrier of step t; a tile is read (step t-1) only after the wait+barrier of step t-1 that
+// retired its DMA on every wave.
+// =======================================================================================
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 10, "extend the table");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+}
+
+template <class HT, int BM, int BN, bool ROWLN>
+__global__ __launch_bounds__(512) void gemm_deep_kernel(GemmArgs p) {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+  constexpr int WR = 2, WC = 4, NW = 8;
+  constexpr int WM = BM / WR, WN = BN / WC;
+  constexpr int MT = WM / 16, NT = WN / 16;
+  constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;  // 32 halfs per row
+  constexpr int AI = BM / (16 * NW), WI = BN / (16 * NW);  // 1-KB DMA pieces (16 rows) per wave per step
+  constexpr int G = AI + WI;                               // LDS-DMA instructions per thread per step
+  static_assert(AI >= 1 && WI >= 1 && 4 * STAGE <= 160 * 1024, "tile / ring does not fit");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int g = blockIdx.z;
+  int pm, pn;
+  {
+    const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
+    const int nwg = nM * nN;
+    int L = blockIdx.x;
+    if (p.map_mode >= 1) {
+      const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    }
+    if (p.map_mode == 2) {
+      constexpr int GM = 8;
+      const int width = GM * nN, grp = L / width, first = grp * GM;
+      const int gsz = nM - first < GM ? nM - first : GM;
+      pm = first + (L % width) % gsz;
+      pn = (L % width) / gsz;
+    } else {
+      pm = L / nN;
+      pn = L % nN;
+    }
+  }
+  const int m0 = pm * BM, n0 = pn * BN;
+  const T* Ag = (const T*)p.A + (long)g * p.g_a;
+  const T* Wg = (const T*)p.W + (long)g * p.g_w;
+
+  // DMA source pointers: piece (i*NW + wave) covers 16 rows x 64 B; lane l -> row l>>2, slot l&3
+  const T* a_src[AI];
+  const T* w_src[WI];
+  const int prow = lane >> 2;
+  const int pch = (lane & 3) ^ ((-(prow >> 2)) & 3);  // logical chunk stored at this lane's slot
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    int m = m0 + (i * NW + wave) * 16 + prow;
+    m = m < p.M ? m : p.M - 1;
+    a_src[i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + pch * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    int n = n0 + (i * NW + wave) * 16 + prow;
+    n = n < p.N ? n : p.N - 1;
+    w_src[i] = Wg + (long)n * p.ldw + pch * 8;
+  }
+  const unsigned lds_base = (unsigned)(size_t)smem;
+  auto dma16 = [&](const T* src, unsigned lds_off, bool nt) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + lds_off);
+    if (nt)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    else
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
+  auto stage = [&](int t) {  // DMA of K-step t into ring slot t & 3
+    const int k0 = t << 5;
+    const long ka = (long)(k0 / p.kchunk) * p.kchunk_stride + (k0 % p.kchunk);
+    const unsigned base = (unsigned)((t & 3) * STAGE);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) dma16(a_src[i] + ka, base + (i * NW + wave) * 1024, p.a_nt != 0);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0, base + A_BYTES + (i * NW + wave) * 1024, false);
+  };
+
+  // fragment addresses: row (lane&15) of a 16-row tile, logical chunk lane>>4 of the 4 in a row
+  const int frow = lane & 15;
+  const int fslot = ((lane >> 4) ^ ((-(frow >> 2)) & 3)) * 16;
+  const int a_off = (wr * WM + frow) * 64 + fslot;
+  const int w_off = A_BYTES + (wc * WN + frow) * 64 + fslot;
+  auto load_frags = [&](int t, V8 (&af)[MT], V8 (&wf)[NT]) {
+    const char* sb = smem + (t & 3) * STAGE;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + a_off + i * 16 * 64);
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mfmas = [&](V8 (&af)[MT], V8 (&wf)[NT]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  const int nk = p.K >> 5;
+  V8 afA[MT], wfA[NT], afB[MT], wfB[NT];
+  // prologue: three steps in flight, then the fragments of step 0
+  stage(0);
+  if (nk > 1) stage(1);
+  if (nk > 2) stage(2);
+  if (nk > 2) wait_vmcnt<2 * G>();
+  else if (nk > 1) wait_vmcnt<G>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  load_frags(0, afA, wfA);
+
+  // one step: retire the DMA of tile t+1, barrier, queue tile t+3, request the fragments of
+  // tile t+1 into the other register set, run the MFMAs of tile t
+#define AFX_DEEP_STEP(t, AF_CUR, WF_CUR, AF_NXT, WF_NXT)        \
+  {                                                             \
+    if ((t) + 2 < nk) wait_vmcnt<G>();                          \
+    else wait_vmcnt<0>();                                       \
+    __builtin_amdgcn_s_barrier();                               \
+    if ((t) + 3 < nk) stage((t) + 3);                           \
+    if ((t) + 1 < nk) load_frags((t) + 1, AF_NXT, WF_NXT);      \
+    mfmas(AF_CUR, WF_CUR);                                      \
+  }
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    AFX_DEEP_STEP(t, afA, wfA, afB, wfB)
+    AFX_DEEP_STEP(t + 1, afB, wfB, afA, wfA)
+  }
+  if (t < nk) AFX_DEEP_STEP(t, afA, wfA, afB, wfB)
+#undef AFX_DEEP_STEP
+
+  gemm_epilogue<HT, BM, BN, WR, WC, ROWLN>(p, acc, smem, m0, n0, g);
+}
+
+template <class HT, int BM, int BN, bool ROWLN>
+static hipError_t launch_gemm_deep_t(const GemmArgs& p, int groups, hipStream_t s) {
+  constexpr int lds = 4 * (BM + BN) * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_deep_kernel<HT, BM, BN, ROWLN>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
+  hipLaunchKernelGGL((gemm_deep_kernel<HT, BM, BN, ROWLN>), grid, dim3(512), lds, s, p);
+  return hipGetLastError();
+}
+
 template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false>
 static hipError_t launch_gemm_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
@@ -417,6 +623,8 @@ void gemm_set_map_mode(int m) { g_map_override = m; }
 void gemm_set_tile(int t) { g_tile_override = t; }
 static int g_ant_override = -1;  // non-temporal A loads: -1 auto (row-complete tile only), 0, 1
 void gemm_set_a_nt(int v) { g_ant_override = v; }
+static int g_deep = 0;  // 1: use the deep-pipelined kernels where they exist (A/B knob)
+void gemm_set_deep(int v) { g_deep = v; }
 static int g_nodma = 0;  // timing-only: skip the operand DMA after the first K-tile (WRONG results)
 void gemm_set_nodma(int v) { g_nodma = v; }
 
@@ -443,7 +651,8 @@ bool gemm_is_narrow(int N) { return N <= 64 || (N > 128 && N < 256 && N % 128 !=
 // this kernel) but quantise badly at M = B*199: measured faster only for the conv layers
 // (huge M, N = 512) and the K = 4096 FFN product (tools/bench_gemm.py, profiles/).
 int gemm_tile_of(const GemmArgs& p, int groups) {
-  if (p.ln_gamma) return 3;
+  if (p.ln_gamma) return g_deep == 1 ? 6 : 3;
+  if (g_deep == 1 && groups == 1 && !gemm_is_narrow(p.N) && g_tile_override == 1) return 5;
   if (gemm_is_narrow(p.N)) return 1;
   if (groups != 1) return 0;
   if (g_tile_override == 2) return 4;  // 256x128 / 8 waves (A/B only: slower everywhere measured)
@@ -466,6 +675,8 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
     case 4: return launch_gemm_t<HT, 256, 128, 4, 2>(p, groups, s);
+    case 5: return launch_gemm_deep_t<HT, 256, 256, false>(p, groups, s);
+    case 6: return launch_gemm_deep_t<HT, 128, 512, true>(p, groups, s);
     default: return launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
   }
 }

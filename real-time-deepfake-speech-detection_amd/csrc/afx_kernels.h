@@ -53,6 +53,7 @@ int gemm_tile_of(const GemmArgs& p, int groups);  // 0: 128x128, 1: 128x64, 2: 2
 void gemm_set_map_mode(int m);  // A/B knob: -1 default, else force map_mode
 void gemm_set_tile(int t);      // A/B knob: -1 default, 0: 128x128 tile, 1: 256x256 tile
 void gemm_set_a_nt(int v);      // A/B knob: -1 auto, 0/1 non-temporal A-panel loads
+void gemm_set_deep(int v);      // A/B knob: 1 = deep-pipelined tile kernels
 void gemm_set_nodma(int v);     // timing-only knob: compute phase without operand DMA (wrong results)
 
 // ---- frontend / row kernels (afx_frontend.hip) ---------------------------------

@@ -54,7 +54,7 @@ def test_gemm_epilogues(K, dtype, M, N, K_):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, "deep"])
 def test_gemm_tile_variants_agree_with_reference(K, dtype, tile):
     """Both tile instances (128x128 / 4 waves, 256x256 / 8 waves) and every workgroup->tile
     mapping must give the same numbers; M, N tails included."""
@@ -66,6 +66,9 @@ def test_gemm_tile_variants_agree_with_reference(K, dtype, tile):
     bias = torch.randn(N, generator=g)
     ref = F.gelu(A.float() @ W.float().t() + bias)
     try:
+        if tile == "deep":  # the deep-pipelined 256x256 kernel (4-stage ring, counted vmcnt)
+            check(lib().afx_debug_set(b"gemm_deep", 1))
+            tile = 1
         check(lib().afx_debug_set(b"gemm_tile", tile))
         for mode in (0, 1, 2):
             check(lib().afx_debug_set(b"gemm_map", mode))
@@ -74,6 +77,7 @@ def test_gemm_tile_variants_agree_with_reference(K, dtype, tile):
     finally:
         check(lib().afx_debug_set(b"gemm_tile", -1))
         check(lib().afx_debug_set(b"gemm_map", -1))
+        check(lib().afx_debug_set(b"gemm_deep", 0))
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -113,7 +117,8 @@ def test_conv_layer_as_gemm(K, dtype, k, s, Tin):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("k,s,Tin", [(3, 2, 301), (2, 2, 40)])
-def test_conv_layer_with_fused_layernorm_gelu(K, dtype, k, s, Tin):
+@pytest.mark.parametrize("deep", [0, 1])
+def test_conv_layer_with_fused_layernorm_gelu(K, dtype, k, s, Tin, deep):
     """Row-complete 128x512 tile: conv + bias + LayerNorm(512) + GELU in one kernel, M tail
     (B*Tout not a multiple of 128) included; fp32 and operand-type outputs."""
     g = torch.Generator().manual_seed(100 + k)
@@ -123,7 +128,12 @@ def test_conv_layer_with_fused_layernorm_gelu(K, dtype, k, s, Tin):
     ga = 1 + 0.1 * torch.randn(512, generator=g)
     be = 0.1 * torch.randn(512, generator=g)
     wp = K.pack_conv(dtype, w.cuda())
-    of, oh = K.conv_ln_act(dtype, x.cuda(), wp, k, s, bias.cuda(), ga.cuda(), be.cuda(), out_f=True, out_h=True)
+    from afx._lib import check, lib
+    check(lib().afx_debug_set(b"gemm_deep", deep))
+    try:
+        of, oh = K.conv_ln_act(dtype, x.cuda(), wp, k, s, bias.cuda(), ga.cuda(), be.cuda(), out_f=True, out_h=True)
+    finally:
+        check(lib().afx_debug_set(b"gemm_deep", 0))
     ref = F.conv1d(x.float().transpose(1, 2), w.to(_td(dtype)).float(), bias, stride=s).transpose(1, 2)
     ref = F.gelu(F.layer_norm(ref, (512,), ga, be, 1e-5))
     assert of.shape == ref.shape

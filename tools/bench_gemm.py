@@ -31,6 +31,9 @@ SETS = {
     "map": [("map0", ("gemm_map", 0)), ("map1", ("gemm_map", 1)), ("map2", ("gemm_map", 2))],
     "nt": [("A default", ("gemm_a_nt", 0)), ("A nt", ("gemm_a_nt", 1))],
     "nodma": [("full", ("gemm_nodma", 0)), ("compute-only", ("gemm_nodma", 1))],
+    "deep": [("2-stage", ("gemm_deep", 0)), ("deep ring", ("gemm_deep", 1))],
+    "deep256": [("128x128", [("gemm_deep", 0), ("gemm_tile", 0)]), ("256x256 2-stage", [("gemm_deep", 0), ("gemm_tile", 1)]),
+                ("256x256 deep", [("gemm_deep", 1), ("gemm_tile", 1)])],
     "epi": [("narrow stores", ("gemm_nodma", 16)), ("wide stores", ("gemm_nodma", 0))],
     "attr": [("full", ("gemm_nodma", 0)), ("-dma", ("gemm_nodma", 1)), ("-dma-lds", ("gemm_nodma", 3)),
              ("-dma-mfma", ("gemm_nodma", 5)), ("-dma-act", ("gemm_nodma", 9)), ("-dma-lds-mfma-act", ("gemm_nodma", 15))],
@@ -38,7 +41,7 @@ SETS = {
 VARIANTS = SETS[os.environ.get("BENCH_SET", "tile")]
 if os.environ.get("BENCH_SET") == "attr":
     SHAPES = [SHAPES[0], SHAPES[3], SHAPES[5], SHAPES[6]]
-if os.environ.get("BENCH_SET") in ("nt", "nodma"):  # the fused conv + LayerNorm kernel (row-complete tile)
+if os.environ.get("BENCH_SET") in ("nt", "nodma", "deep"):  # the fused conv + LayerNorm kernel (row-complete tile)
     SHAPES = [("convln1 M=409536 K=1536", "convln", (B, 12799, 3, 2)), ("convln2 M=204736 K=1536", "convln", (B, 6399, 3, 2)),
               ("convln3 M=102336 K=1536", "convln", (B, 3199, 3, 2)), ("convln5 M=25536 K=1024", "convln", (B, 799, 2, 2))] + SHAPES[3:]
 
@@ -76,8 +79,9 @@ def main():
         for _ in range(2):
             fn()
         for _ in range(rounds):
-            for v, (key, val) in VARIANTS:
-                check(lib().afx_debug_set(key.encode(), val))
+            for v, kv in VARIANTS:
+                for key, val in (kv if isinstance(kv, list) else [kv]):
+                    check(lib().afx_debug_set(key.encode(), val))
                 fn()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -89,8 +93,10 @@ def main():
         row = "  ".join(f"{v}: {flops / (statistics.median(t) * 1e-3) / 1e12:6.0f} TF ({statistics.median(t) * 1e3:6.1f} us)"
                         for v, t in times.items())
         print(f"{name:36s} {row}", flush=True)
-    for key in {k for _, (k, _) in VARIANTS}:
-        check(lib().afx_debug_set(key.encode(), 0 if key == "gemm_nodma" else -1))
+    for key in ("gemm_tile", "gemm_map", "gemm_a_nt"):
+        check(lib().afx_debug_set(key.encode(), -1))
+    for key in ("gemm_nodma", "gemm_deep"):
+        check(lib().afx_debug_set(key.encode(), 0))
 
 
 if __name__ == "__main__":
