@@ -35,7 +35,7 @@ extern "C" {
 typedef struct afx_engine* afx_handle;
 
 enum { AFX_ARCH_SSL = 0, AFX_ARCH_XLSR_AASIST = 1, AFX_ARCH_CONFORMER = 2 };
-enum { AFX_DT_BF16 = 0, AFX_DT_FP16 = 1 }; /* matrix-core operand type; accumulation is always fp32 */
+enum { AFX_DT_BF16 = 0, AFX_DT_FP16 = 1, AFX_DT_FP32 = 2 }; /* operand type (FP32: exact mode, fp32 MFMA); accumulation is always fp32 */
 
 typedef struct afx_config {
   int arch;          /* AFX_ARCH_* */

@@ -10,14 +10,16 @@ from . import _lib
 from ._lib import AfxError, Config, check, lib, ptr, stream_ptr
 
 ARCHS = {"ssl": _lib.ARCH_SSL, "xlsr_aasist": _lib.ARCH_XLSR_AASIST, "conformer": _lib.ARCH_CONFORMER}
-DTYPES = {"bf16": _lib.DT_BF16, "fp16": _lib.DT_FP16}
+DTYPES = {"bf16": _lib.DT_BF16, "fp16": _lib.DT_FP16, "fp32": _lib.DT_FP32}
 # fp16 and bf16 run at the same matrix-core rate on gfx950; fp16's 3 extra mantissa bits
 # are what keeps the scores within 1e-3 of the fp32 reference (DESIGN.md "Numerics").
+# "fp32" is the exact mode: fp32 operands on the fp32 matrix instruction, 1/16 of the rate,
+# no reduced-precision rounding anywhere -- for parity work, not for throughput.
 DEFAULT_DTYPE = os.environ.get("AFX_DTYPE", "fp16")
 
 
 def torch_dtype(name):
-    return torch.bfloat16 if name == "bf16" else torch.float16
+    return {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[name]
 
 
 class Engine:

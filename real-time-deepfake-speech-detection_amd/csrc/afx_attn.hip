@@ -170,6 +170,10 @@ const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dty
   if (T <= 0 || T > ATT_KEYS) return "mhsa: sequence length must be in 1..224 frames (<= 4.5 s clips)";
   if (B <= 0 || H <= 0) return "mhsa: bad shape";
   const float scale = 0.125f;  // 64^-0.5
+  if (dtype == DT_FP32) {  // exact mode: fp32 VALU attention (afx_conformer.hip), q | k | v fp32 rows
+    const float* f = (const float*)qkv;
+    return launch_conf_attn(f, 3L * H * 64, f + H * 64, 3L * H * 64, nullptr, 0, B, T, H, 64, out, (long)H * 64, DT_FP32, s);
+  }
   if (dtype == DT_BF16)
     launch_mhsa_t<BF16>(qkv, out, B, T, H, scale, s);
   else

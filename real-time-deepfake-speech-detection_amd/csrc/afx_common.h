@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
@@ -31,6 +32,22 @@ struct FP16 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   }
 };
+
+// fp32 "exact mode": the operand buffers hold plain floats (no matrix-core intrinsic here:
+// the fp32 GEMM and attention are separate kernels, afx_gemm_f32.hip / conf_attn).
+struct F32T {
+  typedef float T;
+  typedef f32x8 V8;
+  typedef f32x4 V4;
+};
+
+// run `call` with HT bound to the traits of a DType value
+#define AFX_DISPATCH_HT(dtype, ...)                               \
+  do {                                                            \
+    if ((dtype) == DT_BF16) { typedef BF16 HT; __VA_ARGS__; }     \
+    else if ((dtype) == DT_FP16) { typedef FP16 HT; __VA_ARGS__; } \
+    else { typedef F32T HT; __VA_ARGS__; }                        \
+  } while (0)
 
 constexpr float kSeluAlpha = 1.6732632423543772f;
 constexpr float kSeluScale = 1.0507009873554805f;

@@ -41,7 +41,9 @@ const char* launch_conf_tokens(const float* ll, const float* cls, float bn_scale
 // row (i-j+N-1) is a conflict-free ds_read_b128 (row stride 36 dwords).
 // The (N,N,dh) relative tensor of the reference is never materialised.
 // ---------------------------------------------------------------------------------
-template <int DH, class HT>
+// REL = false drops the relative term: plain softmax(q k^T / sqrt dh) v -- the fp32
+// "exact mode" stand-in for the matrix-core mhsa_kernel of the wav2vec2 trunk.
+template <int DH, class HT, bool REL>
 __global__ __launch_bounds__(256) void conf_attn_kernel(const float* __restrict__ q, long ldq,
                                                         const float* __restrict__ kv, long ldkv,
                                                         const float* __restrict__ rel, int max_pos, int N, int H,
@@ -59,11 +61,13 @@ __global__ __launch_bounds__(256) void conf_attn_kernel(const float* __restrict_
     *(f32x4*)(Ks + j * DH + d4 * 4) = *(const f32x4*)row;
     *(f32x4*)(Vs + j * DH + d4 * 4) = *(const f32x4*)(row + inner);
   }
-  for (int idx = tid; idx < (2 * N - 1) * (DH / 4); idx += 256) {
-    const int r = idx / (DH / 4), d4 = idx % (DH / 4);
-    int dist = r - (N - 1);
-    dist = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
-    *(f32x4*)(Es + r * DH + d4 * 4) = *(const f32x4*)(rel + (long)(dist + max_pos) * DH + d4 * 4);
+  if (REL) {
+    for (int idx = tid; idx < (2 * N - 1) * (DH / 4); idx += 256) {
+      const int r = idx / (DH / 4), d4 = idx % (DH / 4);
+      int dist = r - (N - 1);
+      dist = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
+      *(f32x4*)(Es + r * DH + d4 * 4) = *(const f32x4*)(rel + (long)(dist + max_pos) * DH + d4 * 4);
+    }
   }
   __syncthreads();
   const int i = tid;
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void conf_attn_kernel(const float* __restrict_
 #pragma unroll
       for (int d = 0; d < DH; d += 4) {
         const f32x4 kk = *(const f32x4*)(kr + d);
-        const f32x4 ee = *(const f32x4*)(er + d);
+        const f32x4 ee = REL ? *(const f32x4*)(er + d) : f32x4{0.f, 0.f, 0.f, 0.f};
         s0 = fmaf(qv[d], kk[0] + ee[0], s0);
         s1 = fmaf(qv[d + 1], kk[1] + ee[1], s1);
         s0 = fmaf(qv[d + 2], kk[2] + ee[2], s0);
@@ -132,32 +136,35 @@ __global__ __launch_bounds__(256) void conf_attn_kernel(const float* __restrict_
   }
 }
 
-template <int DH, class HT>
+template <int DH, class HT, bool REL>
 static hipError_t launch_conf_attn_t(const float* q, long ldq, const float* kv, long ldkv, const float* rel,
                                      int max_pos, int B, int N, int H, void* out, long ldo, hipStream_t s) {
-  const int lds = (int)((4L * N - 1) * DH * sizeof(float));
+  const int lds = (int)((REL ? 4L * N - 1 : 2L * N) * DH * sizeof(float));
   static int lds_set = 0;  // the attribute is sticky: raise it only when a larger N arrives (graph-capture friendly)
   if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conf_attn_kernel<DH, HT>,
+    hipError_t e = hipFuncSetAttribute((const void*)conf_attn_kernel<DH, HT, REL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     lds_set = lds;
   }
-  hipLaunchKernelGGL((conf_attn_kernel<DH, HT>), dim3(H, B), dim3(256), lds, s, q, ldq, kv, ldkv, rel, max_pos, N,
-                     H, (typename HT::T*)out, ldo);
+  hipLaunchKernelGGL((conf_attn_kernel<DH, HT, REL>), dim3(H, B), dim3(256), lds, s, q, ldq, kv, ldkv, rel, max_pos,
+                     N, H, (typename HT::T*)out, ldo);
   return hipGetLastError();
 }
 
 const char* launch_conf_attn(const float* q, long ldq, const float* kv, long ldkv, const float* rel, int max_pos,
                              int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s) {
   if (N <= 0 || N > 256) return "conf_attn: sequence (frames + class token) must be <= 256";
-  if ((4L * N - 1) * dh * 4 > 160 * 1024) return "conf_attn: K/V/E window does not fit the 160 KB LDS";
+  if ((rel ? 4L * N - 1 : 2L * N) * dh * 4 > 160 * 1024) return "conf_attn: K/V/E window does not fit the 160 KB LDS";
   if ((ldq % 4) || (ldkv % 4) || (ldo % 4)) return "conf_attn: row strides must be multiples of 4";
-  hipError_t e;
-#define AFX_CA(DHv)                                                                                         \
-  e = dtype == DT_BF16 ? launch_conf_attn_t<DHv, BF16>(q, ldq, kv, ldkv, rel, max_pos, B, N, H, out_h, ldo, s) \
-                       : launch_conf_attn_t<DHv, FP16>(q, ldq, kv, ldkv, rel, max_pos, B, N, H, out_h, ldo, s)
-  if (dh == 36) { AFX_CA(36); }
+  hipError_t e = hipSuccess;
+#define AFX_CA(DHv)                                                                                             \
+  AFX_DISPATCH_HT(dtype, e = launch_conf_attn_t<DHv, HT, true>(q, ldq, kv, ldkv, rel, max_pos, B, N, H, out_h, ldo, s))
+  if (!rel) {  // plain attention (exact-mode trunk): fp32 in, fp32 out, head dim 64
+    if (dh != 64 || dtype != DT_FP32) return "conf_attn: the no-relative-term form is the fp32 trunk attention (dh 64)";
+    e = launch_conf_attn_t<64, F32T, false>(q, ldq, kv, ldkv, nullptr, 0, B, N, H, out_h, ldo, s);
+  }
+  else if (dh == 36) { AFX_CA(36); }
   else if (dh == 32) { AFX_CA(32); }
   else if (dh == 64) { AFX_CA(64); }
   else return "conf_attn: supported head dims are 32, 36 (emb 144 / 4 heads) and 64";
@@ -214,24 +221,17 @@ const char* launch_conf_dwconv(const float* x, long ldx, const float* w, const f
   if (lds > 160 * 1024) return "conf_dwconv: sequence too long for the LDS slab";
   dim3 grid((C + 31) / 32, B);
   hipError_t e = hipSuccess;
-  static int lds_set[2] = {0, 0};
-  if (dtype == DT_BF16) {
-    if (lds > lds_set[0]) {
-      e = hipFuncSetAttribute((const void*)conf_dwconv_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e == hipSuccess) lds_set[0] = lds;
+  static int lds_set[3] = {0, 0, 0};
+  if (dtype < 0 || dtype > 2) return "conf_dwconv: unknown dtype";
+  AFX_DISPATCH_HT(dtype, {
+    if (lds > lds_set[dtype]) {
+      e = hipFuncSetAttribute((const void*)conf_dwconv_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) lds_set[dtype] = lds;
     }
     if (e == hipSuccess)
-      hipLaunchKernelGGL(conf_dwconv_kernel<BF16>, grid, dim3(256), lds, s, x, ldx, w, bias, bn_scale, bn_shift, N, C,
-                         k, (__bf16*)out_h, ldo);
-  } else {
-    if (lds > lds_set[1]) {
-      e = hipFuncSetAttribute((const void*)conf_dwconv_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e == hipSuccess) lds_set[1] = lds;
-    }
-    if (e == hipSuccess)
-      hipLaunchKernelGGL(conf_dwconv_kernel<FP16>, grid, dim3(256), lds, s, x, ldx, w, bias, bn_scale, bn_shift, N, C,
-                         k, (_Float16*)out_h, ldo);
-  }
+      hipLaunchKernelGGL(conf_dwconv_kernel<HT>, grid, dim3(256), lds, s, x, ldx, w, bias, bn_scale, bn_shift, N, C, k,
+                         (HT::T*)out_h, ldo);
+  });
   if (e == hipSuccess) e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -143,7 +143,7 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
   if (!cfg || !out) return fail("afx_create: null argument");
   if (cfg->n_layers < 1 || cfg->n_layers > 24)
     return fail("Number of layers must be at least 1 and at most 24.");  // models/fe.py:60-62
-  if (cfg->dtype != AFX_DT_BF16 && cfg->dtype != AFX_DT_FP16) return fail("afx_create: unknown dtype %d", cfg->dtype);
+  if (cfg->dtype != AFX_DT_BF16 && cfg->dtype != AFX_DT_FP16 && cfg->dtype != AFX_DT_FP32) return fail("afx_create: unknown dtype %d", cfg->dtype);
   if (cfg->arch < AFX_ARCH_SSL || cfg->arch > AFX_ARCH_CONFORMER) return fail("afx_create: unknown arch %d", cfg->arch);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -151,7 +151,7 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
   afx_engine* e = new afx_engine();
   e->cfg = *cfg;
   e->dt = cfg->dtype;
-  e->hsz = 2;
+  e->hsz = dtype_size(cfg->dtype);
   const int nl = cfg->n_layers;
   e->wqkv.assign(nl, nullptr);
   e->wo.assign(nl, nullptr);
@@ -159,15 +159,15 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
   e->w2.assign(nl, nullptr);
   e->bqkv.assign(nl, nullptr);
   bool ok = true;
-  for (int i = 1; i < 7; ++i) ok &= (e->convw[i] = e->dalloc((size_t)kC * kC * kConvK[i] * 2)) != nullptr;
-  ok &= (e->projw = e->dalloc((size_t)kD * kC * 2)) != nullptr;
-  ok &= (e->posw = e->dalloc((size_t)kD * (kD / kPosG) * kPosK * 2)) != nullptr;
+  for (int i = 1; i < 7; ++i) ok &= (e->convw[i] = e->dalloc((size_t)kC * kC * kConvK[i] * e->hsz)) != nullptr;
+  ok &= (e->projw = e->dalloc((size_t)kD * kC * e->hsz)) != nullptr;
+  ok &= (e->posw = e->dalloc((size_t)kD * (kD / kPosG) * kPosK * e->hsz)) != nullptr;
   ok &= (e->pos_norm = (float*)e->dalloc(kPosK * 4)) != nullptr;
   for (int l = 0; l < nl && ok; ++l) {
-    ok &= (e->wqkv[l] = e->dalloc((size_t)3 * kD * kD * 2)) != nullptr;
-    ok &= (e->wo[l] = e->dalloc((size_t)kD * kD * 2)) != nullptr;
-    ok &= (e->w1[l] = e->dalloc((size_t)kF * kD * 2)) != nullptr;
-    ok &= (e->w2[l] = e->dalloc((size_t)kD * kF * 2)) != nullptr;
+    ok &= (e->wqkv[l] = e->dalloc((size_t)3 * kD * kD * e->hsz)) != nullptr;
+    ok &= (e->wo[l] = e->dalloc((size_t)kD * kD * e->hsz)) != nullptr;
+    ok &= (e->w1[l] = e->dalloc((size_t)kF * kD * e->hsz)) != nullptr;
+    ok &= (e->w2[l] = e->dalloc((size_t)kD * kF * e->hsz)) != nullptr;
     ok &= (e->bqkv[l] = (float*)e->dalloc((size_t)3 * kD * 4)) != nullptr;
   }
   if (cfg->arch == AFX_ARCH_CONFORMER) {
@@ -187,18 +187,18 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
     e->FFp = round_up(e->FF, 64);
     e->C2 = 2 * e->E;
     e->C2p = round_up(e->C2, 64);
-    ok &= (e->conf_ll = e->dalloc((size_t)e->E * kD * 2)) != nullptr;
+    ok &= (e->conf_ll = e->dalloc((size_t)e->E * kD * e->hsz)) != nullptr;
     e->blk.resize(e->nblk);
     for (int b = 0; b < e->nblk && ok; ++b) {
       ConfBlock& B = e->blk[b];
-      ok &= (B.ff1_w1 = e->dalloc((size_t)e->FF * e->Ep * 2)) != nullptr;
-      ok &= (B.ff1_w2 = e->dalloc((size_t)e->E * e->FFp * 2)) != nullptr;
-      ok &= (B.ff2_w1 = e->dalloc((size_t)e->FF * e->Ep * 2)) != nullptr;
-      ok &= (B.ff2_w2 = e->dalloc((size_t)e->E * e->FFp * 2)) != nullptr;
-      ok &= (B.wqkv = e->dalloc((size_t)3 * e->inner * e->Ep * 2)) != nullptr;
-      ok &= (B.wout = e->dalloc((size_t)e->E * e->Ep * 2)) != nullptr;
-      ok &= (B.pw1 = e->dalloc((size_t)2 * e->C2 * e->Ep * 2)) != nullptr;
-      ok &= (B.pw2 = e->dalloc((size_t)e->E * e->C2p * 2)) != nullptr;
+      ok &= (B.ff1_w1 = e->dalloc((size_t)e->FF * e->Ep * e->hsz)) != nullptr;
+      ok &= (B.ff1_w2 = e->dalloc((size_t)e->E * e->FFp * e->hsz)) != nullptr;
+      ok &= (B.ff2_w1 = e->dalloc((size_t)e->FF * e->Ep * e->hsz)) != nullptr;
+      ok &= (B.ff2_w2 = e->dalloc((size_t)e->E * e->FFp * e->hsz)) != nullptr;
+      ok &= (B.wqkv = e->dalloc((size_t)3 * e->inner * e->Ep * e->hsz)) != nullptr;
+      ok &= (B.wout = e->dalloc((size_t)e->E * e->Ep * e->hsz)) != nullptr;
+      ok &= (B.pw1 = e->dalloc((size_t)2 * e->C2 * e->Ep * e->hsz)) != nullptr;
+      ok &= (B.pw2 = e->dalloc((size_t)e->E * e->C2p * e->hsz)) != nullptr;
       ok &= (B.bn_scale = (float*)e->dalloc((size_t)e->C2 * 4)) != nullptr;
       ok &= (B.bn_shift = (float*)e->dalloc((size_t)e->C2 * 4)) != nullptr;
     }
@@ -288,7 +288,7 @@ static int load_ssl(afx_engine* e, const std::string& k, const float* src, const
     for (int j = 0; j < 3; ++j) {
       if (t == std::string(proj[j]) + "weight") {
         if (expect_shape(k.c_str(), shape, ndim, {kD, kD})) return 1;
-        KOK(launch_pack_linear(src, kD, kD, kD, (char*)e->wqkv[n] + (size_t)j * kD * kD * 2, e->dt, s));
+        KOK(launch_pack_linear(src, kD, kD, kD, (char*)e->wqkv[n] + (size_t)j * kD * kD * e->hsz, e->dt, s));
         return 0;
       }
       if (t == std::string(proj[j]) + "bias") {
@@ -339,7 +339,7 @@ static int load_conformer(afx_engine* e, const std::string& k, const float* src,
         {"ff1.fn.fn.net.0.weight", B.ff1_w1, e->FF, E, Ep},   {"ff1.fn.fn.net.3.weight", B.ff1_w2, E, e->FF, e->FFp},
         {"ff2.fn.fn.net.0.weight", B.ff2_w1, e->FF, E, Ep},   {"ff2.fn.fn.net.3.weight", B.ff2_w2, E, e->FF, e->FFp},
         {"attn.fn.to_q.weight", B.wqkv, e->inner, E, Ep},
-        {"attn.fn.to_kv.weight", (char*)B.wqkv + (size_t)e->inner * Ep * 2, 2 * e->inner, E, Ep},
+        {"attn.fn.to_kv.weight", (char*)B.wqkv + (size_t)e->inner * Ep * e->hsz, 2 * e->inner, E, Ep},
         {"attn.fn.to_out.weight", B.wout, E, e->inner, Ep},   {"conv.net.2.weight", B.pw1, 2 * e->C2, E, Ep},
         {"conv.net.7.weight", B.pw2, E, e->C2, e->C2p},
     };
@@ -490,7 +490,7 @@ struct Ws {
 
 static size_t carve(const afx_engine* e, int B, int L, int Tfeat, void* base, Ws* w) {
   Carver c(base);
-  const size_t hs = 2;
+  const size_t hs = dtype_size(e->dt);
   int T = Tfeat;
   if (L > 0) {
     conv_lengths(L, w->T);
@@ -560,7 +560,7 @@ static int tap(afx_engine* e, const char* name, const void* src, size_t n, bool 
     t.cap = n;
   }
   t.n = n;
-  if (is_half) {
+  if (is_half && e->dt != AFX_DT_FP32) {
     hipLaunchKernelGGL(half_to_f32_kernel, dim3(1024), dim3(256), 0, s, (const uint16_t*)src, t.p, n,
                        e->dt == AFX_DT_BF16 ? 1 : 0);
     HIP_OK(hipGetLastError());
@@ -586,10 +586,10 @@ extern "C" int afx_tap(afx_handle h, const char* name, float* out, size_t cap, s
 // launch of the forward is bracketed by hipEvents on the launch stream and summed per
 // class afterwards.  Off by default: the normal forward records nothing.
 // ---------------------------------------------------------------------------------
-enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_CONV0, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV,
+enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM_F32, PC_CONV0, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV,
                  PC_MISC, PC_AASIST, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm_kernel<128x128>", "gemm_kernel<128x64>", "gemm_kernel<256x256>",
-                                           "gemm_kernel<128x512,rowLN>", "conv0_kernel", "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel",
+                                           "gemm_kernel<128x512,rowLN>", "gemm_f32_kernel<128x128>", "conv0_kernel", "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel",
                                            "conf_dwconv_kernel", "misc", "aasist_head"};
 struct ProfRec { int cls; hipEvent_t a, b; double flops; };
 struct Profiler {
@@ -631,7 +631,7 @@ static const char* timed(int cls, double flops, hipStream_t s, F&& f) {
 static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) {
   const double fl = 2.0 * g.M * g.N * (g.k_algo ? g.k_algo : g.K) * groups;
   static const int cls[7] = {PC_GEMM128, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM256, PC_GEMM256, PC_GEMM_ROWLN};
-  return timed(cls[gemm_tile_of(g, groups)], fl, s, [&] { return launch_gemm(g, dt, groups, s); });
+  return timed(dt == DT_FP32 ? PC_GEMM_F32 : cls[gemm_tile_of(g, groups)], fl, s, [&] { return launch_gemm(g, dt, groups, s); });
 }
 static const char* P_rownorm(const RowNormArgs& a, int dt, hipStream_t s) {
   return timed(PC_ROWNORM, 0, s, [&] { return launch_rownorm(a, dt, s); });
@@ -713,7 +713,7 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     g.o_batch_rows = T[i]; g.oh_batch_rows = T[i];
     g.bias = cf(i, ".0.bias");
     g.act = ACT_GELU;
-    if (g_fuse_conv_ln) {
+    if (g_fuse_conv_ln && dt != DT_FP32) {
       g.ln_gamma = cf(i, ".2.1.weight"); g.ln_beta = cf(i, ".2.1.bias"); g.ln_eps = kLnEps;
       if (i < 6) {
         g.out_h = out; g.ldo_h = kC;
@@ -752,7 +752,7 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     g.out_f = w.x; g.ldo_f = kD; g.o_batch_rows = Tt; g.o_row_off = 0;
     g.out_h = w.xpad; g.ldo_h = kD; g.oh_batch_rows = Tt + kPosK; g.oh_row_off = kPosPad;
     KOK(launch_gemm(g, dt, 1, s));
-    KOK(timed(PC_MISC, 0, s, [&] { return launch_zero_pad_rows(w.xpad, B, Tt, kD, kPosPad, kPosK - kPosPad, s); }));
+    KOK(timed(PC_MISC, 0, s, [&] { return launch_zero_pad_rows(w.xpad, B, Tt, kD, kPosPad, kPosK - kPosPad, dt, s); }));
   }
   if (tap(e, "proj", w.x, (size_t)M * kD, false, s)) return 1;
   // positional conv (grouped, k=128) + GELU, added to x in place
@@ -822,10 +822,11 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
   }));
   if (tap(e, "tokens", w.xc, (size_t)M * E, false, s)) return 1;
   // K-padding columns of the operand buffers must read as zero
-  HIP_OK(hipMemsetAsync(w.hc, 0, (size_t)M * Ep * 2, s));
-  HIP_OK(hipMemsetAsync(w.ao, 0, (size_t)M * Ep * 2, s));
-  HIP_OK(hipMemsetAsync(w.u, 0, (size_t)M * e->C2p * 2, s));
-  if (e->FFp != e->FF) HIP_OK(hipMemsetAsync(w.hid, 0, (size_t)M * e->FFp * 2, s));
+  const size_t hs = dtype_size(dt);
+  HIP_OK(hipMemsetAsync(w.hc, 0, (size_t)M * Ep * hs, s));
+  HIP_OK(hipMemsetAsync(w.ao, 0, (size_t)M * Ep * hs, s));
+  HIP_OK(hipMemsetAsync(w.u, 0, (size_t)M * e->C2p * hs, s));
+  if (e->FFp != e->FF) HIP_OK(hipMemsetAsync(w.hid, 0, (size_t)M * e->FFp * hs, s));
   for (int b = 0; b < e->nblk; ++b) {
     const std::string P = "conformer.encoder_blocks." + std::to_string(b) + ".";
     ConfBlock& K = e->blk[b];
@@ -971,9 +972,13 @@ extern "C" int afx_head_forward(afx_handle h, const float* feats, int B, int T, 
   hipStream_t s = (hipStream_t)stream;
   const size_t n = (size_t)B * T * kD;
   HIP_OK(hipMemcpyAsync(w.ssl_f, feats, n * 4, hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(f32_to_half_kernel, dim3(1024), dim3(256), 0, s, feats, (uint16_t*)w.ssl_h, n,
-                     h->dt == AFX_DT_BF16 ? 1 : 0);
-  HIP_OK(hipGetLastError());
+  if (h->dt == AFX_DT_FP32) {
+    HIP_OK(hipMemcpyAsync(w.ssl_h, feats, n * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    hipLaunchKernelGGL(f32_to_half_kernel, dim3(1024), dim3(256), 0, s, feats, (uint16_t*)w.ssl_h, n,
+                       h->dt == AFX_DT_BF16 ? 1 : 0);
+    HIP_OK(hipGetLastError());
+  }
   t_prof = g_prof.count(h) ? &g_prof[h] : nullptr;
   return run_head(h, B, T, w, logits, s);
 }

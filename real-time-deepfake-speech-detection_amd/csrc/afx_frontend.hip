@@ -92,12 +92,8 @@ const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w
                          int dtype, hipStream_t s) {
   if (B <= 0 || L < 10 || T0 != (L - 10) / 5 + 1) return "conv0: bad shape";
   dim3 grid((T0 + C0_FB - 1) / C0_FB, B);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(conv0_kernel<BF16>, grid, dim3(256), 0, s, wave, L, T0, w, bias, gamma, beta, pre_emph,
-                       pre_coef, (__bf16*)out_h);
-  else
-    hipLaunchKernelGGL(conv0_kernel<FP16>, grid, dim3(256), 0, s, wave, L, T0, w, bias, gamma, beta, pre_emph,
-                       pre_coef, (_Float16*)out_h);
+  AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL(conv0_kernel<HT>, grid, dim3(256), 0, s, wave, L, T0, w, bias, gamma, beta,
+                                            pre_emph, pre_coef, (HT::T*)out_h));
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
@@ -185,10 +181,7 @@ const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
   if (a.rows <= 0 || a.C <= 0 || a.C > 1024 || a.C % 4) return "rownorm: need 0 < C <= 1024, C % 4 == 0";
   if (!a.out_f && !a.out_h) return "rownorm: no output";
   dim3 grid((a.rows + 3) / 4);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(rownorm_kernel<BF16>, grid, dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(rownorm_kernel<FP16>, grid, dim3(256), 0, s, a);
+  AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL(rownorm_kernel<HT>, grid, dim3(256), 0, s, a));
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
@@ -196,6 +189,7 @@ const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
 // ---------------------------------------------------------------------------------
 // zero the time-padding rows of the positional-conv operand buffer (B, pf+T+pb, C)
 // ---------------------------------------------------------------------------------
+// (C counts 2-byte units: an fp32 buffer passes 2 x its channel count)
 __global__ void zero_pad_rows_kernel(uint16_t* buf, int T, int C, int pf, int pb) {
   const int b = blockIdx.y;
   const int rows = pf + pb;
@@ -208,8 +202,9 @@ __global__ void zero_pad_rows_kernel(uint16_t* buf, int T, int C, int pf, int pb
     *(u32x4*)(buf + b * per + (long)r * C + c) = u32x4{0u, 0u, 0u, 0u};
   }
 }
-const char* launch_zero_pad_rows(void* buf_h, int B, int T, int C, int pf, int pb, hipStream_t s) {
+const char* launch_zero_pad_rows(void* buf_h, int B, int T, int C, int pf, int pb, int dtype, hipStream_t s) {
   if (C % 8) return "zero_pad_rows: C % 8 != 0";
+  if (dtype == DT_FP32) C *= 2;
   hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(32, B), dim3(256), 0, s, (uint16_t*)buf_h, T, C, pf, pb);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
@@ -228,10 +223,8 @@ __global__ void pack_linear_kernel(const float* w, int N, int K, int Kpad, typen
 }
 const char* launch_pack_linear(const float* w, int N, int K, int Kpad, void* out_h, int dtype, hipStream_t s) {
   const int blocks = (int)min((long)4096, ((long)N * Kpad + 255) / 256);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(pack_linear_kernel<BF16>, dim3(blocks), dim3(256), 0, s, w, N, K, Kpad, (__bf16*)out_h);
-  else
-    hipLaunchKernelGGL(pack_linear_kernel<FP16>, dim3(blocks), dim3(256), 0, s, w, N, K, Kpad, (_Float16*)out_h);
+  AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL(pack_linear_kernel<HT>, dim3(blocks), dim3(256), 0, s, w, N, K, Kpad,
+                                            (HT::T*)out_h));
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
@@ -250,10 +243,8 @@ __global__ void pack_conv_kernel(const float* w, int N, int Cin, int k, typename
 }
 const char* launch_pack_conv(const float* w, int N, int Cin, int k, void* out_h, int dtype, hipStream_t s) {
   const int blocks = (int)min((long)4096, ((long)N * Cin * k + 255) / 256);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(pack_conv_kernel<BF16>, dim3(blocks), dim3(256), 0, s, w, N, Cin, k, (__bf16*)out_h);
-  else
-    hipLaunchKernelGGL(pack_conv_kernel<FP16>, dim3(blocks), dim3(256), 0, s, w, N, Cin, k, (_Float16*)out_h);
+  AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL(pack_conv_kernel<HT>, dim3(blocks), dim3(256), 0, s, w, N, Cin, k,
+                                            (HT::T*)out_h));
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
@@ -290,12 +281,8 @@ const char* launch_pack_posconv(const float* v, const float* g, int C, int cpg, 
                                 int dtype, hipStream_t s) {
   if (g) hipLaunchKernelGGL(posconv_norm_kernel, dim3(k), dim3(256), 0, s, v, C, cpg, k, norm_tmp);
   const int blocks = (int)min((long)4096, ((long)C * cpg * k + 255) / 256);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(pack_posconv_kernel<BF16>, dim3(blocks), dim3(256), 0, s, v, g, norm_tmp, C, cpg, k,
-                       (__bf16*)out_h);
-  else
-    hipLaunchKernelGGL(pack_posconv_kernel<FP16>, dim3(blocks), dim3(256), 0, s, v, g, norm_tmp, C, cpg, k,
-                       (_Float16*)out_h);
+  AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL(pack_posconv_kernel<HT>, dim3(blocks), dim3(256), 0, s, v, g, norm_tmp, C,
+                                            cpg, k, (HT::T*)out_h));
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

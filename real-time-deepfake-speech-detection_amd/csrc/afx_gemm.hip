@@ -682,6 +682,7 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
 }
 
 const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t s) {
+  if (dtype == DT_FP32) return launch_gemm_f32(p_in, groups, s);
   if (const char* e = check_gemm(p_in, groups)) return e;
   GemmArgs p = p_in;
   p.map_mode = g_map_override >= 0 ? g_map_override : 2;

@@ -7,7 +7,8 @@
 
 namespace afx {
 
-enum DType { DT_BF16 = 0, DT_FP16 = 1 };
+enum DType { DT_BF16 = 0, DT_FP16 = 1, DT_FP32 = 2 };
+inline size_t dtype_size(int dt) { return dt == DT_FP32 ? 4 : 2; }
 
 struct GemmArgs {
   const void* A;  // matrix-core operand type (bf16/fp16), K contiguous
@@ -48,6 +49,7 @@ struct GemmArgs {
   int dbg_nodma;  // timing experiments only
 };
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
+const char* launch_gemm_f32(const GemmArgs& p, int groups, hipStream_t s);  // afx_gemm_f32.hip (DT_FP32 operands)
 bool gemm_is_narrow(int N);  // true: the 128x64 tile instance serves this N
 int gemm_tile_of(const GemmArgs& p, int groups);  // 0: 128x128, 1: 128x64, 2: 256x256 instance
 void gemm_set_map_mode(int m);  // A/B knob: -1 default, else force map_mode
@@ -81,7 +83,8 @@ struct RowNormArgs {
 };
 const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s);
 // zero the time padding rows of the positional-conv operand buffer (B, T+128, C)
-const char* launch_zero_pad_rows(void* buf_h, int B, int T, int C, int pad_front, int pad_back, hipStream_t s);
+const char* launch_zero_pad_rows(void* buf_h, int B, int T, int C, int pad_front, int pad_back, int dtype,
+                                 hipStream_t s);
 // fp32 -> operand type conversion with optional layout permutes (weight packing)
 const char* launch_pack_linear(const float* w, int N, int K, int Kpad, void* out_h, int dtype, hipStream_t s);
 const char* launch_pack_conv(const float* w, int N, int Cin, int k, void* out_h, int dtype, hipStream_t s);
