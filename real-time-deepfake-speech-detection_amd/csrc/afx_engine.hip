@@ -630,7 +630,7 @@ static const char* timed(int cls, double flops, hipStream_t s, F&& f) {
 }
 static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) {
   const double fl = 2.0 * g.M * g.N * (g.k_algo ? g.k_algo : g.K) * groups;
-  static const int cls[7] = {PC_GEMM128, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM256, PC_GEMM256, PC_GEMM_ROWLN};
+  static const int cls[8] = {PC_GEMM128, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM256, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM256};
   return timed(dt == DT_FP32 ? PC_GEMM_F32 : cls[gemm_tile_of(g, groups)], fl, s, [&] { return launch_gemm(g, dt, groups, s); });
 }
 static const char* P_rownorm(const RowNormArgs& a, int dt, hipStream_t s) {

@@ -21,6 +21,8 @@
 #include "afx_common.h"
 #include "afx_kernels.h"
 
+#include <type_traits>
+
 namespace afx {
 
 // ---------------------------------------------------------------------------------------
@@ -586,6 +588,231 @@ __global__ __launch_bounds__(512) void gemm_deep_kernel(GemmArgs p) {
   gemm_epilogue<HT, BM, BN, WR, WC, ROWLN>(p, acc, smem, m0, n0, g);
 }
 
+// =======================================================================================
+// 8-phase 256x256 tile kernel (cdna guide, "The 256^2 8-phase template"): 8 waves as 2(M) x
+// 4(N), each owning 128 x 64 outputs; one workgroup per CU, 128 KB of LDS = 2 K-tile buffers
+// x 4 half-tiles (A0 A1 B0 B1, 128 rows x 64 halfs each).  Half h of A holds rows
+// {64h .. 64h+63} of BOTH wave rows, half h of B holds columns {32h .. 32h+31} of all FOUR
+// wave columns, so that "quadrant (Ai, Bj) of every wave" needs exactly half-tiles Ai and Bj.
+//
+// A K-tile is 4 phases (one 64 x 32 output quadrant x K = 64 each = 16 MFMAs per wave):
+//     phase 1: read B0 (4 ds_read_b128) then A0 (8)   stage A1(t+1)   MFMA (A0,B0)
+//     phase 2: read B1 (4)                            stage B0(t+2)   MFMA (A0,B1)
+//     phase 3: read A1 (8)                            stage A0(t+2)   MFMA (A1,B1)
+//     phase 4: --                                     stage B1(t+2)   MFMA (A1,B0)   [B0 kept]
+// each phase = { ds_reads ; 2 LDS-DMA ; s_barrier ; lgkmcnt(0) ; 16 MFMA ; s_barrier }.
+// The operand DMA is retired ONCE per K-tile, in phase 4, with vmcnt(6): the three half-tiles
+// of tile t+2 stay in flight across the barriers, all of tile t+1 has landed and is read from
+// the next phase on.  The two wave rows run one barrier apart (wr == 1 takes an extra
+// s_barrier up front, wr == 0 at the end), so on every SIMD one wave is in its MFMA segment
+// while the other issues its LDS reads and DMA.
+// Hazards (all counted in barrier intervals, with the one-interval skew between wave rows):
+//   RAW  a wave waits for its own DMA (vmcnt) BEFORE the first barrier of phase 4; readers
+//        touch that buffer in the next phase, i.e. behind a barrier every waiter has reached.
+//   WAR  a half-tile is re-staged two phases after its last read (A0: read ph1, staged ph3;
+//        B1: ph2 -> ph4; A1: ph3 -> ph1 of the next tile), or one phase after when the reads
+//        were retired before the reading phase's first barrier (B0: ph1 reads are issued
+//        first and retired by lgkmcnt(8) there -> staged in ph2).
+// =======================================================================================
+template <class HT>
+__global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+  constexpr int BM = 256, BN = 256;
+  constexpr int HALF = 128 * 128;  // bytes: 128 rows x 64 halfs
+  constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF, BUF = 4 * HALF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int g = blockIdx.z;
+  int pm, pn;
+  {
+    const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
+    const int nwg = nM * nN;
+    int L = blockIdx.x;
+    if (p.map_mode >= 1) {
+      const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    }
+    if (p.map_mode == 2) {
+      constexpr int GM = 8;
+      const int width = GM * nN, grp = L / width, first = grp * GM;
+      const int gsz = nM - first < GM ? nM - first : GM;
+      pm = first + (L % width) % gsz;
+      pn = (L % width) / gsz;
+    } else {
+      pm = L / nN;
+      pn = L % nN;
+    }
+  }
+  const int m0 = pm * BM, n0 = pn * BN;
+  const T* Ag = (const T*)p.A + (long)g * p.g_a;
+  const T* Wg = (const T*)p.W + (long)g * p.g_w;
+
+  // DMA source pointers.  Piece (i*8 + wave) of a half-tile is LDS rows 8(i*8+wave) .. +7,
+  // lane l -> row l>>3, 16-B slot l&7 holding logical chunk (l&7) ^ ((row>>1)&7).
+  const T* srcA[2][2];
+  const T* srcB[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = i * 64 + wave * 8 + (lane >> 3);  // LDS row inside the half-tile
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      int m = m0 + i * 128 + h * 64 + wave * 8 + (lane >> 3);  // r = 64 * (wave row) + row in half
+      m = m < p.M ? m : p.M - 1;
+      srcA[h][i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
+      int n = n0 + (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);  // r = 32 * (wave col) + col in half
+      n = n < p.N ? n : p.N - 1;
+      srcB[h][i] = Wg + (long)n * p.ldw + c * 8;
+    }
+  const unsigned lds_base = (unsigned)(size_t)smem;
+  auto dma16 = [&](const T* src, unsigned lds_off) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + lds_off);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
+  auto stageA = [&](int h, int buf, int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16(srcA[h][i] + kt * 64, buf * BUF + (h ? OFF_A1 : OFF_A0) + (i * 8 + wave) * 1024);
+  };
+  auto stageB = [&](int h, int buf, int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16(srcB[h][i] + kt * 64, buf * BUF + (h ? OFF_B1 : OFF_B0) + (i * 8 + wave) * 1024);
+  };
+
+  // fragment read addresses (bytes): row (lane & 15) of a 16-row tile, logical chunk ks*4 + lane>>4
+  const int frow = lane & 15, fsw = (frow >> 1) & 7, kq = lane >> 4;
+  const int slot[2] = {(kq ^ fsw) * 16, ((4 + kq) ^ fsw) * 16};
+  const char* aR = smem + (wr * 64 + frow) * 128;
+  const char* bR = smem + (wc * 32 + frow) * 128;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  V8 af[4][2], wf[2][2][2];  // A half in flight; both B halves stay resident through a K-tile
+
+  auto readA = [&](int buf, int h) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        af[mi][ks] = *(const V8*)(aR + buf * BUF + (h ? OFF_A1 : OFF_A0) + mi * 2048 + slot[ks]);
+  };
+  auto readB = [&](int buf, int h) {
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        wf[h][nj][ks] = *(const V8*)(bR + buf * BUF + (h ? OFF_B1 : OFF_B0) + nj * 2048 + slot[ks]);
+  };
+  auto quadrant = [&](int ah, int bh) {  // 16 MFMAs: (A half ah) x (B half bh) x K = 64
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+          acc[ah * 4 + mi][bh * 2 + nj] = HT::mfma(wf[bh][nj][ks], af[mi][ks], acc[ah * 4 + mi][bh * 2 + nj]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define AFX_BAR()                          \
+  do {                                     \
+    __builtin_amdgcn_sched_barrier(0);     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_s_barrier();          \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+
+  const int nk = p.K >> 6;
+  // prologue: all of tile 0 and three half-tiles of tile 1 in flight; tile 0 landed
+  stageB(0, 0, 0);
+  stageA(0, 0, 0);
+  stageB(1, 0, 0);
+  stageA(1, 0, 0);
+  if (nk > 1) {
+    stageB(0, 1, 1);
+    stageA(0, 1, 1);
+    stageB(1, 1, 1);
+    wait_vmcnt<6>();
+  } else {
+    wait_vmcnt<0>();
+  }
+  AFX_BAR();
+  if (wr == 1) AFX_BAR();  // the second wave row runs one barrier behind the first
+
+  auto ktile = [&](auto bufc, int t) {
+    constexpr int b = decltype(bufc)::value;
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+    // ---- phase 1
+    readB(b, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    readA(b, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more1) stageA(1, b ^ 1, t + 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the B0 reads (issued first) are done: B0 may be re-staged next phase
+    AFX_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    quadrant(0, 0);
+    AFX_BAR();
+    // ---- phase 2
+    readB(b, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) stageB(0, b, t + 2);
+    AFX_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    quadrant(0, 1);
+    AFX_BAR();
+    // ---- phase 3
+    readA(b, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) stageA(0, b, t + 2);
+    AFX_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    quadrant(1, 1);
+    AFX_BAR();
+    // ---- phase 4
+    if (more2) {
+      stageB(1, b, t + 2);
+      wait_vmcnt<6>();  // tile t+1 has landed; B0/A0/B1 of tile t+2 stay in flight
+    } else {
+      wait_vmcnt<0>();
+    }
+    AFX_BAR();
+    quadrant(1, 0);
+    AFX_BAR();
+  };
+  for (int t = 0; t < nk; t += 2) {
+    ktile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
+  }
+  if (wr == 0) AFX_BAR();
+#undef AFX_BAR
+
+  gemm_epilogue<HT, BM, BN, 2, 4, false>(p, acc, smem, m0, n0, g);
+}
+
+template <class HT>
+static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
+  constexpr int lds = 2 * 4 * 128 * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm8_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid(((p.N + 255) / 256) * ((p.M + 255) / 256), 1, groups);
+  hipLaunchKernelGGL((gemm8_kernel<HT>), grid, dim3(512), lds, s, p);
+  return hipGetLastError();
+}
+
 template <class HT, int BM, int BN, bool ROWLN>
 static hipError_t launch_gemm_deep_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 4 * (BM + BN) * 64;
@@ -656,16 +883,18 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
   if (gemm_is_narrow(p.N)) return 1;
   if (groups != 1) return 0;
   if (g_tile_override == 2) return 4;  // 256x128 / 8 waves (A/B only: slower everywhere measured)
+  if (g_tile_override == 3) return p.kchunk == p.K ? 7 : 0;  // 8-phase 256x256
   if (g_tile_override >= 0) return g_tile_override == 1 ? 2 : 0;
   // Wave-quantisation model fitted to tools/bench_gemm.py (profiles/r01_gemm_tile_ab*.txt):
-  // a 256x256 tile is ~10 % faster per FLOP (half the operand bytes) but runs one workgroup
-  // per CU, a 128x128 tile two; pick the better fill of the 256 CUs.
+  // the 8-phase 256x256 kernel is ~15 % faster per FLOP at K = 1024 (25 % at K = 4096) but
+  // runs one workgroup per CU, a 128x128 tile two; pick the better fill of the 256 CUs.
   const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   const long b256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   if (b128 < 384) return 1;  // small batches: halve the tile to spread over the chip
   const double e128 = (double)b128 / (double)(((b128 + 511) / 512) * 512);
-  const double e256 = 1.10 * (double)b256 / (double)(((b256 + 255) / 256) * 256);
-  return e256 > e128 ? 2 : 0;
+  const double e256 = 1.15 * (double)b256 / (double)(((b256 + 255) / 256) * 256);
+  if (e256 <= e128) return 0;
+  return p.kchunk == p.K ? 7 : 2;  // the 8-phase kernel where its addressing applies (no chunked K)
 }
 
 template <class HT>
@@ -677,6 +906,7 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 4: return launch_gemm_t<HT, 256, 128, 4, 2>(p, groups, s);
     case 5: return launch_gemm_deep_t<HT, 256, 256, false>(p, groups, s);
     case 6: return launch_gemm_deep_t<HT, 128, 512, true>(p, groups, s);
+    case 7: return launch_gemm8_t<HT>(p, groups, s);
     default: return launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
   }
 }

@@ -7,8 +7,8 @@
 // pooling's discrete top-k on a few utterances; this mode removes that), not for
 // the headline rate: the fp32 matrix rate of the chip is 1/16 of the fp16 one.
 //
-// Tile: 128 rows x 128 columns per 256-thread workgroup; each wave owns 32 rows x 128
-// columns (2 x 8 MFMA accumulators).  Operands are read straight from global memory
+// Tile: 128 rows x 128 (or 64) columns per 256-thread workgroup; each wave owns 32 rows x
+// 128 (64) columns (2 x 8 (4) MFMA accumulators).  Operands are read straight from global memory
 // as 16-byte rows (lane (r, kq) reads k = 4 kq .. 4 kq + 3 of row r): the K loop is 16
 // wide, 10 loads feed 64 MFMAs, the panel re-reads across workgroups are L2 hits.
 // MFMA operands are swapped (W as "A") so a lane ends up with 4 consecutive columns.
@@ -17,12 +17,13 @@
 
 namespace afx {
 
+template <int NT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, kq = lane >> 4;
   const int grp = blockIdx.z;
   const long m0 = (long)blockIdx.y * 128 + wave * 32;
-  const int n0 = blockIdx.x * 128;
+  const int n0 = blockIdx.x * (16 * NT);
   if (m0 >= p.M) return;
   const float* A = (const float*)p.A + grp * p.g_a;
   const float* W = (const float*)p.W + grp * p.g_w;
@@ -33,36 +34,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     m = m < p.M ? m : p.M - 1;
     arow[mt] = A + (m / p.rpb) * p.a_batch + (m % p.rpb) * p.a_row + kq * 4;
   }
-  const float* wrow[8];
+  const float* wrow[NT];
 #pragma unroll
-  for (int nt = 0; nt < 8; ++nt) {
+  for (int nt = 0; nt < NT; ++nt) {
     int n = n0 + nt * 16 + r;
     n = n < p.N ? n : p.N - 1;
     wrow[nt] = W + (long)n * p.ldw + kq * 4;
   }
-  f32x4 acc[2][8];
+  f32x4 acc[2][NT];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nch = p.K / p.kchunk;
-  for (int ch = 0; ch < nch; ++ch) {
-    const long ao = (long)ch * p.kchunk_stride;
-    const long wo = (long)ch * p.kchunk;
-    for (int k0 = 0; k0 < p.kchunk; k0 += 16) {
-      f32x4 a[2], b[8];
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // K walk, 16 at a time, software-pipelined one step ahead in registers (a grid of a few
+  // hundred workgroups leaves ~1 wave per SIMD: nothing else hides the load latency)
+  const int spc = p.kchunk / 16;  // steps per chunk
+  const int steps = (p.K / p.kchunk) * spc;
+  f32x4 a[2], b[NT], an[2], bn[NT];
+  auto load = [&](f32x4* ar, f32x4* br, int step) {
+    const int ch = step / spc, k0 = (step - ch * spc) * 16;
+    const long ao = (long)ch * p.kchunk_stride + k0;
+    const long wo = (long)ch * p.kchunk + k0;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) a[mt] = *(const f32x4*)(arow[mt] + ao + k0);
+    for (int mt = 0; mt < 2; ++mt) ar[mt] = *(const f32x4*)(arow[mt] + ao);
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) b[nt] = *(const f32x4*)(wrow[nt] + wo + k0);
+    for (int nt = 0; nt < NT; ++nt) br[nt] = *(const f32x4*)(wrow[nt] + wo);
+  };
+  load(a, b, 0);
+  for (int st = 0; st < steps; ++st) {
+    if (st + 1 < steps) load(an, bn, st + 1);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 8; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][s], a[mt][s], acc[mt][nt], 0, 0, 0);
-    }
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][s], a[mt][s], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) a[mt] = an[mt];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
   }
   // lane holds out[m = m0 + 16 mt + (lane & 15)][n = n0 + 16 nt + 4 (lane >> 4) + 0..3]
   const int gn = grp * p.g_n;
@@ -74,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     const long orow = bi * p.o_batch_rows + ri + p.o_row_off;
     const long hrow = bi * p.oh_batch_rows + ri + p.oh_row_off;
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
       const int n = n0 + nt * 16 + kq * 4;
       if (n >= p.N) continue;  // N % 4 == 0: a lane's 4 columns are all in or all out
       const int c = gn + n;
@@ -95,8 +106,12 @@ const char* launch_gemm_f32(const GemmArgs& p, int groups, hipStream_t s) {
   if (p.ln_gamma) return "gemm(fp32): the fused LayerNorm epilogue is a half-precision tile feature";
   if (!p.out_f && !p.out_h) return "gemm(fp32): no output";
   if (p.rpb <= 0) return "gemm(fp32): rows per batch must be positive";
-  dim3 grid((p.N + 127) / 128, (unsigned)((p.M + 127) / 128), groups);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, p);
+  const long mt = (p.M + 127) / 128;
+  // 128-column tiles unless that leaves the 256 CUs under two workgroups each
+  if (p.N > 64 && mt * ((p.N + 127) / 128) * groups >= 512)
+    hipLaunchKernelGGL(gemm_f32_kernel<8>, dim3((p.N + 127) / 128, (unsigned)mt, groups), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(gemm_f32_kernel<4>, dim3((p.N + 63) / 64, (unsigned)mt, groups), dim3(256), 0, s, p);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -54,10 +54,11 @@ def test_gemm_epilogues(K, dtype, M, N, K_):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("tile", [0, 1, "deep"])
+@pytest.mark.parametrize("tile", [0, 1, "deep", 3])
 def test_gemm_tile_variants_agree_with_reference(K, dtype, tile):
-    """Both tile instances (128x128 / 4 waves, 256x256 / 8 waves) and every workgroup->tile
-    mapping must give the same numbers; M, N tails included."""
+    """Every tile instance (128x128 / 4 waves, 256x256 / 8 waves 2-stage, deep ring, and the
+    8-phase 256x256 kernel = tile 3) and every workgroup->tile mapping must give the same
+    numbers; M, N tails included."""
     from afx._lib import check, lib
     g = torch.Generator().manual_seed(11)
     M, N, K_ = 1000, 768, 1536
@@ -78,6 +79,29 @@ def test_gemm_tile_variants_agree_with_reference(K, dtype, tile):
         check(lib().afx_debug_set(b"gemm_tile", -1))
         check(lib().afx_debug_set(b"gemm_map", -1))
         check(lib().afx_debug_set(b"gemm_deep", 0))
+
+
+@pytest.mark.parametrize("M,N,K_", [(1000, 768, 64), (515, 512, 192), (300, 256, 128), (2048, 1024, 4096), (12736, 1024, 1024)])
+def test_gemm_8phase_kernel_is_bit_identical_to_the_2stage_kernel(K, M, N, K_):
+    """The 8-phase 256x256 kernel keeps DMA in flight across barriers (counted vmcnt, two wave
+    rows one barrier apart): a misplaced wait shows up as rare stale tiles, so beyond the
+    reference check every result is compared BIT FOR BIT with the simple 2-stage kernel (same
+    k order per output element) over repeated launches, at 1, 2, 3 and many K-tiles."""
+    from afx._lib import check, lib
+    g = torch.Generator().manual_seed(K_ + M)
+    A = torch.randn(M, K_, generator=g).half().cuda()
+    W = (torch.randn(N, K_, generator=g) / math.sqrt(K_)).half().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    try:
+        check(lib().afx_debug_set(b"gemm_tile", 0))
+        want, _ = K.gemm("fp16", A, W, bias=bias, act="gelu")
+        _close(want, F.gelu(A.float().cpu() @ W.float().cpu().t() + bias.cpu()), 1e-4, 2e-4)
+        check(lib().afx_debug_set(b"gemm_tile", 3))
+        for _ in range(12):
+            got, _ = K.gemm("fp16", A, W, bias=bias, act="gelu")
+            assert torch.equal(got, want)
+    finally:
+        check(lib().afx_debug_set(b"gemm_tile", -1))
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -25,9 +25,12 @@ SHAPES = [
     ("fc1   M=12736 K=1024 N=4096", "lin", (12736, 4096, 1024)),
     ("fc2   M=12736 K=4096 N=1024", "lin", (12736, 1024, 4096)),
     ("teacher fc1 M=3184 K=1024 N=4096", "lin", (3184, 4096, 1024)),
+    ("square 4096^3", "lin", (4096, 4096, 4096)),
+    ("square 8192^3", "lin", (8192, 8192, 8192)),
 ]
 SETS = {
     "tile": [("128x128", ("gemm_tile", 0)), ("256x128", ("gemm_tile", 2)), ("256x256", ("gemm_tile", 1))],
+    "8ph": [("128x128", ("gemm_tile", 0)), ("256x256 2-stage", ("gemm_tile", 1)), ("256x256 8-phase", ("gemm_tile", 3))],
     "map": [("map0", ("gemm_map", 0)), ("map1", ("gemm_map", 1)), ("map2", ("gemm_map", 2))],
     "nt": [("A default", ("gemm_a_nt", 0)), ("A nt", ("gemm_a_nt", 1))],
     "nodma": [("full", ("gemm_nodma", 0)), ("compute-only", ("gemm_nodma", 1))],
