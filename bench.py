@@ -136,6 +136,15 @@ def main():
         "all_gemm_instances_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
     }
     breakdown = {k: round(v["ms"] / args.steps, 4) for k, v in prof.items() if v["launches"]}
+    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: FETCH_SIZE x 2
+    # + WRITE_SIZE, mean bytes per launch on this workload); counters cannot be read from inside this process
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path) and args.workload == "conformer_student" and B == 64 and args.dtype != "fp32":
+        kern = dom.split("<")[0] + "<afx::" + args.dtype.upper() + ", " + dom.split("<")[1].rstrip(">").split(",")[0].replace("x", ", ")
+        for name, rec in json.load(open(pmc_path))["kernels"].items():
+            if name.startswith("afx::" + kern):
+                roofline["traffic"] = round(rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"])
+                roofline["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json)"
 
     result = {
         "metric": "utterances/sec (4 s @ 16 kHz)", "value": round(value, 2), "unit": "utterances/s",
@@ -150,6 +159,18 @@ def main():
         "roofline": roofline,
         "kernel_ms_per_step": breakdown,
     }
+
+    # ---- the same K steps with the host hand-over inside: pinned fp32 waveform H2D (256 KB per
+    # utterance) + forward + D2H of the scores (main.py:209-213).  Reported beside, never as, `value`.
+    if world == 1:
+        host_wave = wave.cpu().pin_memory()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            host_scores = eng.forward(host_wave.to("cuda", non_blocking=True))[:, 1].cpu()
+        e2e = time.perf_counter() - t0
+        result["with_pcie"] = {"value": round(B * args.steps / e2e, 2), "unit": "utterances/s",
+                               "note": "H2D of the batch + forward + D2H of the scores every step, one stream, no overlap"}
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample (rank 0, N=1) ----
     if rank == 0 and world == 1 and args.cpu_sample > 0:

@@ -586,10 +586,10 @@ extern "C" int afx_tap(afx_handle h, const char* name, float* out, size_t cap, s
 // launch of the forward is bracketed by hipEvents on the launch stream and summed per
 // class afterwards.  Off by default: the normal forward records nothing.
 // ---------------------------------------------------------------------------------
-enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM_F32, PC_CONV0, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV,
+enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN, PC_GEMM_F32, PC_CONV0, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV,
                  PC_MISC, PC_AASIST, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm_kernel<128x128>", "gemm_kernel<128x64>", "gemm_kernel<256x256>",
-                                           "gemm_kernel<128x512,rowLN>", "gemm_f32_kernel<128x128>", "conv0_kernel", "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel",
+                                           "gemm_kernel<128x512,rowLN>", "gemm8_kernel<256x256>", "gemm8_kernel<128x512,rowLN>", "gemm_f32_kernel<128x128>", "conv0_kernel", "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel",
                                            "conf_dwconv_kernel", "misc", "aasist_head"};
 struct ProfRec { int cls; hipEvent_t a, b; double flops; };
 struct Profiler {
@@ -630,7 +630,7 @@ static const char* timed(int cls, double flops, hipStream_t s, F&& f) {
 }
 static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) {
   const double fl = 2.0 * g.M * g.N * (g.k_algo ? g.k_algo : g.K) * groups;
-  static const int cls[8] = {PC_GEMM128, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM256, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM256};
+  static const int cls[9] = {PC_GEMM128, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM256, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN};
   return timed(dt == DT_FP32 ? PC_GEMM_F32 : cls[gemm_tile_of(g, groups)], fl, s, [&] { return launch_gemm(g, dt, groups, s); });
 }
 static const char* P_rownorm(const RowNormArgs& a, int dt, hipStream_t s) {

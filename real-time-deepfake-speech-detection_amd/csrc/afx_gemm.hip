@@ -416,22 +416,6 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   gemm_epilogue<HT, BM, BN, WR, WC, ROWLN>(p, acc, smem, m0, n0, g);
 }
 
-// =======================================================================================
-// Deep-pipelined tile kernel (one workgroup of 8 waves per CU):
-//   * K advances in steps of 32 (one MFMA k-step); LDS holds a ring of FOUR stages
-//     (4 x (BM+BN) x 64 B), so the operand DMA runs THREE steps ahead of the MFMAs;
-//   * LDS-DMA is issued from inline asm and retired with COUNTED vmcnt (never 0 in the
-//     steady state) in front of a raw s_barrier -- loads stay in flight across barriers;
-//   * the fragments of step t+1 are requested into a second register set while the MFMAs of
-//     step t run (hipcc places counted lgkmcnt waits, the DMA being invisible to it), so a
-//     wave's matrix-core stream is not interrupted by LDS latency;
-//   * 64-B LDS rows, 16-B chunk index XOR-swizzled with (-(row>>2))&3: every ds_read_b128
-//     lane group {0-3,12-15,20-27}.. then covers the 16 slots of a 256-B bank row once.
-// Hazards: the DMA issued in step t overwrites the stage of tile t-1, whose fragment reads
-// were consumed (waited) by the MFMAs of step t-1, i.e. before every wave reached the
-// barrier of step t; a tile is read (step t-1) only after the wait+barrier of step t-1 that
-// retired its DMA on every wave.
-// =======================================================================================
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 10, "extend the table");
@@ -446,146 +430,6 @@ __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-}
-
-template <class HT, int BM, int BN, bool ROWLN>
-__global__ __launch_bounds__(512) void gemm_deep_kernel(GemmArgs p) {
-  typedef typename HT::T T;
-  typedef typename HT::V8 V8;
-  constexpr int WR = 2, WC = 4, NW = 8;
-  constexpr int WM = BM / WR, WN = BN / WC;
-  constexpr int MT = WM / 16, NT = WN / 16;
-  constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;  // 32 halfs per row
-  constexpr int AI = BM / (16 * NW), WI = BN / (16 * NW);  // 1-KB DMA pieces (16 rows) per wave per step
-  constexpr int G = AI + WI;                               // LDS-DMA instructions per thread per step
-  static_assert(AI >= 1 && WI >= 1 && 4 * STAGE <= 160 * 1024, "tile / ring does not fit");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave / WC, wc = wave % WC;
-  const int g = blockIdx.z;
-  int pm, pn;
-  {
-    const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
-    const int nwg = nM * nN;
-    int L = blockIdx.x;
-    if (p.map_mode >= 1) {
-      const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
-      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-    }
-    if (p.map_mode == 2) {
-      constexpr int GM = 8;
-      const int width = GM * nN, grp = L / width, first = grp * GM;
-      const int gsz = nM - first < GM ? nM - first : GM;
-      pm = first + (L % width) % gsz;
-      pn = (L % width) / gsz;
-    } else {
-      pm = L / nN;
-      pn = L % nN;
-    }
-  }
-  const int m0 = pm * BM, n0 = pn * BN;
-  const T* Ag = (const T*)p.A + (long)g * p.g_a;
-  const T* Wg = (const T*)p.W + (long)g * p.g_w;
-
-  // DMA source pointers: piece (i*NW + wave) covers 16 rows x 64 B; lane l -> row l>>2, slot l&3
-  const T* a_src[AI];
-  const T* w_src[WI];
-  const int prow = lane >> 2;
-  const int pch = (lane & 3) ^ ((-(prow >> 2)) & 3);  // logical chunk stored at this lane's slot
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    int m = m0 + (i * NW + wave) * 16 + prow;
-    m = m < p.M ? m : p.M - 1;
-    a_src[i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + pch * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < WI; ++i) {
-    int n = n0 + (i * NW + wave) * 16 + prow;
-    n = n < p.N ? n : p.N - 1;
-    w_src[i] = Wg + (long)n * p.ldw + pch * 8;
-  }
-  const unsigned lds_base = (unsigned)(size_t)smem;
-  auto dma16 = [&](const T* src, unsigned lds_off, bool nt) {
-    unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + lds_off);
-    if (nt)
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-    else
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-  };
-  auto stage = [&](int t) {  // DMA of K-step t into ring slot t & 3
-    const int k0 = t << 5;
-    const long ka = (long)(k0 / p.kchunk) * p.kchunk_stride + (k0 % p.kchunk);
-    const unsigned base = (unsigned)((t & 3) * STAGE);
-#pragma unroll
-    for (int i = 0; i < AI; ++i) dma16(a_src[i] + ka, base + (i * NW + wave) * 1024, p.a_nt != 0);
-#pragma unroll
-    for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0, base + A_BYTES + (i * NW + wave) * 1024, false);
-  };
-
-  // fragment addresses: row (lane&15) of a 16-row tile, logical chunk lane>>4 of the 4 in a row
-  const int frow = lane & 15;
-  const int fslot = ((lane >> 4) ^ ((-(frow >> 2)) & 3)) * 16;
-  const int a_off = (wr * WM + frow) * 64 + fslot;
-  const int w_off = A_BYTES + (wc * WN + frow) * 64 + fslot;
-  auto load_frags = [&](int t, V8 (&af)[MT], V8 (&wf)[NT]) {
-    const char* sb = smem + (t & 3) * STAGE;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 64);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + a_off + i * 16 * 64);
-  };
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mfmas = [&](V8 (&af)[MT], V8 (&wf)[NT]) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
-    __builtin_amdgcn_s_setprio(0);
-  };
-
-  const int nk = p.K >> 5;
-  V8 afA[MT], wfA[NT], afB[MT], wfB[NT];
-  // prologue: three steps in flight, then the fragments of step 0
-  stage(0);
-  if (nk > 1) stage(1);
-  if (nk > 2) stage(2);
-  if (nk > 2) wait_vmcnt<2 * G>();
-  else if (nk > 1) wait_vmcnt<G>();
-  else wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  load_frags(0, afA, wfA);
-
-  // one step: retire the DMA of tile t+1, barrier, queue tile t+3, request the fragments of
-  // tile t+1 into the other register set, run the MFMAs of tile t
-#define AFX_DEEP_STEP(t, AF_CUR, WF_CUR, AF_NXT, WF_NXT)        \
-  {                                                             \
-    if ((t) + 2 < nk) wait_vmcnt<G>();                          \
-    else wait_vmcnt<0>();                                       \
-    __builtin_amdgcn_s_barrier();                               \
-    if ((t) + 3 < nk) stage((t) + 3);                           \
-    if ((t) + 1 < nk) load_frags((t) + 1, AF_NXT, WF_NXT);      \
-    mfmas(AF_CUR, WF_CUR);                                      \
-  }
-  int t = 0;
-  for (; t + 1 < nk; t += 2) {
-    AFX_DEEP_STEP(t, afA, wfA, afB, wfB)
-    AFX_DEEP_STEP(t + 1, afB, wfB, afA, wfA)
-  }
-  if (t < nk) AFX_DEEP_STEP(t, afA, wfA, afB, wfB)
-#undef AFX_DEEP_STEP
-
-  gemm_epilogue<HT, BM, BN, WR, WC, ROWLN>(p, acc, smem, m0, n0, g);
 }
 
 // =======================================================================================
@@ -614,13 +458,25 @@ __global__ __launch_bounds__(512) void gemm_deep_kernel(GemmArgs p) {
 //        were retired before the reading phase's first barrier (B0: ph1 reads are issued
 //        first and retired by lgkmcnt(8) there -> staged in ph2).
 // =======================================================================================
-template <class HT>
+template <class HT, int BM, int BN, bool ROWLN>
 __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
-  constexpr int BM = 256, BN = 256;
-  constexpr int HALF = 128 * 128;  // bytes: 128 rows x 64 halfs
-  constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF, BUF = 4 * HALF;
+  // Two instances: 256x256 (A flows, both B halves stay in registers) and the row-complete
+  // 128x512 tile of the conv stack (roles swapped: B flows, both A halves stay resident).
+  // "R" = the resident operand (4 fragment reads per half), "F" = the flowing one (8 per half):
+  //     phase 1: read R0 then F0   stage F1(t+1)   MFMA (F0,R0)
+  //     phase 2: read R1           stage R0(t+2)   MFMA (F0,R1)
+  //     phase 3: read F1           stage F0(t+2)   MFMA (F1,R1)
+  //     phase 4: --                stage R1(t+2)   MFMA (F1,R0)
+  constexpr bool WIDE = BN > BM;              // A is the resident operand
+  constexpr int RA = BM / 2, RB = BN / 2;     // rows of an A / B half-tile
+  constexpr int MTH = RA / 2 / 16, NTH = RB / 4 / 16;  // 16-row fragments per half per wave
+  constexpr int DA = RA / 64, DB = RB / 64;   // LDS-DMA instructions per thread per half-tile
+  constexpr int OFF_A0 = 0, OFF_A1 = RA * 128, OFF_B0 = 2 * RA * 128, OFF_B1 = OFF_B0 + RB * 128;
+  constexpr int BUF = 2 * (RA + RB) * 128;
+  static_assert((WIDE ? MTH : NTH) == 2 && (WIDE ? NTH : MTH) == 4, "resident operand: 4 reads per half, flowing: 8");
+  static_assert(2 * (WIDE ? DA : DB) + (WIDE ? DB : DA) == 6, "vmcnt(6) leaves R0, F0, R1 of tile t+2 in flight");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -653,21 +509,29 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 
   // DMA source pointers.  Piece (i*8 + wave) of a half-tile is LDS rows 8(i*8+wave) .. +7,
   // lane l -> row l>>3, 16-B slot l&7 holding logical chunk (l&7) ^ ((row>>1)&7).
-  const T* srcA[2][2];
-  const T* srcB[2][2];
+  // A half h, LDS row r: wave row r / (RA/2), row r % (RA/2) of that wave's half h;
+  // B half h, LDS row r: wave column r / (RB/4), column r % (RB/4) of that wave's half h.
+  const T* srcA[2][DA];
+  const T* srcB[2][DB];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = i * 64 + wave * 8 + (lane >> 3);  // LDS row inside the half-tile
+    for (int i = 0; i < DA; ++i) {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((r >> 1) & 7);
-      int m = m0 + i * 128 + h * 64 + wave * 8 + (lane >> 3);  // r = 64 * (wave row) + row in half
+      int m = m0 + (r / (RA / 2)) * (BM / 2) + h * (RA / 2) + r % (RA / 2);
       m = m < p.M ? m : p.M - 1;
       srcA[h][i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
-      int n = n0 + (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);  // r = 32 * (wave col) + col in half
+    }
+#pragma unroll
+    for (int i = 0; i < DB; ++i) {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      int n = n0 + (r / (RB / 4)) * (BN / 4) + h * (RB / 4) + r % (RB / 4);
       n = n < p.N ? n : p.N - 1;
       srcB[h][i] = Wg + (long)n * p.ldw + c * 8;
     }
+  }
   const unsigned lds_base = (unsigned)(size_t)smem;
   auto dma16 = [&](const T* src, unsigned lds_off) {
     unsigned keep;
@@ -677,51 +541,59 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   };
   auto stageA = [&](int h, int buf, int kt) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma16(srcA[h][i] + kt * 64, buf * BUF + (h ? OFF_A1 : OFF_A0) + (i * 8 + wave) * 1024);
+    for (int i = 0; i < DA; ++i) dma16(srcA[h][i] + kt * 64, buf * BUF + (h ? OFF_A1 : OFF_A0) + (i * 8 + wave) * 1024);
   };
   auto stageB = [&](int h, int buf, int kt) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma16(srcB[h][i] + kt * 64, buf * BUF + (h ? OFF_B1 : OFF_B0) + (i * 8 + wave) * 1024);
+    for (int i = 0; i < DB; ++i) dma16(srcB[h][i] + kt * 64, buf * BUF + (h ? OFF_B1 : OFF_B0) + (i * 8 + wave) * 1024);
   };
 
   // fragment read addresses (bytes): row (lane & 15) of a 16-row tile, logical chunk ks*4 + lane>>4
   const int frow = lane & 15, fsw = (frow >> 1) & 7, kq = lane >> 4;
   const int slot[2] = {(kq ^ fsw) * 16, ((4 + kq) ^ fsw) * 16};
-  const char* aR = smem + (wr * 64 + frow) * 128;
-  const char* bR = smem + (wc * 32 + frow) * 128;
+  const char* aR = smem + (wr * (RA / 2) + frow) * 128;
+  const char* bR = smem + (wc * (RB / 4) + frow) * 128;
 
-  f32x4 acc[8][4];
+  f32x4 acc[2 * MTH][2 * NTH];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2 * MTH; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  V8 af[4][2], wf[2][2][2];  // A half in flight; both B halves stay resident through a K-tile
+    for (int j = 0; j < 2 * NTH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the resident operand keeps both halves in registers, the flowing one a single half
+  V8 af[WIDE ? 2 : 1][MTH][2], wf[WIDE ? 1 : 2][NTH][2];
 
   auto readA = [&](int buf, int h) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MTH; ++mi)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
-        af[mi][ks] = *(const V8*)(aR + buf * BUF + (h ? OFF_A1 : OFF_A0) + mi * 2048 + slot[ks]);
+        af[WIDE ? h : 0][mi][ks] = *(const V8*)(aR + buf * BUF + (h ? OFF_A1 : OFF_A0) + mi * 2048 + slot[ks]);
   };
   auto readB = [&](int buf, int h) {
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
+    for (int nj = 0; nj < NTH; ++nj)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
-        wf[h][nj][ks] = *(const V8*)(bR + buf * BUF + (h ? OFF_B1 : OFF_B0) + nj * 2048 + slot[ks]);
+        wf[WIDE ? 0 : h][nj][ks] = *(const V8*)(bR + buf * BUF + (h ? OFF_B1 : OFF_B0) + nj * 2048 + slot[ks]);
   };
   auto quadrant = [&](int ah, int bh) {  // 16 MFMAs: (A half ah) x (B half bh) x K = 64
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MTH; ++mi)
 #pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-          acc[ah * 4 + mi][bh * 2 + nj] = HT::mfma(wf[bh][nj][ks], af[mi][ks], acc[ah * 4 + mi][bh * 2 + nj]);
+        for (int nj = 0; nj < NTH; ++nj)
+          acc[ah * MTH + mi][bh * NTH + nj] =
+              HT::mfma(wf[WIDE ? 0 : bh][nj][ks], af[WIDE ? ah : 0][mi][ks], acc[ah * MTH + mi][bh * NTH + nj]);
     __builtin_amdgcn_s_setprio(0);
   };
+  // R / F views of the two operands
+  auto readR = [&](int buf, int h) { if constexpr (WIDE) readA(buf, h); else readB(buf, h); };
+  auto readF = [&](int buf, int h) { if constexpr (WIDE) readB(buf, h); else readA(buf, h); };
+  auto stageR = [&](int h, int buf, int kt) { if constexpr (WIDE) stageA(h, buf, kt); else stageB(h, buf, kt); };
+  auto stageF = [&](int h, int buf, int kt) { if constexpr (WIDE) stageB(h, buf, kt); else stageA(h, buf, kt); };
+  auto quadFR = [&](int fh, int rh) { if constexpr (WIDE) quadrant(rh, fh); else quadrant(fh, rh); };
 #define AFX_BAR()                          \
   do {                                     \
     __builtin_amdgcn_sched_barrier(0);     \
@@ -733,14 +605,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 
   const int nk = p.K >> 6;
   // prologue: all of tile 0 and three half-tiles of tile 1 in flight; tile 0 landed
-  stageB(0, 0, 0);
-  stageA(0, 0, 0);
-  stageB(1, 0, 0);
-  stageA(1, 0, 0);
+  stageR(0, 0, 0);
+  stageF(0, 0, 0);
+  stageR(1, 0, 0);
+  stageF(1, 0, 0);
   if (nk > 1) {
-    stageB(0, 1, 1);
-    stageA(0, 1, 1);
-    stageB(1, 1, 1);
+    stageR(0, 1, 1);
+    stageF(0, 1, 1);
+    stageR(1, 1, 1);
     wait_vmcnt<6>();
   } else {
     wait_vmcnt<0>();
@@ -752,41 +624,41 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     constexpr int b = decltype(bufc)::value;
     const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
     // ---- phase 1
-    readB(b, 0);
+    readR(b, 0);
     __builtin_amdgcn_sched_barrier(0);
-    readA(b, 0);
+    readF(b, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (more1) stageA(1, b ^ 1, t + 1);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the B0 reads (issued first) are done: B0 may be re-staged next phase
+    if (more1) stageF(1, b ^ 1, t + 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the R0 reads (issued first) are done: R0 may be re-staged next phase
     AFX_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    quadrant(0, 0);
+    quadFR(0, 0);
     AFX_BAR();
     // ---- phase 2
-    readB(b, 1);
+    readR(b, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (more2) stageB(0, b, t + 2);
+    if (more2) stageR(0, b, t + 2);
     AFX_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    quadrant(0, 1);
+    quadFR(0, 1);
     AFX_BAR();
     // ---- phase 3
-    readA(b, 1);
+    readF(b, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (more2) stageA(0, b, t + 2);
+    if (more2) stageF(0, b, t + 2);
     AFX_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    quadrant(1, 1);
+    quadFR(1, 1);
     AFX_BAR();
     // ---- phase 4
     if (more2) {
-      stageB(1, b, t + 2);
-      wait_vmcnt<6>();  // tile t+1 has landed; B0/A0/B1 of tile t+2 stay in flight
+      stageR(1, b, t + 2);
+      wait_vmcnt<6>();  // tile t+1 has landed; R0/F0/R1 of tile t+2 stay in flight
     } else {
       wait_vmcnt<0>();
     }
     AFX_BAR();
-    quadrant(1, 0);
+    quadFR(1, 0);
     AFX_BAR();
   };
   for (int t = 0; t < nk; t += 2) {
@@ -796,35 +668,22 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   if (wr == 0) AFX_BAR();
 #undef AFX_BAR
 
-  gemm_epilogue<HT, BM, BN, 2, 4, false>(p, acc, smem, m0, n0, g);
-}
-
-template <class HT>
-static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
-  constexpr int lds = 2 * 4 * 128 * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm8_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  dim3 grid(((p.N + 255) / 256) * ((p.M + 255) / 256), 1, groups);
-  hipLaunchKernelGGL((gemm8_kernel<HT>), grid, dim3(512), lds, s, p);
-  return hipGetLastError();
+  gemm_epilogue<HT, BM, BN, 2, 4, ROWLN>(p, acc, smem, m0, n0, g);
 }
 
 template <class HT, int BM, int BN, bool ROWLN>
-static hipError_t launch_gemm_deep_t(const GemmArgs& p, int groups, hipStream_t s) {
-  constexpr int lds = 4 * (BM + BN) * 64;
+static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
+  constexpr int lds = 2 * (BM + BN) * 128;
+  static_assert(lds <= 160 * 1024, "two K-tile buffers must fit the 160 KB LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_deep_kernel<HT, BM, BN, ROWLN>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm8_kernel<HT, BM, BN, ROWLN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
-  hipLaunchKernelGGL((gemm_deep_kernel<HT, BM, BN, ROWLN>), grid, dim3(512), lds, s, p);
+  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN>), grid, dim3(512), lds, s, p);
   return hipGetLastError();
 }
 
@@ -850,7 +709,7 @@ void gemm_set_map_mode(int m) { g_map_override = m; }
 void gemm_set_tile(int t) { g_tile_override = t; }
 static int g_ant_override = -1;  // non-temporal A loads: -1 auto (row-complete tile only), 0, 1
 void gemm_set_a_nt(int v) { g_ant_override = v; }
-static int g_deep = 0;  // 1: use the deep-pipelined kernels where they exist (A/B knob)
+static int g_deep = -1;  // row-complete conv tile: 0 = 2-stage kernel, otherwise (default) the 8-phase kernel (A/B knob)
 void gemm_set_deep(int v) { g_deep = v; }
 static int g_nodma = 0;  // timing-only: skip the operand DMA after the first K-tile (WRONG results)
 void gemm_set_nodma(int v) { g_nodma = v; }
@@ -872,14 +731,14 @@ static const char* check_gemm(const GemmArgs& p, int groups) {
 
 bool gemm_is_narrow(int N) { return N <= 64 || (N > 128 && N < 256 && N % 128 != 0); }
 
-// Which tile instance serves a problem: 0 = 128x128, 1 = 128x64, 2 = 256x256, 3 = the
-// row-complete 128x512 tile with the fused LayerNorm epilogue.
+// Which tile instance serves a problem: 0 = 128x128, 1 = 128x64, 2 = 256x256 (2-stage),
+// 3 = the row-complete 128x512 tile with the fused LayerNorm epilogue (2-stage), 4 = 256x128,
+// 7 = 8-phase 256x256, 8 = 8-phase row-complete 128x512.
 // 256x256 tiles halve the operand bytes per FLOP (the per-CU L2->LDS rate is what bounds
 // this kernel) but quantise badly at M = B*199: measured faster only for the conv layers
 // (huge M, N = 512) and the K = 4096 FFN product (tools/bench_gemm.py, profiles/).
 int gemm_tile_of(const GemmArgs& p, int groups) {
-  if (p.ln_gamma) return g_deep == 1 ? 6 : 3;
-  if (g_deep == 1 && groups == 1 && !gemm_is_narrow(p.N) && g_tile_override == 1) return 5;
+  if (p.ln_gamma) return g_deep != 0 && p.kchunk == p.K ? 8 : 3;
   if (gemm_is_narrow(p.N)) return 1;
   if (groups != 1) return 0;
   if (g_tile_override == 2) return 4;  // 256x128 / 8 waves (A/B only: slower everywhere measured)
@@ -904,9 +763,8 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
     case 4: return launch_gemm_t<HT, 256, 128, 4, 2>(p, groups, s);
-    case 5: return launch_gemm_deep_t<HT, 256, 256, false>(p, groups, s);
-    case 6: return launch_gemm_deep_t<HT, 128, 512, true>(p, groups, s);
-    case 7: return launch_gemm8_t<HT>(p, groups, s);
+    case 7: return launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
+    case 8: return launch_gemm8_t<HT, 128, 512, true>(p, groups, s);
     default: return launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
   }
 }

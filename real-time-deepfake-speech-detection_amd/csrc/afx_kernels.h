@@ -51,11 +51,11 @@ struct GemmArgs {
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
 const char* launch_gemm_f32(const GemmArgs& p, int groups, hipStream_t s);  // afx_gemm_f32.hip (DT_FP32 operands)
 bool gemm_is_narrow(int N);  // true: the 128x64 tile instance serves this N
-int gemm_tile_of(const GemmArgs& p, int groups);  // 0: 128x128, 1: 128x64, 2: 256x256 instance
+int gemm_tile_of(const GemmArgs& p, int groups);  // tile instance id (afx_gemm.hip)
 void gemm_set_map_mode(int m);  // A/B knob: -1 default, else force map_mode
 void gemm_set_tile(int t);      // A/B knob: -1 default, 0: 128x128 tile, 1: 256x256 tile
 void gemm_set_a_nt(int v);      // A/B knob: -1 auto, 0/1 non-temporal A-panel loads
-void gemm_set_deep(int v);      // A/B knob: 1 = deep-pipelined tile kernels
+void gemm_set_deep(int v);      // A/B knob, conv tile: 0 = 2-stage kernel, -1/2 = 8-phase kernel (default)
 void gemm_set_nodma(int v);     // timing-only knob: compute phase without operand DMA (wrong results)
 
 // ---- frontend / row kernels (afx_frontend.hip) ---------------------------------

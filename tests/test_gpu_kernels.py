@@ -54,10 +54,10 @@ def test_gemm_epilogues(K, dtype, M, N, K_):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("tile", [0, 1, "deep", 3])
+@pytest.mark.parametrize("tile", [0, 1, 3])
 def test_gemm_tile_variants_agree_with_reference(K, dtype, tile):
-    """Every tile instance (128x128 / 4 waves, 256x256 / 8 waves 2-stage, deep ring, and the
-    8-phase 256x256 kernel = tile 3) and every workgroup->tile mapping must give the same
+    """Every tile instance (128x128 / 4 waves, 256x256 / 8 waves 2-stage, and the 8-phase
+    256x256 kernel = tile 3) and every workgroup->tile mapping must give the same
     numbers; M, N tails included."""
     from afx._lib import check, lib
     g = torch.Generator().manual_seed(11)
@@ -67,9 +67,6 @@ def test_gemm_tile_variants_agree_with_reference(K, dtype, tile):
     bias = torch.randn(N, generator=g)
     ref = F.gelu(A.float() @ W.float().t() + bias)
     try:
-        if tile == "deep":  # the deep-pipelined 256x256 kernel (4-stage ring, counted vmcnt)
-            check(lib().afx_debug_set(b"gemm_deep", 1))
-            tile = 1
         check(lib().afx_debug_set(b"gemm_tile", tile))
         for mode in (0, 1, 2):
             check(lib().afx_debug_set(b"gemm_map", mode))
@@ -78,7 +75,7 @@ def test_gemm_tile_variants_agree_with_reference(K, dtype, tile):
     finally:
         check(lib().afx_debug_set(b"gemm_tile", -1))
         check(lib().afx_debug_set(b"gemm_map", -1))
-        check(lib().afx_debug_set(b"gemm_deep", 0))
+        check(lib().afx_debug_set(b"gemm_deep", -1))
 
 
 @pytest.mark.parametrize("M,N,K_", [(1000, 768, 64), (515, 512, 192), (300, 256, 128), (2048, 1024, 4096), (12736, 1024, 1024)])
@@ -141,7 +138,7 @@ def test_conv_layer_as_gemm(K, dtype, k, s, Tin):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("k,s,Tin", [(3, 2, 301), (2, 2, 40)])
-@pytest.mark.parametrize("deep", [0, 1])
+@pytest.mark.parametrize("deep", [0, 2])  # 2-stage kernel, 8-phase kernel
 def test_conv_layer_with_fused_layernorm_gelu(K, dtype, k, s, Tin, deep):
     """Row-complete 128x512 tile: conv + bias + LayerNorm(512) + GELU in one kernel, M tail
     (B*Tout not a multiple of 128) included; fp32 and operand-type outputs."""
@@ -157,12 +154,33 @@ def test_conv_layer_with_fused_layernorm_gelu(K, dtype, k, s, Tin, deep):
     try:
         of, oh = K.conv_ln_act(dtype, x.cuda(), wp, k, s, bias.cuda(), ga.cuda(), be.cuda(), out_f=True, out_h=True)
     finally:
-        check(lib().afx_debug_set(b"gemm_deep", 0))
+        check(lib().afx_debug_set(b"gemm_deep", -1))
     ref = F.conv1d(x.float().transpose(1, 2), w.to(_td(dtype)).float(), bias, stride=s).transpose(1, 2)
     ref = F.gelu(F.layer_norm(ref, (512,), ga, be, 1e-5))
     assert of.shape == ref.shape
     _close(of, ref, 2e-4, 2e-4)
     _close(oh, ref, _eps(dtype) * 4, 1e-3)
+
+
+def test_conv_layernorm_8phase_tile_is_bit_identical_to_the_2stage_tile(K):
+    """Race screen for the 8-phase 128x512 row-complete tile (see the 256x256 one above)."""
+    from afx._lib import check, lib
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(8, 3199, 512, generator=g).half().cuda()
+    bias = (torch.randn(512, generator=g) * 0.5).cuda()
+    ga = (1 + 0.1 * torch.randn(512, generator=g)).cuda()
+    be = (0.1 * torch.randn(512, generator=g)).cuda()
+    for k in (3, 2):
+        wp = K.pack_conv("fp16", (torch.randn(512, 512, k, generator=g) / math.sqrt(512 * k)).cuda())
+        try:
+            check(lib().afx_debug_set(b"gemm_deep", 0))  # the 2-stage tile
+            want, _ = K.conv_ln_act("fp16", x, wp, k, 2, bias, ga, be, out_f=True, out_h=False)
+            check(lib().afx_debug_set(b"gemm_deep", 2))
+            for _ in range(8):
+                got, _ = K.conv_ln_act("fp16", x, wp, k, 2, bias, ga, be, out_f=True, out_h=False)
+                assert torch.equal(got, want)
+        finally:
+            check(lib().afx_debug_set(b"gemm_deep", -1))
 
 
 @pytest.mark.parametrize("dtype", DT)

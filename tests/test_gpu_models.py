@@ -175,3 +175,29 @@ def test_hipgraph_replay_matches_eager_and_harness_writes_scores(afx_mod, tmp_pa
     from oracle import pre
     x = synth.waveforms(3, 1000, batch_idx=5)
     assert (pe(x.cuda()).cpu() - pre.pre_emphasis(x)).abs().max().item() < 1e-6
+
+
+def test_eer_of_the_build_matches_the_oracle(afx_mod):
+    """EER delta on a synthetic trial list.  Labels are drawn from the oracle's
+    own scores plus noise (so the oracle EER sits at 10-20 %); the fp16 engine's scores must rank
+    the trials the same way: |EER_build - EER_oracle| < 0.005 percentage points."""
+    engine, synth = afx_mod
+    from afx import harness
+    from oracle import models, pre
+    sd = synth.model_state_dict("ConformerModel", n_layers=2, n_encoders=2)
+    eng = engine.Engine("conformer", n_layers=2, dtype="fp16", conf_blocks=2)
+    eng.load_state_dict(sd)
+    ref, got = [], []
+    for i in range(8):  # 256 one-second trials
+        wave = synth.waveforms(32, 16000, batch_idx=500 + i)
+        ref.append(models.conformer_forward(sd, wave)[:, 1])
+        got.append(eng.forward(wave.cuda())[:, 1].cpu())
+    ref, got = torch.cat(ref), torch.cat(got)
+    g = torch.Generator().manual_seed(4096)
+    noisy = ref + ref.std() * 0.8 * torch.randn(ref.shape, generator=g)
+    labels = (noisy > noisy.median()).long().numpy()
+    eer_ref = pre.eer_percent(ref.numpy(), labels)
+    eer_got = harness.calculate_EER(got.numpy(), labels)
+    print(f"EER oracle {eer_ref:.4f} %  build {eer_got:.4f} %  max|dscore| {(got - ref).abs().max().item():.2e}")
+    assert 5.0 < eer_ref < 35.0
+    assert abs(eer_got - eer_ref) < 0.005

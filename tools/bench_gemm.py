@@ -34,9 +34,7 @@ SETS = {
     "map": [("map0", ("gemm_map", 0)), ("map1", ("gemm_map", 1)), ("map2", ("gemm_map", 2))],
     "nt": [("A default", ("gemm_a_nt", 0)), ("A nt", ("gemm_a_nt", 1))],
     "nodma": [("full", ("gemm_nodma", 0)), ("compute-only", ("gemm_nodma", 1))],
-    "deep": [("2-stage", ("gemm_deep", 0)), ("deep ring", ("gemm_deep", 1))],
-    "deep256": [("128x128", [("gemm_deep", 0), ("gemm_tile", 0)]), ("256x256 2-stage", [("gemm_deep", 0), ("gemm_tile", 1)]),
-                ("256x256 deep", [("gemm_deep", 1), ("gemm_tile", 1)])],
+    "deep": [("2-stage", ("gemm_deep", 0)), ("8-phase", ("gemm_deep", 2))],
     "epi": [("narrow stores", ("gemm_nodma", 16)), ("wide stores", ("gemm_nodma", 0))],
     "attr": [("full", ("gemm_nodma", 0)), ("-dma", ("gemm_nodma", 1)), ("-dma-lds", ("gemm_nodma", 3)),
              ("-dma-mfma", ("gemm_nodma", 5)), ("-dma-act", ("gemm_nodma", 9)), ("-dma-lds-mfma-act", ("gemm_nodma", 15))],
@@ -98,8 +96,8 @@ def main():
         print(f"{name:36s} {row}", flush=True)
     for key in ("gemm_tile", "gemm_map", "gemm_a_nt"):
         check(lib().afx_debug_set(key.encode(), -1))
-    for key in ("gemm_nodma", "gemm_deep"):
-        check(lib().afx_debug_set(key.encode(), 0))
+    check(lib().afx_debug_set(b"gemm_nodma", 0))
+    check(lib().afx_debug_set(b"gemm_deep", -1))
 
 
 if __name__ == "__main__":
