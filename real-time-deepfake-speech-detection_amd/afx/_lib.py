@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libafx.so")
+LIB_PATH = os.environ.get("AFX_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libafx.so")
 
 ARCH_SSL, ARCH_XLSR_AASIST, ARCH_CONFORMER = 0, 1, 2
 DT_BF16, DT_FP16, DT_FP32 = 0, 1, 2
@@ -80,6 +80,11 @@ def lib():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
         _lib = l
+        # A/B knobs for measurement runs, e.g. AFX_DEBUG="fuse_conformer=0,gemm_tile=0" (afx_debug_set keys)
+        for kv in filter(None, os.environ.get("AFX_DEBUG", "").split(",")):
+            key, _, val = kv.partition("=")
+            if l.afx_debug_set(key.strip().encode(), int(val)) != 0:
+                raise AfxError(l.afx_last_error().decode())
     return _lib
 
 

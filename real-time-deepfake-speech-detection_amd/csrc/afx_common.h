@@ -89,6 +89,14 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float swish(float x) { return x * sigmoid_acc(x); }
+// v_exp + v_rcp forms (about 2 ulp) for results that are rounded to fp16/bf16 next: the accurate
+// expf + IEEE division above are ~40 VALU instructions per element, these are 5.  A wave64 VALU
+// instruction occupies its SIMD for 4 cycles, so this is what bounds the register-resident
+// Conformer chains (one or two waves per SIMD, tools/bench_chain attribution in DESIGN.md).
+__device__ __forceinline__ float sigmoid_fast(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+__device__ __forceinline__ float swish_fast(float x) { return x * sigmoid_fast(x); }
 __device__ __forceinline__ float selu(float x) {
   return x > 0.f ? kSeluScale * x : kSeluScale * kSeluAlpha * (expf(x) - 1.0f);
 }

@@ -1,0 +1,400 @@
+// Conformer block, row-local parts fused, gfx950.
+//
+// Everything in a Conformer block except the attention itself and the depthwise conv acts on
+// one token row at a time.  A wave owns 16 token rows and carries them through a whole chain
+// of LayerNorm -> Linear -> activation -> Linear -> residual steps WITHOUT leaving its
+// registers: the fp32 residual rows live in the MFMA accumulator layout (lane = row l&15,
+// 4 consecutive columns 4(l>>4)..+3 of every 16-column tile); a LayerNorm is a 4-lane
+// reduction (v_permlane16/32_swap); turning 32 columns of accumulator into the next product's
+// A operand is one v_permlane16_swap per register (the wide-store exchange of the GEMM
+// epilogue), which leaves lane l with 8 consecutive columns starting at
+// kb(l) = 16 ((l>>4)&1) + 8 (l>>5) -- the weight fragment is simply fetched with the same
+// permutation, so both MFMA operands agree on which k every slot carries.  Weights stream
+// through LDS: the eight waves of a workgroup (128 rows) fill chunks of <= 32 fragment blocks by
+// LDS-DMA, already in MFMA fragment order (1 KB per 16 x 32 block = the 64 lanes' 16-byte
+// pieces), into a ring of four 32-KB buffers: every wave issues exactly 4 DMA instructions
+// per chunk (padding goes to a dump block), so "chunk i has landed" is the counted wait
+// vmcnt(8) with chunks i+1 and i+2 still in flight, chunk i+3 is issued behind the barrier
+// that frees its buffer.  Each weight byte leaves L2 once per workgroup and every fragment
+// read is a conflict-free ds_read_b128.  (Measured: weights from L2 per wave 81 us per chain,
+// double-buffered LDS chunks 40 us, this ring: see DESIGN.md.)
+//
+// Three chains per block replace fifteen launches (5 LayerNorms, 9 GEMMs, 1 memset):
+//   A  x += 1/2 FF1(x);  q|k|v = W_qkv LN(x)                          (before the attention)
+//   B  x += W_out attn + b;  glu_in = W_pw1 LN(x) + b                 (before the depthwise conv)
+//   C  x += W_pw2 u + b;  x += 1/2 FF2(x);  x = LN_post(x)            (end of the block)
+// E = 144 (the reference's emb_size), FF = 576, conv inner = 288; other sizes take the
+// unfused path of afx_engine.hip.
+#include "afx_common.h"
+#include "afx_kernels.h"
+
+// Timing experiments only (wrong results): build with -DCHAIN_DBG=<mask> into a separate library
+// (1: no weight DMA after the prologue, 2: no MFMA, 4: no barriers, 8: every fragment read hits one LDS address).
+#ifndef CHAIN_DBG
+#define CHAIN_DBG 0
+#endif
+
+namespace afx {
+
+namespace {
+
+constexpr int ET = 9;   // 16-column tiles of the residual stream (E = 144)
+constexpr int EK = 5;   // 32-wide k-steps covering E (144 -> 160, the pad columns are zero)
+constexpr int HT6 = 6;  // the FF hidden layer is walked in 6 parts of 6 tiles (96 columns = 3 k-steps)
+constexpr int RING = 4, BUFSZ = 32 * 1024, DUMP = RING * BUFSZ;  // + one 1-KB dump block
+constexpr int PARAMS = DUMP + 1024;  // byte offset of the parameter block behind the ring and the dump block
+constexpr int NWAVE = 8;  // 128 token rows per workgroup: each weight byte is fetched once per 128 rows
+
+struct ChunkDesc {  // NT x KS fragment blocks of matrix W: rows n0 .. n0 + 16 NT, k-steps k0 .. k0 + KS
+  const void* W;
+  int ldw, n0, k0, nt, ks;
+};
+
+// the static weight-chunk sequence of each chain (must match the compute order below)
+template <int STAGE>
+__device__ __forceinline__ ChunkDesc chunk_of(const ConfChainArgs& p, int idx) {
+  auto ff = [&](int c) {  // 12 chunks: W1 part, W2 part, ...
+    const int part = c >> 1;
+    return (c & 1) ? ChunkDesc{p.ff_w2, p.FFp, 0, 3 * part, ET, 3} : ChunkDesc{p.ff_w1, p.Ep, part * HT6 * 16, 0, HT6, EK};
+  };
+  auto rows6 = [&](const void* W, int ld, int c, int tiles) {  // N = 16 tiles, six tiles per chunk (the last may be shorter)
+    const int left = tiles - 6 * c;
+    return ChunkDesc{W, ld, c * 96, 0, left < 6 ? left : 6, EK};
+  };
+  if constexpr (STAGE == 0) return idx < 12 ? ff(idx) : rows6(p.w_a, p.Ep, idx - 12, 3 * ET);
+  else if constexpr (STAGE == 1) return idx < 2 ? rows6(p.w_a, p.Ep, idx, ET) : rows6(p.w_b, p.Ep, idx - 2, 4 * ET);
+  else return idx < 3 ? ChunkDesc{p.w_a, p.ld_w_a, 0, 3 * idx, ET, 3} : ff(idx - 3);
+}
+template <int STAGE> constexpr int kChunks = STAGE == 0 ? 12 + 5 : STAGE == 1 ? 2 + 6 : 3 + 12;
+
+template <class HT, int STAGE>
+struct Chain {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+
+  const ConfChainArgs& p;
+  int lane, wave, r16, kq, kb;
+  char* smem;
+  unsigned lds_base;
+  int consumed = 0;
+  __device__ Chain(const ConfChainArgs& args, char* lds) : p(args) {
+    lane = threadIdx.x & 63;
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    r16 = lane & 15;
+    kq = lane >> 4;
+    kb = (kq & 1) * 16 + (kq >> 1) * 8;
+    smem = lds;
+    lds_base = (unsigned)(size_t)lds;
+    prm = (const float*)(lds + PARAMS);
+  }
+  const float* prm;
+
+  // ---- weight stream -------------------------------------------------------------------
+  __device__ __forceinline__ void issue(int idx) {  // exactly 32 / NWAVE LDS-DMA instructions per wave
+    if constexpr ((CHAIN_DBG & 1) != 0) {
+      if (idx >= RING - 1) return;
+    }
+    const ChunkDesc d = chunk_of<STAGE>(p, idx);
+    const int nb = d.nt * d.ks;
+    const unsigned dst0 = lds_base + (idx & (RING - 1)) * BUFSZ;
+    const T* src0 = (const T*)d.W + (long)(d.n0 + r16) * d.ldw + d.k0 * 32 + kb;
+#pragma unroll
+    for (int i = 0; i < 32 / NWAVE; ++i) {
+      const int b = i * NWAVE + wave;
+      const bool valid = b < nb;
+      const int j = d.ks == 3 ? (b * 11) >> 5 : (b * 13) >> 6;  // b / ks for b < 32, ks in {3, 5}
+      const int k = b - j * d.ks;
+      const T* src = valid ? src0 + (long)j * 16 * d.ldw + k * 32 : src0;
+      unsigned keep;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(valid ? dst0 + b * 1024 : lds_base + DUMP);
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+  }
+  // The per-column vectors (biases, LayerNorm gamma/beta: one packed 8-KB block per chain) ride
+  // the same DMA stream -- one instruction per wave, first in the queue.  Nothing in the chain
+  // is a compiler-visible global load: the DMAs are issued from inline asm, so a compiler wait
+  // for one of its own loads would be vmcnt(0) and drain the weight ring every time (measured:
+  // 36 us per chain with the bias vectors read from global inside the chain).
+  __device__ __forceinline__ void prologue() {
+    {
+      unsigned keep;
+      const float* src = p.params + wave * 256 + lane * 4;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + PARAMS + wave * 1024);
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+    static_assert(kChunks<STAGE> >= RING - 1 && NWAVE * 256 == kChainParamFloats, "prologue shape");
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) issue(i);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // the parameter block (oldest) has landed; 3 chunks x 4 stay in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  // Before consuming chunk i: its DMA has landed on every wave (counted wait, then the barrier),
+  // and every wave is done with chunk i-1, whose buffer chunk i+3 now takes.  Returns the
+  // lane's fragment base inside chunk i.
+  __device__ __forceinline__ const char* next_chunk() {
+    const int i = consumed++;
+    const int after = kChunks<STAGE> - 1 - i;  // chunks issued behind this one
+    static_assert(32 / NWAVE == 4, "the counted waits below assume 4 DMA instructions per wave per chunk");
+    if constexpr ((CHAIN_DBG & 1) == 0) {
+      if (after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if constexpr ((CHAIN_DBG & 4) == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (i + RING - 1 < kChunks<STAGE>) issue(i + RING - 1);
+    return smem + (i & (RING - 1)) * BUFSZ + lane * 16;
+  }
+
+  // Fragment reads are batched per group of 3 output tiles (3 KS ds_read_b128 in flight) and the
+  // MFMAs walk k outside, tiles inside (3 independent accumulators back to back); the second
+  // wave of the SIMD fills the read latency.  The sched_barriers pin that shape: left alone,
+  // hipcc emits read -> wait -> MFMA on one accumulator at a time.
+  template <int NT, int KS, bool ACCUM>
+  __device__ __forceinline__ void gemm_impl(const V8* a, const char* wb, f32x4* acc) const {
+    static_assert(NT % 3 == 0, "tiles are processed in groups of 3");
+    constexpr int NG = NT / 3;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      V8 w[3][KS];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) w[t][k] = *(const V8*)(wb + ((CHAIN_DBG & 8) ? 0 : ((g * 3 + t) * KS + k) * 1024));
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 c[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) c[t] = ACCUM ? acc[g * 3 + t] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          if constexpr ((CHAIN_DBG & 2) != 0) asm volatile("" :: "v"(w[t][k]));
+          else c[t] = HT::mfma(w[t][k], a[k], c[t]);
+        }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[g * 3 + t] = c[t];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  template <int NT, int KS>
+  __device__ __forceinline__ void gemm(const V8* a, const char* wb, f32x4* acc) const {
+    gemm_impl<NT, KS, false>(a, wb, acc);
+  }
+  template <int NT, int KS>
+  __device__ __forceinline__ void gemm_acc(const V8* a, const char* wb, f32x4* acc) const {
+    gemm_impl<NT, KS, true>(a, wb, acc);
+  }
+  // N = 16 TILES output columns of a K = 160 product, six tiles per weight chunk
+  template <int TILES>
+  __device__ __forceinline__ void gemm_rows6(const V8* a, f32x4* acc) {
+#pragma unroll
+    for (int c = 0; c < TILES / 6; ++c) gemm<6, EK>(a, next_chunk(), acc + 6 * c);
+    if constexpr (TILES % 6 != 0) gemm<TILES % 6, EK>(a, next_chunk(), acc + 6 * (TILES / 6));
+  }
+
+  // ---- row math ------------------------------------------------------------------------
+  // two adjacent accumulator tiles -> this lane's 8 consecutive k of the 32-wide step
+  __device__ __forceinline__ V8 pack_pair(f32x4 a, f32x4 b) const {
+    V8 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[r]), __float_as_uint(b[r]), false, false);
+      h[r] = (T)__uint_as_float(sw[0]);
+      h[4 + r] = (T)__uint_as_float(sw[1]);
+    }
+    return h;
+  }
+  __device__ __forceinline__ void layernorm(const f32x4 (&x)[ET], const float* __restrict__ g, const float* __restrict__ b,
+                                            f32x4 (&y)[ET]) const {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < ET; ++j) s += (x[j][0] + x[j][1]) + (x[j][2] + x[j][3]);
+    const float mean = rows_sum(s) * (1.0f / (16 * ET));
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < ET; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = x[j][r] - mean;
+        q = fmaf(d, d, q);
+      }
+    const float rstd = 1.0f / sqrtf(rows_sum(q) * (1.0f / (16 * ET)) + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < ET; ++j) {
+      const f32x4 gg = *(const f32x4*)(g + j * 16 + kq * 4), bb = *(const f32x4*)(b + j * 16 + kq * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[j][r] = fmaf((x[j][r] - mean) * rstd, gg[r], bb[r]);
+    }
+  }
+  __device__ __forceinline__ void frags_of_rows(const f32x4 (&y)[ET], V8 (&a)[EK]) const {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = pack_pair(y[2 * t], y[2 * t + 1]);
+    a[4] = pack_pair(y[8], f32x4{0.f, 0.f, 0.f, 0.f});
+  }
+
+  // x += 1/2 (W2 swish(W1 LN(x) + b1) + b2): the macaron feed-forward half step (12 weight chunks)
+  __device__ __forceinline__ void feed_forward(f32x4 (&x)[ET]) {
+    f32x4 y[ET];
+    layernorm(x, prm + CP_FF_G, prm + CP_FF_B, y);
+    V8 a[EK];
+    frags_of_rows(y, a);
+    f32x4 o[ET];
+#pragma unroll
+    for (int j = 0; j < ET; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int part = 0; part < 6; ++part) {
+      f32x4 h[HT6];
+      gemm<HT6, EK>(a, next_chunk(), h);
+      V8 hf[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int c0 = part * HT6 * 16 + t * 32 + kq * 4;
+        const f32x4 ba = *(const f32x4*)(prm + CP_FF_B1 + c0), bb = *(const f32x4*)(prm + CP_FF_B1 + c0 + 16);
+        f32x4 u = h[2 * t] + ba, v = h[2 * t + 1] + bb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          u[r] = swish_fast(u[r]);
+          v[r] = swish_fast(v[r]);
+        }
+        hf[t] = pack_pair(u, v);
+      }
+      gemm_acc<ET, 3>(hf, next_chunk(), o);
+    }
+#pragma unroll
+    for (int j = 0; j < ET; ++j) {
+      const f32x4 bb = *(const f32x4*)(prm + CP_FF_B2 + j * 16 + kq * 4);
+      x[j] += 0.5f * (o[j] + bb);
+    }
+  }
+};
+
+}  // namespace
+
+template <class HT, int STAGE>
+__global__ __launch_bounds__(64 * NWAVE) void conf_chain_kernel(ConfChainArgs p) {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Chain<HT, STAGE> c(p, smem);
+  // every wave takes part in the weight fills and barriers; rows past M are clamped and not stored
+  const long row = ((long)blockIdx.x * NWAVE + c.wave) * 16 + c.r16;
+  const bool ok = row < p.M;
+  const long rc = ok ? row : p.M - 1;
+
+  f32x4 x[ET];
+#pragma unroll
+  for (int j = 0; j < ET; ++j) x[j] = *(const f32x4*)(p.x_in + rc * p.E + j * 16 + c.kq * 4);
+  V8 ain[ET];  // stage 1: attention output (5 k-steps), stage 2: depthwise-conv output (9 k-steps)
+  if constexpr (STAGE != 0) {
+#pragma unroll
+    for (int t = 0; t < (STAGE == 1 ? EK : ET); ++t) ain[t] = *(const V8*)((const T*)p.in_h + rc * p.ld_in_h + t * 32 + c.kb);
+  }
+  // the row loads are consumed (compiler-placed waits) before the DMA stream starts
+#pragma unroll
+  for (int j = 0; j < ET; ++j) asm volatile("" : "+v"(x[j]));
+  if constexpr (STAGE != 0) {
+#pragma unroll
+    for (int t = 0; t < (STAGE == 1 ? EK : ET); ++t) asm volatile("" : "+v"(ain[t]));
+  }
+  c.prologue();
+
+  if constexpr (STAGE == 0) {
+    c.feed_forward(x);
+    if (ok) {
+#pragma unroll
+      for (int j = 0; j < ET; ++j) *(f32x4*)(p.x_out + row * p.E + j * 16 + c.kq * 4) = x[j];
+    }
+    f32x4 y[ET];
+    c.layernorm(x, c.prm + CP_LN2_G, c.prm + CP_LN2_B, y);
+    V8 a[EK];
+    c.frags_of_rows(y, a);
+    // q | k | v: 3 x 144 columns (27 tiles), no bias; six tiles per weight chunk, the last one three
+#pragma unroll
+    for (int part = 0; part < 5; ++part) {
+      f32x4 q[6];
+      if (part < 4) c.template gemm<6, EK>(a, c.next_chunk(), q);
+      else c.template gemm<3, EK>(a, c.next_chunk(), q);
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < (part < 4 ? 6 : 3); ++j) *(f32x4*)(p.out2 + row * p.ld_out2 + (part * 6 + j) * 16 + c.kq * 4) = q[j];
+      }
+    }
+  } else if constexpr (STAGE == 1) {
+    // attention output (operand type, row stride ld_in_h, pad columns zero) -> out-projection
+    V8 a[EK];
+#pragma unroll
+    for (int t = 0; t < EK; ++t) a[t] = ain[t];
+    f32x4 o[ET];
+    c.template gemm_rows6<ET>(a, o);
+#pragma unroll
+    for (int j = 0; j < ET; ++j) x[j] += o[j] + *(const f32x4*)(c.prm + CP_BA + j * 16 + c.kq * 4);
+    if (ok) {
+#pragma unroll
+      for (int j = 0; j < ET; ++j) *(f32x4*)(p.x_out + row * p.E + j * 16 + c.kq * 4) = x[j];
+    }
+    f32x4 y[ET];
+    c.layernorm(x, c.prm + CP_LN2_G, c.prm + CP_LN2_B, y);
+    c.frags_of_rows(y, a);
+    // pointwise conv 1 (144 -> 576, bias): the GLU input, fp32; six tiles per weight chunk
+#pragma unroll
+    for (int part = 0; part < 6; ++part) {
+      f32x4 gl[6];
+      c.template gemm<6, EK>(a, c.next_chunk(), gl);
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int col = part * 96 + j * 16 + c.kq * 4;
+          *(f32x4*)(p.out2 + row * p.ld_out2 + col) = gl[j] + *(const f32x4*)(c.prm + CP_BB + col);
+        }
+      }
+    }
+  } else {
+    // depthwise-conv output (operand type, 288 columns) -> pointwise conv 2 -> residual
+    const V8* a = ain;
+    f32x4 o[ET];
+#pragma unroll
+    for (int j = 0; j < ET; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) c.template gemm_acc<ET, 3>(a + 3 * kc, c.next_chunk(), o);
+#pragma unroll
+    for (int j = 0; j < ET; ++j) x[j] += o[j] + *(const f32x4*)(c.prm + CP_BA + j * 16 + c.kq * 4);
+    c.feed_forward(x);
+    f32x4 y[ET];
+    c.layernorm(x, c.prm + CP_LN2_G, c.prm + CP_LN2_B, y);
+    if (ok) {
+#pragma unroll
+      for (int j = 0; j < ET; ++j) *(f32x4*)(p.x_out + row * p.E + j * 16 + c.kq * 4) = y[j];
+    }
+  }
+}
+
+template <class HT, int STAGE>
+static hipError_t launch_conf_chain_t(const ConfChainArgs& p, hipStream_t s) {
+  constexpr int lds = PARAMS + kChainParamFloats * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conf_chain_kernel<HT, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conf_chain_kernel<HT, STAGE>), dim3((unsigned)((p.M + 16 * NWAVE - 1) / (16 * NWAVE))), dim3(64 * NWAVE), lds, s, p);
+  return hipGetLastError();
+}
+
+const char* launch_conf_chain(const ConfChainArgs& p, int stage, int dtype, hipStream_t s) {
+  if (p.E != 16 * ET || p.Ep < 32 * EK || p.FFp != 4 * 16 * ET) return "conf_chain: the fused Conformer chains are built for emb 144 / ff 576";
+  if (dtype == DT_FP32) return "conf_chain: half-precision operands only";
+  if (p.M <= 0 || stage < 0 || stage > 2) return "conf_chain: bad arguments";
+  hipError_t e;
+  if (dtype == DT_BF16)
+    e = stage == 0 ? launch_conf_chain_t<BF16, 0>(p, s) : stage == 1 ? launch_conf_chain_t<BF16, 1>(p, s) : launch_conf_chain_t<BF16, 2>(p, s);
+  else
+    e = stage == 0 ? launch_conf_chain_t<FP16, 0>(p, s) : stage == 1 ? launch_conf_chain_t<FP16, 1>(p, s) : launch_conf_chain_t<FP16, 2>(p, s);
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+}  // namespace afx

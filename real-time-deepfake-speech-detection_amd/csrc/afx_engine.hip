@@ -92,6 +92,7 @@ struct TapRec {
 struct ConfBlock {
   void *ff1_w1, *ff1_w2, *ff2_w1, *ff2_w2, *wqkv, *wout, *pw1, *pw2;
   float *bn_scale, *bn_shift;
+  float* chain_prm[3];  // per fused chain: the per-column vectors packed into one 8-KB block (ConfChainArgs::params)
 };
 
 struct afx_engine {
@@ -201,6 +202,7 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
       ok &= (B.pw2 = e->dalloc((size_t)e->E * e->C2p * e->hsz)) != nullptr;
       ok &= (B.bn_scale = (float*)e->dalloc((size_t)e->C2 * 4)) != nullptr;
       ok &= (B.bn_shift = (float*)e->dalloc((size_t)e->C2 * 4)) != nullptr;
+      for (int st = 0; st < 3; ++st) ok &= (B.chain_prm[st] = (float*)e->dalloc(kChainParamFloats * 4)) != nullptr;
     }
   }
   if (!ok) {
@@ -443,6 +445,25 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
         return fail("afx_finalize: depthwise kernel has %zu elements, expected %d x %d", dw.n, h->C2, h->ck);
       const FT& rp = h->f[B + "attn.fn.rel_pos_emb.weight"];
       if (rp.n != (size_t)1025 * h->dh) return fail("afx_finalize: rel_pos_emb must be (1025, %d)", h->dh);
+      if (h->E == 144) {  // parameter blocks of the fused chains (layout: ChainParamOffsets in afx_kernels.h)
+        auto put = [&](int st, int off, const std::string& name, int n) -> int {
+          HIP_OK(hipMemcpyAsync(h->blk[b].chain_prm[st] + off, h->F(B + name), (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+          return 0;
+        };
+        for (int st = 0; st < 3; ++st) HIP_OK(hipMemsetAsync(h->blk[b].chain_prm[st], 0, kChainParamFloats * 4, s));
+        for (int st = 0; st < 3; st += 2) {  // stages 0 and 2 carry a feed-forward module
+          const std::string ff = st == 0 ? "ff1" : "ff2";
+          if (put(st, CP_FF_G, ff + ".fn.norm.weight", 144) || put(st, CP_FF_B, ff + ".fn.norm.bias", 144) ||
+              put(st, CP_FF_B1, ff + ".fn.fn.net.0.bias", 576) || put(st, CP_FF_B2, ff + ".fn.fn.net.3.bias", 144))
+            return 1;
+        }
+        if (put(0, CP_LN2_G, "attn.norm.weight", 144) || put(0, CP_LN2_B, "attn.norm.bias", 144) ||
+            put(1, CP_LN2_G, "conv.net.0.weight", 144) || put(1, CP_LN2_B, "conv.net.0.bias", 144) ||
+            put(1, CP_BA, "attn.fn.to_out.bias", 144) || put(1, CP_BB, "conv.net.2.bias", 576) ||
+            put(2, CP_LN2_G, "post_norm.weight", 144) || put(2, CP_LN2_B, "post_norm.bias", 144) ||
+            put(2, CP_BA, "conv.net.7.bias", 144))
+          return 1;
+      }
     }
     // BatchNorm2d(1): four scalars -> host (one-off synchronisation)
     float w, b, m, v;
@@ -586,11 +607,11 @@ extern "C" int afx_tap(afx_handle h, const char* name, float* out, size_t cap, s
 // launch of the forward is bracketed by hipEvents on the launch stream and summed per
 // class afterwards.  Off by default: the normal forward records nothing.
 // ---------------------------------------------------------------------------------
-enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN, PC_GEMM_F32, PC_CONV0, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV,
+enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN, PC_GEMM_F32, PC_CONV0, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV, PC_CONF_CHAIN,
                  PC_MISC, PC_AASIST, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm_kernel<128x128>", "gemm_kernel<128x64>", "gemm_kernel<256x256>",
                                            "gemm_kernel<128x512,rowLN>", "gemm8_kernel<256x256>", "gemm8_kernel<128x512,rowLN>", "gemm_f32_kernel<128x128>", "conv0_kernel", "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel",
-                                           "conf_dwconv_kernel", "misc", "aasist_head"};
+                                           "conf_dwconv_kernel", "conf_chain_kernel", "misc", "aasist_head"};
 struct ProfRec { int cls; hipEvent_t a, b; double flops; };
 struct Profiler {
   bool on = false;
@@ -608,6 +629,7 @@ struct Profiler {
 };
 static std::unordered_map<afx_engine*, Profiler> g_prof;
 static thread_local Profiler* t_prof = nullptr;
+static int g_fuse_conformer = 1;  // Conformer block: row-local chains fused (afx_conformer_fused.hip); 0 = per-op path
 static int g_fuse_conv_ln = 1;  // conv layers 1-6: LayerNorm+GELU in the GEMM epilogue (A/B knob)
 static void prof_forget(afx_engine* e) {
   auto it = g_prof.find(e);
@@ -827,7 +849,49 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
   HIP_OK(hipMemsetAsync(w.ao, 0, (size_t)M * Ep * hs, s));
   HIP_OK(hipMemsetAsync(w.u, 0, (size_t)M * e->C2p * hs, s));
   if (e->FFp != e->FF) HIP_OK(hipMemsetAsync(w.hid, 0, (size_t)M * e->FFp * hs, s));
-  for (int b = 0; b < e->nblk; ++b) {
+  const bool fused = g_fuse_conformer && dt != DT_FP32 && E == 144 && e->inner == E && e->FFp == 4 * E;
+  for (int b = 0; fused && b < e->nblk; ++b) {
+    // three register-resident row chains around the attention and the depthwise conv
+    const std::string P = "conformer.encoder_blocks." + std::to_string(b) + ".";
+    ConfBlock& K = e->blk[b];
+    ConfChainArgs c;
+    memset(&c, 0, sizeof c);
+    c.M = M; c.E = E; c.Ep = Ep; c.FFp = e->FFp;
+    c.x_in = w.xc; c.x_out = w.xc;  // in place: a wave reads and writes only its own 16 rows
+    auto ff = [&](void* w1, void* w2) { c.ff_w1 = w1; c.ff_w2 = w2; };
+    const double ff_fl = 2.0 * M * E * e->FF * 2;
+    ff(K.ff1_w1, K.ff1_w2);
+    c.params = K.chain_prm[0];
+    c.w_a = K.wqkv; c.ld_w_a = Ep;
+    c.out2 = w.qkv32; c.ld_out2 = 3 * e->inner;
+    KOK(timed(PC_CONF_CHAIN, ff_fl + 2.0 * M * E * 3 * e->inner, s, [&] { return launch_conf_chain(c, 0, dt, s); }));
+    KOK(timed(PC_CONF_ATTN, 6.0 * B * e->heads * (double)N * N * e->dh, s, [&] {
+      return launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
+                              e->F(P + "attn.fn.rel_pos_emb.weight"), 512, B, N, e->heads, e->dh, w.ao, Ep, dt, s);
+    }));
+    c.in_h = w.ao; c.ld_in_h = Ep;
+    c.params = K.chain_prm[1];
+    c.w_a = K.wout;
+    c.w_b = K.pw1;
+    c.out2 = w.glu32; c.ld_out2 = 2 * e->C2;
+    KOK(timed(PC_CONF_CHAIN, 2.0 * M * E * (e->inner + 2 * e->C2), s, [&] { return launch_conf_chain(c, 1, dt, s); }));
+    KOK(timed(PC_CONF_DWCONV, 2.0 * B * N * e->C2 * e->ck, s, [&] {
+      return launch_conf_dwconv(w.glu32, 2 * e->C2, e->F(P + "conv.net.4.conv.weight"),
+                                e->F(P + "conv.net.4.conv.bias"), K.bn_scale, K.bn_shift, B, N, e->C2, e->ck, w.u,
+                                e->C2p, dt, s);
+    }));
+    c.in_h = w.u; c.ld_in_h = e->C2p;
+    c.params = K.chain_prm[2];
+    c.w_a = K.pw2; c.ld_w_a = e->C2p;
+    ff(K.ff2_w1, K.ff2_w2);
+    c.w_b = nullptr; c.out2 = nullptr;
+    KOK(timed(PC_CONF_CHAIN, ff_fl + 2.0 * M * e->C2 * E, s, [&] { return launch_conf_chain(c, 2, dt, s); }));
+    if (e->taps_on) {
+      const std::string nm = "block" + std::to_string(b);
+      if (tap(e, nm.c_str(), w.xc, (size_t)M * E, false, s)) return 1;
+    }
+  }
+  for (int b = 0; !fused && b < e->nblk; ++b) {
     const std::string P = "conformer.encoder_blocks." + std::to_string(b) + ".";
     ConfBlock& K = e->blk[b];
     auto norm_to_h = [&](const char* nm) -> const char* {
@@ -1057,6 +1121,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
   }
   if (!strcmp(key, "gemm_a_nt")) {
     gemm_set_a_nt(value);
+    return 0;
+  }
+  if (!strcmp(key, "fuse_conformer")) {
+    g_fuse_conformer = value != 0;
     return 0;
   }
   if (!strcmp(key, "fuse_conv_ln")) {

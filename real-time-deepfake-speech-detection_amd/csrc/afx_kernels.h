@@ -108,6 +108,30 @@ const char* launch_conf_attn(const float* q, long ldq, const float* kv, long ldk
 const char* launch_conf_dwconv(const float* x, long ldx, const float* w /*[C][k]*/, const float* bias,
                                const float* bn_scale, const float* bn_shift, int B, int N, int C, int k,
                                void* out_h, long ldo, int dtype, hipStream_t s);
+// Row-local chains of a Conformer block, 16 token rows per wave, registers only
+// (afx_conformer_fused.hip).  stage 0: x += 1/2 FF1(x), out2 = W_a LN2(x) (q|k|v, no bias);
+// stage 1: x += W_a in_h + b_a, out2 = W_b LN2(x) + b_b (pointwise conv 1, GLU input);
+// stage 2: x += W_a in_h + b_a, x += 1/2 FF(x), x_out = LN2(x) (post-norm).
+// float offsets inside a chain's parameter block (per-column vectors, 8 KB, zero-filled where unused):
+// FF LayerNorm gamma/beta, FF bias 1 (576) and 2, second LayerNorm gamma/beta, bias of W_a, bias of W_b (576)
+enum ChainParamOffsets { CP_FF_G = 0, CP_FF_B = 144, CP_FF_B1 = 288, CP_FF_B2 = 864, CP_LN2_G = 1008, CP_LN2_B = 1152,
+                         CP_BA = 1296, CP_BB = 1440 };
+constexpr int kChainParamFloats = 2048;
+struct ConfChainArgs {
+  int M, E, Ep, FFp;        // rows; emb (144); weight row strides of the K = E and K = 4E matrices
+  const float* x_in;        // (M, E) fp32 residual rows
+  float* x_out;
+  const float* params;      // the chain's parameter block (ChainParamOffsets)
+  const void *ff_w1, *ff_w2;                       // feed-forward module (stages 0 and 2): packed [4E][Ep], [E][FFp]
+  const void* w_a;                                 // stage 0: W_qkv [3E][Ep]; 1: W_out [E][Ep]; 2: W_pw2 [E][ld_w_a]
+  int ld_w_a;
+  const void* w_b;                                 // stage 1: W_pw1 [4E][Ep]
+  const void* in_h;                                // stage 1: attention output (M, ld_in_h); 2: depthwise-conv output
+  long ld_in_h;
+  float* out2;                                     // stage 0: q|k|v (M, 3E); 1: GLU input (M, 4E)
+  long ld_out2;
+};
+const char* launch_conf_chain(const ConfChainArgs& p, int stage, int dtype, hipStream_t s);
 // logits = fc5(token0):  x (B*N, E) fp32 rows, token row = b*N.
 const char* launch_small_linear(const float* x, long row_stride, int rows, int K, const float* w, const float* b,
                                 int N, float* out, hipStream_t s);
