@@ -125,6 +125,10 @@ int afx_k_rownorm(int dtype, const float* x, long ldx, int rows, int C, const fl
 int afx_k_mhsa(int dtype, const void* qkv, void* out, int B, int T, int H, void* stream);
 int afx_k_conf_attn(int dtype, const float* q, long ldq, const float* kv, long ldkv, const float* rel, int max_pos,
                     int B, int N, int H, int dh, void* out_h, long ldo, void* stream);
+/* the same on the matrix cores (operand-type q/k/E/P, fp32 accumulation): rel_h is the embedding table
+ * packed by afx_k_pack_linear with Kpad = 64; head dim 36, at most 209 tokens */
+int afx_k_conf_attn_mfma(int dtype, const float* q, long ldq, const float* kv, long ldkv, const void* rel_h, int max_pos,
+                         int B, int N, int H, int dh, void* out_h, long ldo, void* stream);
 int afx_k_conf_dwconv(int dtype, const float* x, long ldx, const float* w, const float* bias, const float* bn_scale,
                       const float* bn_shift, int B, int N, int C, int k, void* out_h, long ldo, void* stream);
 

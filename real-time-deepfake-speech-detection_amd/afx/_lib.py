@@ -58,6 +58,7 @@ SIGNATURES = {
     "afx_k_rownorm": (_I, [_I, _P, _L, _I, _I, _P, _P, _F, _I, _P, _L, _P, _L, _P]),
     "afx_k_mhsa": (_I, [_I, _P, _P, _I, _I, _I, _P]),
     "afx_k_conf_attn": (_I, [_I, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "afx_k_conf_attn_mfma": (_I, [_I, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "afx_k_conf_dwconv": (_I, [_I, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
     "afx_aasist_error": (C.c_char_p, []),
     "afx_k_gat": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),

@@ -90,6 +90,15 @@ def conf_attn(dtype, q, kv, rel, B, N, H, dh, max_pos=512):
     return out
 
 
+def conf_attn_mfma(dtype, q, kv, rel, B, N, H, dh, max_pos=512):
+    """Matrix-core form of conf_attn (head dim 36, N <= 209): the table is packed to (2*max_pos+1, 64) halfs first."""
+    rel_h = pack_linear(dtype, rel, 64)
+    out = torch.empty(B * N, H * dh, dtype=torch_dtype(dtype), device=q.device)
+    check(lib().afx_k_conf_attn_mfma(DTYPES[dtype], ptr(q), q.stride(0), ptr(kv), kv.stride(0), ptr(rel_h), max_pos, B, N,
+                                     H, dh, ptr(out), H * dh, stream_ptr()))
+    return out
+
+
 def conf_dwconv(dtype, x, w, bias, bn_scale, bn_shift, B, N, Cc, k):
     """x (B*N, 2*C) fp32 -> (B*N, C) half."""
     out = torch.empty(B * N, Cc, dtype=torch_dtype(dtype), device=x.device)

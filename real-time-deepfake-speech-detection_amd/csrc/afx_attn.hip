@@ -21,7 +21,7 @@ constexpr int ATT_KEYS = 224;       // padded key capacity (7 k-steps of 32)
 constexpr int ATT_VT_STRIDE = 232;  // halfs per V^T row: 464 B, conflict-free ds_read_b64
 
 template <class HT, int KS>  // KS = number of 32-key steps actually computed
-__global__ __launch_bounds__(256) void mhsa_kernel(const typename HT::T* __restrict__ qkv,
+__global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __restrict__ qkv,
                                                    typename HT::T* __restrict__ out, int T, int H, float scale) {
   typedef typename HT::T Tt;
   typedef typename HT::V8 V8;
@@ -65,18 +65,28 @@ __global__ __launch_bounds__(256) void mhsa_kernel(const typename HT::T* __restr
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const V8*)(base + (long)qrow * ld + ks * 32 + g * 8);
 
-    // S^T tiles: s[kt][r] = S[q0+ql][16kt + 4g + r]
+    // S^T tiles: s[kt][r] = S[q0+ql][16kt + 4g + r].  Two key tiles at a time (4 fragment reads in
+    // flight, then 4 MFMAs on two accumulators): the sched_barriers stop hipcc from hoisting all 28
+    // reads to the top, which cost 360 VGPRs and left one workgroup per CU.
     f32x4 s[NKT];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int krow = kt * 16 + ql;
-      const int sw = (krow >> 1) & 7;
+    for (int kp = 0; kp < NKT; kp += 2) {
+      V8 kf[2][2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const V8 kf = *(const V8*)(k_lds + krow * 128 + (((ks * 4 + g) ^ sw) * 16));
-        s[kt] = HT::mfma(kf, qf[ks], s[kt]);
+      for (int u = 0; u < 2; ++u) {
+        const int krow = (kp + u) * 16 + ql;
+        const int sw = (krow >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kf[u][ks] = *(const V8*)(k_lds + krow * 128 + (((ks * 4 + g) ^ sw) * 16));
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) s[kp + u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) s[kp + u] = HT::mfma(kf[u][ks], qf[ks], s[kp + u]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     float mx = -1e30f;
 #pragma unroll
@@ -113,19 +123,22 @@ __global__ __launch_bounds__(256) void mhsa_kernel(const typename HT::T* __restr
         pf[r] = (Tt)s[2 * s2][r];
         pf[4 + r] = (Tt)s[2 * s2 + 1][r];
       }
+      V8 vf[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const Tt* vr = vt_lds + (nt * 16 + ql) * ATT_VT_STRIDE + s2 * 32 + g * 4;
         const V4 lo = *(const V4*)vr;
         const V4 hi = *(const V4*)(vr + 16);
-        V8 vf;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          vf[r] = lo[r];
-          vf[4 + r] = hi[r];
+          vf[nt][r] = lo[r];
+          vf[nt][4 + r] = hi[r];
         }
-        o[nt] = HT::mfma(vf, pf, o[nt]);  // O^T = V^T P^T: the lane keeps ONE query row
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) o[nt] = HT::mfma(vf[nt], pf, o[nt]);  // O^T = V^T P^T: the lane keeps ONE query row
+      __builtin_amdgcn_sched_barrier(0);
     }
     // o[nt][r] = O[q0 + ql][16nt + 4g + r]: 4 consecutive head dims of the lane's own query row,
     // so the row's 1/sum is already local.  v_permlane16_swap pairs the two 16-column tiles

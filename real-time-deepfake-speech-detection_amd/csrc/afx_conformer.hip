@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void conf_attn_kernel(const float* __restrict_
                                                         const float* __restrict__ rel, int max_pos, int N, int H,
                                                         typename HT::T* __restrict__ out, long ldo) {
   typedef typename HT::T Tt;
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm_f[];
+  float* sm = sm_f;
   float* Ks = sm;                 // [N][DH]
   float* Vs = Ks + (long)N * DH;  // [N][DH]
   float* Es = Vs + (long)N * DH;  // [2N-1][DH]
@@ -173,6 +174,225 @@ const char* launch_conf_attn(const float* q, long ldq, const float* kv, long ldk
 }
 
 // ---------------------------------------------------------------------------------
+// The same attention on the matrix cores (operand type fp16 / bf16, fp32 accumulation), for
+// N <= 208 tokens and head dim <= 64.  One workgroup per (utterance, head); K (row-major,
+// XOR-swizzled 128-B rows, head dim zero-padded to 64) and V^T live in LDS as in mhsa_kernel;
+// a wave walks 16-query tiles:
+//   S1^T = K Q^T                       13 key tiles x 2 k-steps
+//   R^T  = E_win Q^T                   the relative term for ALL offsets the tile can see:
+//                                      rows r = i - j + N - 1 in [i0, i0 + N + 14], fragments of
+//                                      the fp16 embedding table straight from L2
+//   skew                               R goes through a per-wave LDS tile [16][228] fp32 and comes
+//                                      back as S2[i][j] = R[i][i - j + N - 1] (Transformer-XL's
+//                                      relative shift), conflict-free (row stride 229 words is odd)
+//   softmax, O^T = V^T P^T             as in mhsa_kernel; the lane keeps its query row throughout
+// The reference's (N, N, dh) relative tensor is never formed; 75 MFMAs replace ~24 k fp32 FMAs
+// per query tile.
+// ---------------------------------------------------------------------------------
+constexpr int CA_KEYS = 224, CA_VT_STRIDE = 232, CA_RS = 228, CA_NKT = 14, CA_KS = 7;
+
+template <class HT, int DH>
+__global__ __launch_bounds__(256) void conf_attn_mfma_kernel(const float* __restrict__ q, long ldq,
+                                                             const float* __restrict__ kv, long ldkv,
+                                                             const typename HT::T* __restrict__ rel_h, int max_pos,
+                                                             int N, int H, typename HT::T* __restrict__ out, long ldo) {
+  typedef typename HT::T Tt;
+  typedef typename HT::V8 V8;
+  typedef typename HT::V4 V4;
+  constexpr int DT = (DH + 15) / 16;  // 16-wide head-dim tiles of the output
+  static_assert(DH % 4 == 0 && DH <= 64, "head dim");
+  extern __shared__ __attribute__((aligned(16))) float sm_f[];
+  char* sm = (char*)sm_f;
+  char* k_lds = sm;                                        // [224][128 B]
+  Tt* vt_lds = (Tt*)(sm + CA_KEYS * 128);                  // [16 DT][232]
+  float* r_lds = (float*)(sm + CA_KEYS * 128 + 16 * DT * CA_VT_STRIDE * 2);  // [4 waves][16][228]
+
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int inner = H * DH;
+  // ---- stage K (fp16, swizzled, zero padded) and V^T ---------------------------------
+  for (int i = tid; i < (CA_KEYS * 128 + 16 * DT * CA_VT_STRIDE * 2) / 16; i += 256) ((u32x4*)sm)[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  for (int idx = tid; idx < N * (DH / 4); idx += 256) {
+    const int key = idx / (DH / 4), q4 = idx % (DH / 4);
+    const float* row = kv + ((long)b * N + key) * ldkv + h * DH + q4 * 4;
+    const f32x4 kk = *(const f32x4*)row;
+    const f32x4 vv = *(const f32x4*)(row + inner);
+    V4 kh;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kh[i] = (Tt)kk[i];
+    const int c = q4 >> 1;
+    *(V4*)(k_lds + key * 128 + ((c ^ ((key >> 1) & 7)) * 16) + (q4 & 1) * 8) = kh;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vt_lds[(q4 * 4 + i) * CA_VT_STRIDE + key] = (Tt)vv[i];
+  }
+  __syncthreads();
+
+  const int ql = lane & 15, g = lane >> 4;
+  const float scale = 1.0f / sqrtf((float)DH);
+  float* rw = r_lds + wave * 16 * CA_RS;
+  const int nqt = (N + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q0 = qt * 16;
+    int qrow = q0 + ql;
+    qrow = qrow < N ? qrow : N - 1;
+    // Q fragments (scaled, operand type): k-slot (g, j) of step ks <-> head dim 32 ks + 8 g + j
+    V8 qf[2];
+    {
+      const float* qp = q + ((long)b * N + qrow) * ldq + h * DH;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int d = ks * 32 + g * 8 + half * 4;
+          f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (d < DH) t = *(const f32x4*)(qp + d);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) qf[ks][half * 4 + i] = (Tt)(t[i] * scale);
+        }
+    }
+    // relative term for every offset this tile can see: r_local = r - q0, E row = r - (N-1) + max_pos
+#pragma unroll
+    for (int rp = 0; rp < CA_NKT; rp += 2) {
+      V8 ef[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        int er = q0 + (rp + u) * 16 + ql - (N - 1);
+        er = er < -max_pos ? -max_pos : (er > max_pos ? max_pos : er);
+        const Tt* ep = rel_h + (long)(er + max_pos) * 64 + g * 8;
+        ef[u][0] = *(const V8*)ep;
+        ef[u][1] = *(const V8*)(ep + 32);
+      }
+      f32x4 r2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) r2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) r2[u] = HT::mfma(ef[u][ks], qf[ks], r2[u]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) *(f32x4*)(rw + ql * CA_RS + (rp + u) * 16 + g * 4) = r2[u];
+    }
+    // S^T tiles: s[kt][c] = S1[q0+ql][16kt + 4g + c], two key tiles at a time
+    f32x4 s[CA_NKT];
+#pragma unroll
+    for (int kp = 0; kp < CA_NKT; kp += 2) {
+      V8 kf[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int krow = (kp + u) * 16 + ql;
+        const int sw = (krow >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kf[u][ks] = *(const V8*)(k_lds + krow * 128 + (((ks * 4 + g) ^ sw) * 16));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) s[kp + u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) s[kp + u] = HT::mfma(kf[u][ks], qf[ks], s[kp + u]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // add the shifted relative term, mask, softmax (the wave's own R tile: no barrier needed,
+    // LDS accesses of one wave complete in order)
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < CA_NKT; ++kt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int key = kt * 16 + g * 4 + c;
+        int rl = ql + (N - 1) - key;
+        rl = rl < 0 ? 0 : rl;
+        const float v = key < N ? s[kt][c] + rw[ql * CA_RS + rl] : -1e30f;
+        s[kt][c] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = rows_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < CA_NKT; ++kt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float e = __expf(s[kt][c] - mx);
+        s[kt][c] = e;
+        sum += e;
+      }
+    sum = rows_sum(sum);
+    const float rinv = 1.0f / sum;
+    // O = P V : k-slot (g, jj) of step s2 <-> key 32*s2 + 16*(jj>>2) + 4g + (jj&3)
+    f32x4 o[DT];
+#pragma unroll
+    for (int nt = 0; nt < DT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < CA_KS; ++s2) {
+      V8 pf;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        pf[c] = (Tt)s[2 * s2][c];
+        pf[4 + c] = (Tt)s[2 * s2 + 1][c];
+      }
+      V8 vf[DT];
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) {
+        const Tt* vr = vt_lds + (nt * 16 + ql) * CA_VT_STRIDE + s2 * 32 + g * 4;
+        const V4 lo = *(const V4*)vr;
+        const V4 hi = *(const V4*)(vr + 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          vf[nt][c] = lo[c];
+          vf[nt][4 + c] = hi[c];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) o[nt] = HT::mfma(vf[nt], pf, o[nt]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int qi = q0 + ql;
+    if (qi < N) {
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) {
+        const int d = nt * 16 + g * 4;
+        if (d < DH) {
+          V4 hv;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) hv[c] = (Tt)(o[nt][c] * rinv);
+          *(V4*)(out + ((long)b * N + qi) * ldo + h * DH + d) = hv;
+        }
+      }
+    }
+  }
+}
+
+const char* launch_conf_attn_mfma(const float* q, long ldq, const float* kv, long ldkv, const void* rel_h, int max_pos,
+                                  int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s) {
+  if (dh != 36) return "conf_attn_mfma: built for head dim 36 (emb 144 / 4 heads)";
+  if (N <= 0 || N + 15 > CA_KEYS) return "conf_attn_mfma: at most 209 tokens";
+  if (dtype == DT_FP32) return "conf_attn_mfma: half-precision operands only";
+  if ((ldq % 4) || (ldkv % 4) || (ldo % 4)) return "conf_attn_mfma: row strides must be multiples of 4";
+  constexpr int DT = 3;
+  const int lds = CA_KEYS * 128 + 16 * DT * CA_VT_STRIDE * 2 + 4 * 16 * CA_RS * 4;
+  hipError_t e = hipSuccess;
+  static int set[2] = {0, 0};
+  if (dtype == DT_BF16) {
+    if (!set[0]) e = hipFuncSetAttribute((const void*)conf_attn_mfma_kernel<BF16, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    set[0] = 1;
+    if (e == hipSuccess)
+      hipLaunchKernelGGL((conf_attn_mfma_kernel<BF16, 36>), dim3(H, B), dim3(256), lds, s, q, ldq, kv, ldkv, (const __bf16*)rel_h,
+                         max_pos, N, H, (__bf16*)out_h, ldo);
+  } else {
+    if (!set[1]) e = hipFuncSetAttribute((const void*)conf_attn_mfma_kernel<FP16, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    set[1] = 1;
+    if (e == hipSuccess)
+      hipLaunchKernelGGL((conf_attn_mfma_kernel<FP16, 36>), dim3(H, B), dim3(256), lds, s, q, ldq, kv, ldkv, (const _Float16*)rel_h,
+                         max_pos, N, H, (_Float16*)out_h, ldo);
+  }
+  if (e == hipSuccess) e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------
 // ConformerConvModule middle: GLU(channel) -> depthwise Conv1d(k, "same" pad
 // (k/2, k/2 - (k+1)%2)) -> BatchNorm1d (eval, folded to scale/shift) -> Swish.
 // One workgroup per (utterance, 32-channel slab): the gated activations for every
@@ -185,12 +405,14 @@ __global__ __launch_bounds__(256) void conf_dwconv_kernel(const float* __restric
                                                           const float* __restrict__ bn_shift, int N, int C, int k,
                                                           typename HT::T* __restrict__ out, long ldo) {
   typedef typename HT::T Tt;
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr bool EXACT = sizeof(Tt) == 4;  // fp32 "exact mode": accurate exp / division
+  constexpr int KMAX = 31, TB = 8;         // taps held in registers; outputs per register window
+  extern __shared__ __attribute__((aligned(16))) float sm_f[];
+  float* sm = sm_f;
   const int c0 = blockIdx.x * 32, b = blockIdx.y, tid = threadIdx.x;
   const int pl = k / 2;
-  const int rows = N + k - 1;
-  float* us = sm;              // [rows][32]
-  float* ws = sm + rows * 32;  // [k][32]
+  const int rows = N + KMAX - 1 + TB;  // zero rows behind the sequence let the last window read freely
+  float* us = sm;                      // [rows][32]: gated activations, row r <-> frame r - pl
   const int cl = tid & 31, tl = tid >> 5;
   const int c = c0 + cl;
   const bool cok = c < C;
@@ -199,25 +421,47 @@ __global__ __launch_bounds__(256) void conf_dwconv_kernel(const float* __restric
     float u = 0.f;
     if (cok && t >= 0 && t < N) {
       const float* row = x + ((long)b * N + t) * ldx;
-      u = row[c] * sigmoid_acc(row[C + c]);
+      u = row[c] * (EXACT ? sigmoid_acc(row[C + c]) : sigmoid_fast(row[C + c]));
     }
     us[r * 32 + cl] = u;
   }
-  for (int j = tl; j < k; j += 8) ws[j * 32 + cl] = cok ? w[(long)c * k + j] : 0.f;
+  // this channel's taps in registers (zero beyond k), BatchNorm folded to scale/shift
+  float wr[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) wr[j] = (cok && j < k) ? w[(long)c * k + j] : 0.f;
+  const float bi = cok ? bias[c] : 0.f, sc = cok ? bn_scale[c] : 0.f, sh = cok ? bn_shift[c] : 0.f;
   __syncthreads();
-  if (!cok) return;
-  const float bi = bias[c], sc = bn_scale[c], sh = bn_shift[c];
-  for (int t = tl; t < N; t += 8) {
-    float a = bi;
-    for (int j = 0; j < k; ++j) a = fmaf(ws[j * 32 + cl], us[(t + j) * 32 + cl], a);
-    out[((long)b * N + t) * ldo + c] = (Tt)swish(fmaf(a, sc, sh));
+  // each thread owns a contiguous run of frames and walks it TB outputs at a time: one window of
+  // TB + 30 inputs comes from LDS, the TB x 31 FMAs run from registers (the per-tap LDS reads of
+  // the first version, two per FMA, were what bounded this kernel)
+  const int per = (N + 7) / 8;
+  const int t_end = min(N, (tl + 1) * per);
+  for (int t0 = tl * per; t0 < t_end; t0 += TB) {
+    float win[TB + KMAX - 1];
+#pragma unroll
+    for (int i = 0; i < TB + KMAX - 1; ++i) win[i] = us[(t0 + i) * 32 + cl];
+    float acc[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) acc[u] = bi;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+#pragma unroll
+      for (int u = 0; u < TB; ++u) acc[u] = fmaf(wr[j], win[u + j], acc[u]);
+    if (cok) {
+#pragma unroll
+      for (int u = 0; u < TB; ++u) {
+        const float y = fmaf(acc[u], sc, sh);
+        if (t0 + u < t_end) out[((long)b * N + t0 + u) * ldo + c] = (Tt)(EXACT ? swish(y) : swish_fast(y));
+      }
+    }
   }
 }
 
 const char* launch_conf_dwconv(const float* x, long ldx, const float* w, const float* bias, const float* bn_scale,
                                const float* bn_shift, int B, int N, int C, int k, void* out_h, long ldo, int dtype,
                                hipStream_t s) {
-  const int lds = (N + k - 1 + k) * 32 * (int)sizeof(float);
+  if (k > 31) return "conf_dwconv: depthwise kernels up to 31 taps";
+  const int lds = (N + 31 - 1 + 8) * 32 * (int)sizeof(float);
   if (lds > 160 * 1024) return "conf_dwconv: sequence too long for the LDS slab";
   dim3 grid((C + 31) / 32, B);
   hipError_t e = hipSuccess;

@@ -92,6 +92,7 @@ struct TapRec {
 struct ConfBlock {
   void *ff1_w1, *ff1_w2, *ff2_w1, *ff2_w2, *wqkv, *wout, *pw1, *pw2;
   float *bn_scale, *bn_shift;
+  void* rel_h;          // rel_pos_emb in operand type, rows padded to 64 (matrix-core attention)
   float* chain_prm[3];  // per fused chain: the per-column vectors packed into one 8-KB block (ConfChainArgs::params)
 };
 
@@ -203,6 +204,7 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
       ok &= (B.bn_scale = (float*)e->dalloc((size_t)e->C2 * 4)) != nullptr;
       ok &= (B.bn_shift = (float*)e->dalloc((size_t)e->C2 * 4)) != nullptr;
       for (int st = 0; st < 3; ++st) ok &= (B.chain_prm[st] = (float*)e->dalloc(kChainParamFloats * 4)) != nullptr;
+      ok &= (B.rel_h = e->dalloc((size_t)1025 * 64 * e->hsz)) != nullptr;
     }
   }
   if (!ok) {
@@ -445,6 +447,7 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
         return fail("afx_finalize: depthwise kernel has %zu elements, expected %d x %d", dw.n, h->C2, h->ck);
       const FT& rp = h->f[B + "attn.fn.rel_pos_emb.weight"];
       if (rp.n != (size_t)1025 * h->dh) return fail("afx_finalize: rel_pos_emb must be (1025, %d)", h->dh);
+      KOK(launch_pack_linear(rp.p, 1025, h->dh, 64, h->blk[b].rel_h, h->dt, s));
       if (h->E == 144) {  // parameter blocks of the fused chains (layout: ChainParamOffsets in afx_kernels.h)
         auto put = [&](int st, int off, const std::string& name, int n) -> int {
           HIP_OK(hipMemcpyAsync(h->blk[b].chain_prm[st] + off, h->F(B + name), (size_t)n * 4, hipMemcpyDeviceToDevice, s));
@@ -629,6 +632,7 @@ struct Profiler {
 };
 static std::unordered_map<afx_engine*, Profiler> g_prof;
 static thread_local Profiler* t_prof = nullptr;
+static int g_conf_attn_mfma = 1;   // Conformer attention on the matrix cores (0: the fp32 VALU kernel)
 static int g_fuse_conformer = 1;  // Conformer block: row-local chains fused (afx_conformer_fused.hip); 0 = per-op path
 static int g_fuse_conv_ln = 1;  // conv layers 1-6: LayerNorm+GELU in the GEMM epilogue (A/B knob)
 static void prof_forget(afx_engine* e) {
@@ -866,6 +870,9 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     c.out2 = w.qkv32; c.ld_out2 = 3 * e->inner;
     KOK(timed(PC_CONF_CHAIN, ff_fl + 2.0 * M * E * 3 * e->inner, s, [&] { return launch_conf_chain(c, 0, dt, s); }));
     KOK(timed(PC_CONF_ATTN, 6.0 * B * e->heads * (double)N * N * e->dh, s, [&] {
+      if (g_conf_attn_mfma && dt != DT_FP32 && e->dh == 36 && N + 15 <= 224)
+        return launch_conf_attn_mfma(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner, K.rel_h, 512, B, N, e->heads,
+                                     e->dh, w.ao, Ep, dt, s);
       return launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
                               e->F(P + "attn.fn.rel_pos_emb.weight"), 512, B, N, e->heads, e->dh, w.ao, Ep, dt, s);
     }));
@@ -920,6 +927,9 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     q.out_f = w.qkv32; q.ldo_f = 3 * e->inner;
     KOK(launch_gemm(q, dt, 1, s));
     KOK(timed(PC_CONF_ATTN, 6.0 * B * e->heads * (double)N * N * e->dh, s, [&] {
+      if (g_conf_attn_mfma && dt != DT_FP32 && e->dh == 36 && N + 15 <= 224)
+        return launch_conf_attn_mfma(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner, K.rel_h, 512, B, N, e->heads,
+                                     e->dh, w.ao, Ep, dt, s);
       return launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
                               e->F(P + "attn.fn.rel_pos_emb.weight"), 512, B, N, e->heads, e->dh, w.ao, Ep, dt, s);
     }));
@@ -1123,6 +1133,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
     gemm_set_a_nt(value);
     return 0;
   }
+  if (!strcmp(key, "conf_attn_mfma")) {
+    g_conf_attn_mfma = value != 0;
+    return 0;
+  }
   if (!strcmp(key, "fuse_conformer")) {
     g_fuse_conformer = value != 0;
     return 0;
@@ -1149,6 +1163,10 @@ extern "C" int afx_k_mhsa(int dtype, const void* qkv, void* out, int B, int T, i
 extern "C" int afx_k_conf_attn(int dtype, const float* q, long ldq, const float* kv, long ldkv, const float* rel,
                                int max_pos, int B, int N, int H, int dh, void* out_h, long ldo, void* stream) {
   KRET(launch_conf_attn(q, ldq, kv, ldkv, rel, max_pos, B, N, H, dh, out_h, ldo, dtype, (hipStream_t)stream));
+}
+extern "C" int afx_k_conf_attn_mfma(int dtype, const float* q, long ldq, const float* kv, long ldkv, const void* rel_h,
+                                    int max_pos, int B, int N, int H, int dh, void* out_h, long ldo, void* stream) {
+  KRET(launch_conf_attn_mfma(q, ldq, kv, ldkv, rel_h, max_pos, B, N, H, dh, out_h, ldo, dtype, (hipStream_t)stream));
 }
 extern "C" int afx_k_conf_dwconv(int dtype, const float* x, long ldx, const float* w, const float* bias,
                                  const float* bn_scale, const float* bn_shift, int B, int N, int C, int k, void* out_h,

@@ -104,6 +104,10 @@ const char* launch_conf_tokens(const float* ll, const float* cls, float bn_scale
 // rel (2*max_pos+1, dh) fp32; out operand-type rows of stride ldo.
 const char* launch_conf_attn(const float* q, long ldq, const float* kv, long ldkv, const float* rel, int max_pos,
                              int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s);
+// the same on the matrix cores: rel_h is the embedding table in operand type, rows padded to 64
+// (pack_linear with Kpad = 64); N <= 209 tokens, head dim 36
+const char* launch_conf_attn_mfma(const float* q, long ldq, const float* kv, long ldkv, const void* rel_h, int max_pos,
+                                  int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s);
 // GLU -> depthwise conv (same pad) -> BatchNorm(eval) -> Swish.  x (B*N, 2*C) fp32.
 const char* launch_conf_dwconv(const float* x, long ldx, const float* w /*[C][k]*/, const float* bias,
                                const float* bn_scale, const float* bn_shift, int B, int N, int C, int k,

@@ -254,6 +254,31 @@ def test_conformer_relative_attention(K, N, H, dh):
     _close(got, ref, 2e-3, 2e-3)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("N", [200, 50, 209, 13])
+def test_conformer_relative_attention_on_matrix_cores(K, dtype, N):
+    """The MFMA form (S1 = K Q^T, R = E_win Q^T skewed through LDS, P V): against the fp32 definition
+    computed from the ROUNDED q, k, v, E (the kernel rounds them to the operand type)."""
+    B, H, dh = 2, 4, 36
+    g = torch.Generator().manual_seed(N)
+    rnd = lambda t: t.to(_td(dtype)).float()
+    q = torch.randn(B * N, H * dh, generator=g)
+    kv = torch.randn(B * N, 2 * H * dh, generator=g)
+    rel = torch.randn(1025, dh, generator=g)
+    got = K.conf_attn_mfma(dtype, q.cuda(), kv.cuda(), rel.cuda(), B, N, H, dh).float().cpu()
+    qq = rnd(q * dh ** -0.5).view(B, N, H, dh).transpose(1, 2)
+    kk = rnd(kv[:, : H * dh]).reshape(B, N, H, dh).transpose(1, 2)
+    vv = rnd(kv[:, H * dh:]).reshape(B, N, H, dh).transpose(1, 2)
+    seq = torch.arange(N)
+    dist = (seq[:, None] - seq[None, :]).clamp(-512, 512) + 512
+    dots = torch.einsum("bhid,bhjd->bhij", qq, kk) + torch.einsum("bhnd,nrd->bhnr", qq, rnd(rel)[dist])
+    ref = torch.einsum("bhij,bhjd->bhid", torch.softmax(dots, -1), vv).transpose(1, 2).reshape(B * N, H * dh)
+    _close(got, ref, _eps(dtype) * 6, _eps(dtype) * 6)
+    from afx._lib import AfxError
+    with pytest.raises(AfxError, match="209 tokens"):
+        K.conf_attn_mfma(dtype, torch.zeros(2 * 210, H * dh).cuda(), torch.zeros(2 * 210, 2 * H * dh).cuda(), rel.cuda(), 2, 210, H, dh)
+
+
 @pytest.mark.parametrize("k", [31, 16])
 def test_conformer_glu_depthwise_bn_swish(K, k):
     B, N, C = 2, 200, 288
