@@ -46,11 +46,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
     static_assert(BN % (16 * WC) == 0, "row-complete tile");
     __syncthreads();  // every wave is done reading the last K-tile: LDS becomes scratch
     float* red = (float*)smem;  // [WC][BM] partial row sums
+    // bias, gamma, beta of the BN columns: one global round trip for the whole workgroup, then LDS
+    // (fetched per use they were a dependent L2 round trip per column pair)
+    float* vec = red + WC * BM;  // [3][BN]
+    for (int t = tid; t < BN; t += 64 * WR * WC) {
+      vec[t] = p.bias[n0 + t];
+      vec[BN + t] = p.ln_gamma[n0 + t];
+      vec[2 * BN + t] = p.ln_beta[n0 + t];
+    }
+    __syncthreads();
     const int kq = lane >> 4;
     // v = acc + bias, kept in the accumulator registers
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const f32x4 b = *(const f32x4*)(p.bias + n0 + wc * WN + j * 16 + 4 * kq);
+      const f32x4 b = *(const f32x4*)(vec + wc * WN + j * 16 + 4 * kq);
 #pragma unroll
       for (int i = 0; i < MT; ++i) acc[i][j] += b;
     }
@@ -100,9 +109,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
     const int cbw = (kq & 1) * 16 + (kq >> 1) * 8;
 #pragma unroll
     for (int jp = 0; jp < NT / 2; ++jp) {
-      const int na = n0 + wc * WN + jp * 32 + 4 * kq, nb = na + 16;
-      const f32x4 ga0 = *(const f32x4*)(p.ln_gamma + na), be0 = *(const f32x4*)(p.ln_beta + na);
-      const f32x4 ga1 = *(const f32x4*)(p.ln_gamma + nb), be1 = *(const f32x4*)(p.ln_beta + nb);
+      const int ca = wc * WN + jp * 32 + 4 * kq, cbb = ca + 16;  // columns inside the tile
+      const f32x4 ga0 = *(const f32x4*)(vec + BN + ca), be0 = *(const f32x4*)(vec + 2 * BN + ca);
+      const f32x4 ga1 = *(const f32x4*)(vec + BN + cbb), be1 = *(const f32x4*)(vec + 2 * BN + cbb);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int m = m0 + wr * WM + i * 16 + (lane & 15);
@@ -163,22 +172,55 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
     // -> one 16-B store per lane (two for fp32), half the store instructions of the narrow
     // form; the store tail of these kernels is issue-bound (cdna guide T21).
     const int cb = (kq & 1) * 16 + (kq >> 1) * 8;  // column base of this lane inside a tile pair
+    // Every global load of the epilogue is issued ahead of its use: the bias vectors (they do not
+    // depend on the row) before the loop, the residual rows one (row tile, column pair) step ahead.
+    // Loaded at the point of use, each of the MT x NT/2 steps was a dependent L2 round trip --
+    // ~15 us per 256x256 tile, more than its K-loop at K = 512 (tools/bench_gemm_k.py).
+    f32x4 bia[NT / 2][2];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int jp = 0; jp < NT / 2; ++jp) {
+      const int na = n0 + wc * WN + jp * 32 + 4 * kq, nbb = na + 16;
+      bia[jp][0] = bia[jp][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        if (na < p.N) bia[jp][0] = *(const f32x4*)(p.bias + gcol + na);
+        if (nbb < p.N) bia[jp][1] = *(const f32x4*)(p.bias + gcol + nbb);
+      }
+    }
+    constexpr int STEPS = MT * (NT / 2);
+    const bool one_batch = p.rpb >= p.M;  // plain GEMM: no per-batch row remap, no integer divisions
+    auto row_of = [&](int i, long& orow, long& hrow, bool& mok) {
       const int m = m0 + wr * WM + i * 16 + (lane & 15);
-      const bool mok = m < p.M;
+      mok = m < p.M;
       const int mc = mok ? m : p.M - 1;
-      const long orow = (long)(mc / p.rpb) * p.o_batch_rows + (mc % p.rpb) + p.o_row_off;
-      const long hrow = (long)(mc / p.rpb) * p.oh_batch_rows + (mc % p.rpb) + p.oh_row_off;
+      const int bq = one_batch ? 0 : mc / p.rpb, br = one_batch ? mc : mc - bq * p.rpb;
+      orow = (long)bq * p.o_batch_rows + br + p.o_row_off;
+      hrow = (long)bq * p.oh_batch_rows + br + p.oh_row_off;
+    };
+    auto load_resid = [&](int step, f32x4 (&r)[2]) {
+      const int i = step / (NT / 2), jp = step % (NT / 2);
+      long orow, hrow;
+      bool mok;
+      row_of(i, orow, hrow, mok);
+      const int n = n0 + wc * WN + jp * 32 + cb;
+      r[0] = r[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (mok && n < p.N) {
+        const float* rp = p.resid + orow * p.ldr + gcol + n;
+        r[0] = *(const f32x4*)rp;
+        r[1] = *(const f32x4*)(rp + 4);
+      }
+    };
+    f32x4 rcur[2], rnxt[2];
+    if (p.resid) load_resid(0, rcur);
 #pragma unroll
-      for (int jp = 0; jp < NT / 2; ++jp) {
+    for (int step = 0; step < STEPS; ++step) {
+      const int i = step / (NT / 2), jp = step % (NT / 2);
+      if (p.resid && step + 1 < STEPS) load_resid(step + 1, rnxt);
+      long orow, hrow;
+      bool mok;
+      row_of(i, orow, hrow, mok);
+      {
         const int nb = n0 + wc * WN + jp * 32;  // first column of the tile pair
-        f32x4 va = acc[i][2 * jp], vb = acc[i][2 * jp + 1];
-        if (p.bias) {
-          const int na = nb + 4 * kq, nbb = na + 16;
-          if (na < p.N) va += *(const f32x4*)(p.bias + gcol + na);
-          if (nbb < p.N) vb += *(const f32x4*)(p.bias + gcol + nbb);
-        }
+        f32x4 va = acc[i][2 * jp] + bia[jp][0], vb = acc[i][2 * jp + 1] + bia[jp][1];
         if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
           const f32x2_t a0 = gelu_erf2(f32x2_t{va[0], va[1]}), a1 = gelu_erf2(f32x2_t{va[2], va[3]});
           const f32x2_t b0 = gelu_erf2(f32x2_t{vb[0], vb[1]}), b1 = gelu_erf2(f32x2_t{vb[2], vb[3]});
@@ -191,8 +233,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
             vb[r] = apply_act(vb[r], p.act);
           }
         }
-        va *= alpha;
-        vb *= alpha;
+        if (alpha != 1.f) {
+          va *= alpha;
+          vb *= alpha;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va[r]), __float_as_uint(vb[r]), false, false);
@@ -200,27 +244,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           vb[r] = __uint_as_float(sw[1]);
         }
         const int n = nb + cb;  // this lane now owns columns n .. n+7 (va | vb)
-        if (!mok || n >= p.N) continue;
-        if (p.resid) {
-          const float* rp = p.resid + orow * p.ldr + gcol + n;
-          va += *(const f32x4*)rp;
-          vb += *(const f32x4*)(rp + 4);
-        }
-        if (p.out_f) {
-          float* op = p.out_f + orow * p.ldo_f + gcol + n;
-          *(f32x4*)op = va;
-          *(f32x4*)(op + 4) = vb;
-        }
-        if (p.out_h) {
-          V8 h;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            h[r] = (T)va[r];
-            h[4 + r] = (T)vb[r];
+        if (p.dbg_nodma & 32) {  // timing only: no stores
+          asm volatile("" :: "v"(va), "v"(vb));
+        } else if (mok && n < p.N) {
+          if (p.resid) {
+            va += rcur[0];
+            vb += rcur[1];
           }
-          *(V8*)((T*)p.out_h + hrow * p.ldo_h + gcol + n) = h;
+          if (p.out_f) {
+            float* op = p.out_f + orow * p.ldo_f + gcol + n;
+            *(f32x4*)op = va;
+            *(f32x4*)(op + 4) = vb;
+          }
+          if (p.out_h) {
+            V8 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              h[r] = (T)va[r];
+              h[4 + r] = (T)vb[r];
+            }
+            *(V8*)((T*)p.out_h + hrow * p.ldo_h + gcol + n) = h;
+          }
         }
       }
+      rcur[0] = rnxt[0];
+      rcur[1] = rnxt[1];
     }
     return;
   }
@@ -483,11 +531,25 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int g = blockIdx.z;
-  int pm, pn;
-  {
-    const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
-    const int nwg = nM * nN;
-    int L = blockIdx.x;
+  const T* Ag = (const T*)p.A + (long)g * p.g_a;
+  const T* Wg = (const T*)p.W + (long)g * p.g_w;
+  const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
+  const int nwg = nM * nN;
+
+  // DMA source pointers.  Piece (i*8 + wave) of a half-tile is LDS rows 8(i*8+wave) .. +7,
+  // lane l -> row l>>3, 16-B slot l&7 holding logical chunk (l&7) ^ ((row>>1)&7).
+  // A half h, LDS row r: wave row r / (RA/2), row r % (RA/2) of that wave's half h;
+  // B half h, LDS row r: wave column r / (RB/4), column r % (RB/4) of that wave's half h.
+  const T* srcA[2][DA];
+  const T* srcB[2][DB];
+  int m0 = 0, n0 = 0;
+  // PERSISTENT: the grid is one workgroup per CU and a workgroup walks tiles v = blockIdx.x,
+  // + gridDim.x, ...  Workgroups are dealt round-robin over the 8 XCDs and gridDim.x is a
+  // multiple of 8, so v & 7 is the XCD for every tile of a workgroup and the remap below (a
+  // contiguous run of the logical tile order per XCD, GROUP_M super-tiles) holds as before.
+  auto setup = [&](int v) {
+    int pm, pn;
+    int L = v;
     if (p.map_mode >= 1) {
       const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
       L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
@@ -502,36 +564,28 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
       pm = L / nN;
       pn = L % nN;
     }
-  }
-  const int m0 = pm * BM, n0 = pn * BN;
-  const T* Ag = (const T*)p.A + (long)g * p.g_a;
-  const T* Wg = (const T*)p.W + (long)g * p.g_w;
-
-  // DMA source pointers.  Piece (i*8 + wave) of a half-tile is LDS rows 8(i*8+wave) .. +7,
-  // lane l -> row l>>3, 16-B slot l&7 holding logical chunk (l&7) ^ ((row>>1)&7).
-  // A half h, LDS row r: wave row r / (RA/2), row r % (RA/2) of that wave's half h;
-  // B half h, LDS row r: wave column r / (RB/4), column r % (RB/4) of that wave's half h.
-  const T* srcA[2][DA];
-  const T* srcB[2][DB];
+    m0 = pm * BM;
+    n0 = pn * BN;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int i = 0; i < DA; ++i) {
-      const int r = (i * 8 + wave) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((r >> 1) & 7);
-      int m = m0 + (r / (RA / 2)) * (BM / 2) + h * (RA / 2) + r % (RA / 2);
-      m = m < p.M ? m : p.M - 1;
-      srcA[h][i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
+      for (int i = 0; i < DA; ++i) {
+        const int r = (i * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int m = m0 + (r / (RA / 2)) * (BM / 2) + h * (RA / 2) + r % (RA / 2);
+        m = m < p.M ? m : p.M - 1;
+        srcA[h][i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
+      }
+#pragma unroll
+      for (int i = 0; i < DB; ++i) {
+        const int r = (i * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int n = n0 + (r / (RB / 4)) * (BN / 4) + h * (RB / 4) + r % (RB / 4);
+        n = n < p.N ? n : p.N - 1;
+        srcB[h][i] = Wg + (long)n * p.ldw + c * 8;
+      }
     }
-#pragma unroll
-    for (int i = 0; i < DB; ++i) {
-      const int r = (i * 8 + wave) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((r >> 1) & 7);
-      int n = n0 + (r / (RB / 4)) * (BN / 4) + h * (RB / 4) + r % (RB / 4);
-      n = n < p.N ? n : p.N - 1;
-      srcB[h][i] = Wg + (long)n * p.ldw + c * 8;
-    }
-  }
+  };
   const unsigned lds_base = (unsigned)(size_t)smem;
   auto dma16 = [&](const T* src, unsigned lds_off) {
     unsigned keep;
@@ -555,10 +609,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   const char* bR = smem + (wc * (RB / 4) + frow) * 128;
 
   f32x4 acc[2 * MTH][2 * NTH];
-#pragma unroll
-  for (int i = 0; i < 2 * MTH; ++i)
-#pragma unroll
-    for (int j = 0; j < 2 * NTH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // the resident operand keeps both halves in registers, the flowing one a single half
   V8 af[WIDE ? 2 : 1][MTH][2], wf[WIDE ? 1 : 2][NTH][2];
 
@@ -604,21 +654,18 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   } while (0)
 
   const int nk = p.K >> 6;
-  // prologue: all of tile 0 and three half-tiles of tile 1 in flight; tile 0 landed
-  stageR(0, 0, 0);
-  stageF(0, 0, 0);
-  stageR(1, 0, 0);
-  stageF(1, 0, 0);
-  if (nk > 1) {
-    stageR(0, 1, 1);
-    stageF(0, 1, 1);
-    stageR(1, 1, 1);
-    wait_vmcnt<6>();
-  } else {
-    wait_vmcnt<0>();
-  }
-  AFX_BAR();
-  if (wr == 1) AFX_BAR();  // the second wave row runs one barrier behind the first
+  // prologue of an output tile: all of K-tile 0 and three half-tiles of K-tile 1 go out
+  auto issue_prologue = [&] {
+    stageR(0, 0, 0);
+    stageF(0, 0, 0);
+    stageR(1, 0, 0);
+    stageF(1, 0, 0);
+    if (nk > 1) {
+      stageR(0, 1, 1);
+      stageF(0, 1, 1);
+      stageR(1, 1, 1);
+    }
+  };
 
   auto ktile = [&](auto bufc, int t) {
     constexpr int b = decltype(bufc)::value;
@@ -661,14 +708,50 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     quadFR(1, 0);
     AFX_BAR();
   };
-  for (int t = 0; t < nk; t += 2) {
-    ktile(std::integral_constant<int, 0>{}, t);
-    if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
+  int v = blockIdx.x;
+  setup(v);
+  issue_prologue();
+  bool first = true;
+  for (;;) {
+    // K-tile 0 has landed.  For the first output tile that is the counted wait of the template;
+    // for later ones the epilogue stores of the previous tile were issued BEHIND these DMAs and
+    // vmcnt retires in order, so the wait is vmcnt(0) (the stores were issued all through the
+    // epilogue and are mostly acknowledged by now).
+    if (first && nk > 1) wait_vmcnt<6>();
+    else wait_vmcnt<0>();
+    first = false;
+    AFX_BAR();
+    if (wr == 1) AFX_BAR();  // the second wave row runs one barrier behind the first
+#pragma unroll
+    for (int i = 0; i < 2 * MTH; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * NTH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nk; t += 2) {
+      ktile(std::integral_constant<int, 0>{}, t);
+      if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (wr == 0) AFX_BAR();  // both wave rows are done with every LDS read of this output tile
+    // The operand DMA of the NEXT output tile goes out before this tile's epilogue: its latency
+    // and the first K-tile's fill hide behind the bias / activation / store work.  (The row-
+    // LayerNorm epilogue keeps its scratch in the one half-tile the prologue does not write.)
+    const int m0c = m0, n0c = n0;
+    const int vn = v + gridDim.x;
+    if (vn < nwg) {
+      setup(vn);
+      issue_prologue();
+    }
+    if (p.dbg_nodma & 64) {  // timing only: no epilogue at all
+#pragma unroll
+      for (int i = 0; i < 2 * MTH; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * NTH; ++j) asm volatile("" :: "v"(acc[i][j]));
+    } else {
+      gemm_epilogue<HT, BM, BN, 2, 4, ROWLN>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
+    }
+    if (vn >= nwg) break;
+    v = vn;
   }
-  if (wr == 0) AFX_BAR();
 #undef AFX_BAR
-
-  gemm_epilogue<HT, BM, BN, 2, 4, ROWLN>(p, acc, smem, m0, n0, g);
 }
 
 template <class HT, int BM, int BN, bool ROWLN>
@@ -682,7 +765,16 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    n_cu = prop.multiProcessorCount & ~7;  // a multiple of the 8 XCDs (the tile remap relies on it)
+    if (n_cu < 8) n_cu = 8;
+  }
+  const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+  dim3 grid(tiles < n_cu ? tiles : n_cu, 1, groups);  // persistent: at most one workgroup per CU
   hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN>), grid, dim3(512), lds, s, p);
   return hipGetLastError();
 }
