@@ -120,6 +120,11 @@ int afx_k_conv0(int dtype, const float* wave, int B, int L, const float* w, cons
                 const float* beta, int pre_emph, float coef, void* out_h, void* stream);
 /* data/preprocess.py:16-29 as a stand-alone op: y[t] = x[t] - coef*x[t-1], reflect pad */
 int afx_k_pre_emphasis(const float* x, int B, int L, float coef, float* y, void* stream);
+/* Utterance length policy, batched (data/test_set.py:139-146 pad, :201-227 adjustDuration, :229-248
+ * adjustDuration_random_start): x = the ragged clips packed back to back (device), offs[B+1] their sample
+ * offsets (device, int64), starts[B] crop starts or NULL; out (B, duration): out[b][i] = x_b[(start_b + i) mod n_b]. */
+int afx_k_tile_crop(const float* x, const long long* offs, const long long* starts, int B, int duration, float* out,
+                    void* stream);
 int afx_k_rownorm(int dtype, const float* x, long ldx, int rows, int C, const float* gamma, const float* beta,
                   float eps, int act, float* out_f, long ldo_f, void* out_h, long ldo_h, void* stream);
 int afx_k_mhsa(int dtype, const void* qkv, void* out, int B, int T, int H, void* stream);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "afx_k_pack_conv": (_I, [_I, _P, _I, _I, _I, _P, _P]),
     "afx_k_conv0": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "afx_k_pre_emphasis": (_I, [_P, _I, _I, _F, _P, _P]),
+    "afx_k_tile_crop": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "afx_k_rownorm": (_I, [_I, _P, _L, _I, _I, _P, _P, _F, _I, _P, _L, _P, _L, _P]),
     "afx_k_mhsa": (_I, [_I, _P, _P, _I, _I, _I, _P]),
     "afx_k_conf_attn": (_I, [_I, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P, _L, _P]),

@@ -65,6 +65,30 @@ def adjust_duration(x, duration):
     return x[:duration]
 
 
+def batch_adjust_duration(clips, duration, starts=None, device="cuda"):
+    """The same policy for a whole ragged batch as ONE device op: ``clips`` is a list of 1-D waveforms
+    of any lengths, the result a (B, duration) fp32 batch on the GPU.  ``starts`` (optional, one per
+    clip) are the crop starts of data/test_set.py:229-248 for clips longer than ``duration``."""
+    import ctypes as C
+
+    from ._lib import check, lib, ptr, stream_ptr
+    lens = [int(c.numel()) for c in clips]
+    if not clips or min(lens) <= 0:
+        raise ValueError("every clip needs at least one sample")
+    offs = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int64)
+    packed = torch.cat([c.reshape(-1).to(torch.float32) for c in clips]).to(device)
+    offs_d = offs.to(device)
+    st = None
+    if starts is not None:
+        for s0, n in zip(starts, lens):
+            if s0 < 0 or (n >= duration and s0 > n - duration) or (n < duration and s0 != 0):
+                raise ValueError("crop start outside the clip")
+        st = torch.tensor(list(starts), dtype=torch.int64, device=device)
+    out = torch.empty(len(clips), duration, dtype=torch.float32, device=device)
+    check(lib().afx_k_tile_crop(ptr(packed), ptr(offs_d), ptr(st), len(clips), duration, ptr(out), stream_ptr()))
+    return out
+
+
 def calculate_EER(scores, labels):
     """trainer.py:134-139."""
     from scipy.interpolate import interp1d

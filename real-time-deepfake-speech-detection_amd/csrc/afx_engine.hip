@@ -1133,6 +1133,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
     gemm_set_a_nt(value);
     return 0;
   }
+  if (!strcmp(key, "conv0_mfma")) {
+    conv0_set_mfma(value);
+    return 0;
+  }
   if (!strcmp(key, "conf_attn_mfma")) {
     g_conf_attn_mfma = value != 0;
     return 0;
@@ -1149,6 +1153,11 @@ extern "C" int afx_debug_set(const char* key, int value) {
 }
 extern "C" int afx_k_pre_emphasis(const float* x, int B, int L, float coef, float* y, void* stream) {
   KRET(launch_pre_emphasis(x, B, L, coef, y, (hipStream_t)stream));
+}
+extern "C" int afx_k_tile_crop(const float* x, const long long* offs, const long long* starts, int B, int duration,
+                               float* out, void* stream) {
+  if (!x || !offs || !out) return fail("afx_k_tile_crop: null argument");
+  KRET(launch_tile_crop(x, offs, starts, B, duration, out, (hipStream_t)stream));
 }
 extern "C" int afx_k_rownorm(int dtype, const float* x, long ldx, int rows, int C, const float* gamma,
                              const float* beta, float eps, int act, float* out_f, long ldo_f, void* out_h, long ldo_h,

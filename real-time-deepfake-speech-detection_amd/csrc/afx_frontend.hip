@@ -16,6 +16,7 @@ namespace afx {
 // (data/preprocess.py:16-29) is applied while the waveform window is staged in LDS.
 // ---------------------------------------------------------------------------------
 constexpr int C0_FB = 64;  // frames per workgroup
+static int g_conv0_mfma = 1;  // A/B knob: matrix-core form of conv layer 0 (0: the VALU form below)
 
 template <class HT>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wave, int L, int T0,
@@ -87,16 +88,142 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
   }
 }
 
+// The same layer with the 10-tap products on the fp32 matrix instruction (exact fp32, like the VALU
+// form above): out^T tile = W (16 channels x 12 taps, zero padded) . frames (12 x 16), three
+// v_mfma_f32_16x16x4_f32 per 16-channel tile.  A lane then holds 4 consecutive channels x 32 tiles
+// of ONE frame: the LayerNorm statistics are a 4-lane reduction per 16 frames (not a 64-lane one per
+// frame), and only LayerNorm + GELU + convert remain on the VALU: ~80 instructions per frame instead
+// of ~185.  Workgroup = 256 frames (4 waves x 4 groups of 16); weights (24 KB, tap-padded) and the
+// waveform window live in LDS.
+#ifndef CONV0_DBG
+#define CONV0_DBG 0  // timing experiments only (wrong results): 1 no GELU, 2 no stores, 4 no MFMA, 8 no LayerNorm statistics
+#endif
+constexpr int C0M_FB = 256;
+template <class HT>
+__global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restrict__ wave, int L, int T0,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int pre_emph, float pre_coef, typename HT::T* __restrict__ out) {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+  __shared__ float xs[C0M_FB * 5 + 16];
+  __shared__ float ws[3 * 32 * 64];      // [k-step][channel tile][lane]: the lane's A-operand value
+  __shared__ float pv[3 * 512];          // bias | gamma | beta
+  const int b = blockIdx.y, f0 = blockIdx.x * C0M_FB;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* x = wave + (long)b * L;
+  const int s0 = f0 * 5;
+  for (int i = tid; i < C0M_FB * 5 + 16; i += 256) {
+    const int gidx = s0 + i;
+    float v = 0.f;
+    if (gidx < L) {
+      v = x[gidx];
+      if (pre_emph) {
+        const int gp = gidx > 0 ? gidx - 1 : 1;  // reflect pad of one sample on the left
+        v -= pre_coef * x[gp];
+      }
+    }
+    xs[i] = v;
+  }
+  for (int i = tid; i < 3 * 32 * 64; i += 256) {
+    const int s = i / 2048, ct = (i >> 6) & 31, l = i & 63;
+    const int tap = 4 * s + (l >> 4);
+    ws[i] = tap < 10 ? w[(ct * 16 + (l & 15)) * 10 + tap] : 0.f;
+  }
+  for (int i = tid; i < 512; i += 256) {
+    pv[i] = bias[i];
+    pv[512 + i] = gamma[i];
+    pv[1024 + i] = beta[i];
+  }
+  __syncthreads();
+  const int fr = lane & 15, kq = lane >> 4;
+  for (int grp = 0; grp < 4; ++grp) {
+    const int fl = (wv * 4 + grp) * 16;  // first frame of this group inside the workgroup
+    if (f0 + fl >= T0) break;
+    float bx[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) bx[s] = xs[(fl + fr) * 5 + 4 * s + kq];
+    f32x4 acc[32];
+#pragma unroll
+    for (int ct = 0; ct < 32; ++ct) {
+      f32x4 c = *(const f32x4*)(pv + ct * 16 + kq * 4);  // bias: the accumulator's own channels
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        if constexpr ((CONV0_DBG & 4) != 0) c[0] += ws[(s * 32 + ct) * 64 + lane] * bx[s];
+        else c = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[(s * 32 + ct) * 64 + lane], bx[s], c, 0, 0, 0);
+      }
+      acc[ct] = c;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 32; ++ct) sum += (acc[ct][0] + acc[ct][1]) + (acc[ct][2] + acc[ct][3]);
+    const float mean = rows_sum(sum) * (1.0f / 512.0f);
+    float sq = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 32; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[ct][r] -= mean;
+        sq = fmaf(acc[ct][r], acc[ct][r], sq);
+      }
+    const float rstd = 1.0f / sqrtf(rows_sum(sq) * (1.0f / 512.0f) + 1e-5f);
+    const int f = f0 + fl + fr;
+    T* orow = out + ((long)b * T0 + (f < T0 ? f : T0 - 1)) * 512;
+    const int cb = (kq & 1) * 16 + (kq >> 1) * 8;
+#pragma unroll
+    for (int cp = 0; cp < 16; ++cp) {  // channel-tile pairs -> 8 consecutive channels per lane
+      f32x4 va, vb;
+      {
+        const f32x4 g0 = *(const f32x4*)(pv + 512 + cp * 32 + kq * 4), b0 = *(const f32x4*)(pv + 1024 + cp * 32 + kq * 4);
+        const f32x4 g1 = *(const f32x4*)(pv + 512 + cp * 32 + 16 + kq * 4), b1 = *(const f32x4*)(pv + 1024 + cp * 32 + 16 + kq * 4);
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2_t ya = gelu_erf2(f32x2_t{fmaf(acc[2 * cp][r] * rstd, g0[r], b0[r]), fmaf(acc[2 * cp][r + 1] * rstd, g0[r + 1], b0[r + 1])});
+          const f32x2_t yb = gelu_erf2(f32x2_t{fmaf(acc[2 * cp + 1][r] * rstd, g1[r], b1[r]), fmaf(acc[2 * cp + 1][r + 1] * rstd, g1[r + 1], b1[r + 1])});
+          if constexpr ((CONV0_DBG & 1) != 0) {
+            va[r] = acc[2 * cp][r] * rstd; va[r + 1] = acc[2 * cp][r + 1] * rstd;
+            vb[r] = acc[2 * cp + 1][r] * rstd; vb[r + 1] = acc[2 * cp + 1][r + 1] * rstd;
+          } else {
+            va[r] = ya[0]; va[r + 1] = ya[1];
+            vb[r] = yb[0]; vb[r + 1] = yb[1];
+          }
+        }
+      }
+      V8 h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va[r]), __float_as_uint(vb[r]), false, false);
+        h[r] = (T)__uint_as_float(sw[0]);
+        h[4 + r] = (T)__uint_as_float(sw[1]);
+      }
+      if constexpr ((CONV0_DBG & 2) != 0) asm volatile("" :: "v"(h));
+      else if (f < T0) *(V8*)(orow + cp * 32 + cb) = h;
+    }
+  }
+}
+
 const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w, const float* bias,
                          const float* gamma, const float* beta, int pre_emph, float pre_coef, void* out_h,
                          int dtype, hipStream_t s) {
   if (B <= 0 || L < 10 || T0 != (L - 10) / 5 + 1) return "conv0: bad shape";
+  if (dtype != DT_FP32 && g_conv0_mfma) {
+    dim3 grid((T0 + C0M_FB - 1) / C0M_FB, B);
+    if (dtype == DT_BF16)
+      hipLaunchKernelGGL(conv0_mfma_kernel<BF16>, grid, dim3(256), 0, s, wave, L, T0, w, bias, gamma, beta, pre_emph,
+                         pre_coef, (__bf16*)out_h);
+    else
+      hipLaunchKernelGGL(conv0_mfma_kernel<FP16>, grid, dim3(256), 0, s, wave, L, T0, w, bias, gamma, beta, pre_emph,
+                         pre_coef, (_Float16*)out_h);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+  }
   dim3 grid((T0 + C0_FB - 1) / C0_FB, B);
   AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL(conv0_kernel<HT>, grid, dim3(256), 0, s, wave, L, T0, w, bias, gamma, beta,
                                             pre_emph, pre_coef, (HT::T*)out_h));
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
+void conv0_set_mfma(int v) { g_conv0_mfma = v != 0; }
 
 // ---------------------------------------------------------------------------------
 // Stand-alone pre-emphasis (data/preprocess.py:16-29) for callers that apply it as a
@@ -112,6 +239,31 @@ __global__ void pre_emphasis_kernel(const float* __restrict__ x, int L, float co
 const char* launch_pre_emphasis(const float* x, int B, int L, float coef, float* y, hipStream_t s) {
   if (B <= 0 || L <= 0) return "pre_emphasis: empty input";
   hipLaunchKernelGGL(pre_emphasis_kernel, dim3(min((L + 255) / 256, 1024), B), dim3(256), 0, s, x, L, coef, y);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------
+// Utterance length policy as one batched device op (data/test_set.py:139-146 `pad`,
+// :201-227 `adjustDuration`, :229-248 `adjustDuration_random_start`): all three are
+//     out[b][i] = x_b[(start_b + i) mod n_b],   i < duration
+// (a short clip is repeated whole plus a residue, a long one is cropped from start_b; start_b = 0
+// for the first-N policies).  x is the ragged batch packed back to back, offs[b] .. offs[b+1] its
+// sample range.
+// ---------------------------------------------------------------------------------
+__global__ void tile_crop_kernel(const float* __restrict__ x, const long long* __restrict__ offs,
+                                 const long long* __restrict__ starts, int duration, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const long long o = offs[b], n = offs[b + 1] - o;
+  long long p = starts ? starts[b] : 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < duration; i += gridDim.x * blockDim.x)
+    out[(long)b * duration + i] = x[o + (p + i) % n];
+}
+const char* launch_tile_crop(const float* x, const long long* offs, const long long* starts, int B, int duration,
+                             float* out, hipStream_t s) {
+  if (B <= 0 || duration <= 0) return "tile_crop: empty batch";
+  hipLaunchKernelGGL(tile_crop_kernel, dim3(min((duration + 255) / 256, 256), B), dim3(256), 0, s, x, offs, starts,
+                     duration, out);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -63,6 +63,10 @@ void gemm_set_nodma(int v);     // timing-only knob: compute phase without opera
 const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w /*[512][10]*/,
                          const float* bias, const float* gamma, const float* beta, int pre_emph,
                          float pre_coef, void* out_h, int dtype, hipStream_t s);
+// ragged batch (packed, offs[B+1]) -> (B, duration): out[b][i] = x_b[(start_b + i) mod n_b]; starts may be null
+const char* launch_tile_crop(const float* x, const long long* offs, const long long* starts, int B, int duration,
+                             float* out, hipStream_t s);
+void conv0_set_mfma(int v);  // A/B knob: 1 (default) = fp32 matrix-core form, 0 = VALU form
 // y[t] = x[t] - coef * x[t-1] with a reflect pad on the left; (B,L) fp32 -> (B,L) fp32
 const char* launch_pre_emphasis(const float* x, int B, int L, float coef, float* y, hipStream_t s);
 // rows x C fp32 -> LayerNorm (optional activation) -> fp32 and/or operand-type outputs.

@@ -201,3 +201,26 @@ def test_eer_of_the_build_matches_the_oracle(afx_mod):
     print(f"EER oracle {eer_ref:.4f} %  build {eer_got:.4f} %  max|dscore| {(got - ref).abs().max().item():.2e}")
     assert 5.0 < eer_ref < 35.0
     assert abs(eer_got - eer_ref) < 0.005
+
+
+def test_length_policy_as_one_batched_device_op(afx_mod):
+    """pad-by-tiling, first-N crop and random-start crop for a ragged batch in one
+    kernel, against the reference policies restated in oracle/pre.py (data/test_set.py:139-248)."""
+    import numpy as np
+    from afx import harness
+    from oracle import pre
+    g = torch.Generator().manual_seed(3)
+    lens = [1, 7, 3999, 16000, 16001, 40000]
+    clips = [torch.randn(n, generator=g) for n in lens]
+    D = 16000
+    got = harness.batch_adjust_duration(clips, D).cpu()
+    for b, c in enumerate(clips):
+        assert torch.equal(got[b], pre.adjust_duration(c, D))
+        assert np.array_equal(got[b].numpy(), pre.pad_tile(c.numpy(), D))
+    starts = [0, 0, 0, 0, 1, 12345]
+    got = harness.batch_adjust_duration(clips, D, starts=starts).cpu()
+    for b, (c, s0) in enumerate(zip(clips, starts)):
+        ref = pre.adjust_duration(c, D) if c.numel() < D else c[s0:s0 + D]
+        assert torch.equal(got[b], ref)
+    with pytest.raises(ValueError):
+        harness.batch_adjust_duration(clips, D, starts=[0, 0, 0, 1, 0, 0])

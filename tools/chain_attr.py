@@ -16,5 +16,5 @@ for _ in range(3):
 eng.profile_begin()
 for _ in range(10):
     eng.forward(wave)
-c = eng.profile_end()["conf_chain_kernel"]
-print(f"{os.environ.get('AFX_LIB', 'default')[-18:]:20s} {c['ms'] / c['launches'] * 1e3:7.1f} us per chain launch", flush=True)
+c = eng.profile_end()[os.environ.get("AFX_CLASS", "conf_chain_kernel")]
+print(f"{os.environ.get('AFX_LIB', 'default')[-18:]:20s} {c['ms'] / c['launches'] * 1e3:7.1f} us per launch", flush=True)

@@ -35,8 +35,8 @@ __global__ __launch_bounds__(512) void k(char* out, long row_bytes, int rows_per
   }
 }
 
-int main() {
-  const int M = 12736 / 256 * 256, N = 4096;  // fp16 output of the fc1 shape, whole tiles
+int main(int argc, char** argv) {
+  const int M = (argc > 1 ? atoi(argv[1]) : 12736) / 256 * 256, N = 4096;  // fp16 output of the fc1 shape, whole tiles
   const long row_bytes = (long)N * 2, bytes = (long)M * row_bytes;
   char* d;
   hipMalloc(&d, bytes);
