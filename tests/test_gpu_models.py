@@ -224,3 +224,26 @@ def test_length_policy_as_one_batched_device_op(afx_mod):
         assert torch.equal(got[b], ref)
     with pytest.raises(ValueError):
         harness.batch_adjust_duration(clips, D, starts=[0, 0, 0, 1, 0, 0])
+
+
+def test_streaming_scores_equal_the_reference_on_every_window(afx_mod):
+    """BASELINE config 5 semantics (afx/streaming.py): every hop, each stream's score is the model's
+    score of the last `window` samples (history repeated while it is shorter) -- checked against the
+    CPU oracle at every hop, across the ring wrap-around."""
+    engine, synth = afx_mod
+    from afx.streaming import SlidingWindowScorer
+    from oracle import models, pre
+    sd = synth.model_state_dict("ConformerModel", n_layers=1, n_encoders=1)
+    eng = engine.Engine("conformer", n_layers=1, dtype="fp16", conf_blocks=1)
+    eng.load_state_dict(sd)
+    S, W, H = 3, 16000, 4000
+    sc = SlidingWindowScorer(eng, S, window=W, hop=H)
+    stream = synth.waveforms(S, 9 * H, batch_idx=77)
+    for step in range(9):
+        got = sc.push(stream[:, step * H:(step + 1) * H].cuda()).cpu()
+        hist = stream[:, : (step + 1) * H]
+        win = torch.stack([pre.adjust_duration(hist[s], W) if hist.shape[1] < W else hist[s, -W:] for s in range(S)])
+        ref = models.conformer_forward(sd, win)[:, 1]
+        assert (got - ref).abs().max().item() <= SCORE_TOL, f"hop {step}"
+    with pytest.raises(ValueError):
+        sc.push(torch.zeros(S, H))
