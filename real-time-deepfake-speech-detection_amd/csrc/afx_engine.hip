@@ -847,13 +847,16 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     return launch_conf_tokens(w.ll32, e->F("conformer.class_token"), e->conf_bn_scale, e->conf_bn_shift, B, T, E, w.xc, s);
   }));
   if (tap(e, "tokens", w.xc, (size_t)M * E, false, s)) return 1;
-  // K-padding columns of the operand buffers must read as zero
+  // K-padding columns of the operand buffers must read as zero (the fused chains only read past
+  // the real columns of the attention output: 144 -> 160)
   const size_t hs = dtype_size(dt);
-  HIP_OK(hipMemsetAsync(w.hc, 0, (size_t)M * Ep * hs, s));
-  HIP_OK(hipMemsetAsync(w.ao, 0, (size_t)M * Ep * hs, s));
-  HIP_OK(hipMemsetAsync(w.u, 0, (size_t)M * e->C2p * hs, s));
-  if (e->FFp != e->FF) HIP_OK(hipMemsetAsync(w.hid, 0, (size_t)M * e->FFp * hs, s));
   const bool fused = g_fuse_conformer && dt != DT_FP32 && E == 144 && e->inner == E && e->FFp == 4 * E;
+  HIP_OK(hipMemsetAsync(w.ao, 0, (size_t)M * Ep * hs, s));
+  if (!fused) {
+    HIP_OK(hipMemsetAsync(w.hc, 0, (size_t)M * Ep * hs, s));
+    HIP_OK(hipMemsetAsync(w.u, 0, (size_t)M * e->C2p * hs, s));
+    if (e->FFp != e->FF) HIP_OK(hipMemsetAsync(w.hid, 0, (size_t)M * e->FFp * hs, s));
+  }
   for (int b = 0; fused && b < e->nblk; ++b) {
     // three register-resident row chains around the attention and the depthwise conv
     const std::string P = "conformer.encoder_blocks." + std::to_string(b) + ".";
