@@ -39,31 +39,48 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
   const Tt* vbase = base + 2L * H * 64;
 
   // ---- stage K (swizzled rows) and V^T ------------------------------------------
-  for (int idx = tid; idx < KEYS * 8; idx += 256) {
-    const int key = idx >> 3, c = idx & 7;
-    u32x4 kv = u32x4{0u, 0u, 0u, 0u};
-    V8 vv;
+  // all global loads of the thread first, then the LDS writes: issued one (load, wait, write) step at a
+  // time the staging was 7 dependent L2 round trips and most of this kernel's time
+  {
+    constexpr int IT = KEYS * 8 / 256;
+    static_assert(KEYS * 8 % 256 == 0, "staging loop shape");
+    u32x4 kreg[IT];
+    V8 vreg[IT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) vv[i] = (Tt)0.f;
-    if (key < T) {
-      kv = *(const u32x4*)(kbase + (long)key * ld + c * 8);
-      vv = *(const V8*)(vbase + (long)key * ld + c * 8);
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * 256, key = idx >> 3, c = idx & 7;
+      kreg[it] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) vreg[it][i] = (Tt)0.f;
+      if (key < T) {
+        kreg[it] = *(const u32x4*)(kbase + (long)key * ld + c * 8);
+        vreg[it] = *(const V8*)(vbase + (long)key * ld + c * 8);
+      }
     }
-    *(u32x4*)(k_lds + key * 128 + ((c ^ ((key >> 1) & 7)) * 16)) = kv;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) vt_lds[(c * 8 + i) * ATT_VT_STRIDE + key] = vv[i];
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * 256, key = idx >> 3, c = idx & 7;
+      *(u32x4*)(k_lds + key * 128 + ((c ^ ((key >> 1) & 7)) * 16)) = kreg[it];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) vt_lds[(c * 8 + i) * ATT_VT_STRIDE + key] = vreg[it][i];
+    }
   }
   __syncthreads();
 
   const int ql = lane & 15, g = lane >> 4;
   const int nqt = (T + 15) >> 4;
+  auto load_q = [&](int qt, V8 (&f)[2]) {
+    int qrow = qt * 16 + ql;
+    qrow = qrow < T ? qrow : T - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) f[ks] = *(const V8*)(base + (long)qrow * ld + ks * 32 + g * 8);
+  };
+  V8 qnext[2];
+  if (wave < nqt) load_q(wave, qnext);
   for (int qt = wave; qt < nqt; qt += 4) {
     const int q0 = qt * 16;
-    int qrow = q0 + ql;
-    qrow = qrow < T ? qrow : T - 1;
-    V8 qf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const V8*)(base + (long)qrow * ld + ks * 32 + g * 8);
+    V8 qf[2] = {qnext[0], qnext[1]};
+    if (qt + 4 < nqt) load_q(qt + 4, qnext);  // the next tile's Q rows are in flight under this tile's work
 
     // S^T tiles: s[kt][r] = S[q0+ql][16kt + 4g + r].  Two key tiles at a time (4 fragment reads in
     // flight, then 4 MFMAs on two accumulators): the sched_barriers stop hipcc from hoisting all 28

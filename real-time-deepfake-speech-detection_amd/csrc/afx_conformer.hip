@@ -213,18 +213,33 @@ __global__ __launch_bounds__(256) void conf_attn_mfma_kernel(const float* __rest
   // ---- stage K (fp16, swizzled, zero padded) and V^T ---------------------------------
   for (int i = tid; i < (CA_KEYS * 128 + 16 * DT * CA_VT_STRIDE * 2) / 16; i += 256) ((u32x4*)sm)[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
-  for (int idx = tid; idx < N * (DH / 4); idx += 256) {
-    const int key = idx / (DH / 4), q4 = idx % (DH / 4);
-    const float* row = kv + ((long)b * N + key) * ldkv + h * DH + q4 * 4;
-    const f32x4 kk = *(const f32x4*)row;
-    const f32x4 vv = *(const f32x4*)(row + inner);
-    V4 kh;
+  {  // all of the thread's global loads first, then the LDS writes (one dependent L2 round trip, not eight)
+    constexpr int IT = (209 * (DH / 4) + 255) / 256;
+    f32x4 kreg[IT], vreg[IT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) kh[i] = (Tt)kk[i];
-    const int c = q4 >> 1;
-    *(V4*)(k_lds + key * 128 + ((c ^ ((key >> 1) & 7)) * 16) + (q4 & 1) * 8) = kh;
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < N * (DH / 4)) {
+        const int key = idx / (DH / 4), q4 = idx % (DH / 4);
+        const float* row = kv + ((long)b * N + key) * ldkv + h * DH + q4 * 4;
+        kreg[it] = *(const f32x4*)row;
+        vreg[it] = *(const f32x4*)(row + inner);
+      }
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vt_lds[(q4 * 4 + i) * CA_VT_STRIDE + key] = (Tt)vv[i];
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < N * (DH / 4)) {
+        const int key = idx / (DH / 4), q4 = idx % (DH / 4);
+        V4 kh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kh[i] = (Tt)kreg[it][i];
+        const int c = q4 >> 1;
+        *(V4*)(k_lds + key * 128 + ((c ^ ((key >> 1) & 7)) * 16) + (q4 & 1) * 8) = kh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vt_lds[(q4 * 4 + i) * CA_VT_STRIDE + key] = (Tt)vreg[it][i];
+      }
+    }
   }
   __syncthreads();
 
