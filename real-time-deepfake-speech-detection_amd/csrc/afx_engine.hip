@@ -610,10 +610,10 @@ extern "C" int afx_tap(afx_handle h, const char* name, float* out, size_t cap, s
 // launch of the forward is bracketed by hipEvents on the launch stream and summed per
 // class afterwards.  Off by default: the normal forward records nothing.
 // ---------------------------------------------------------------------------------
-enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN, PC_GEMM_F32, PC_CONV0, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV, PC_CONF_CHAIN,
+enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN, PC_GEMM_F32, PC_CONV0, PC_POSCONV, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV, PC_CONF_CHAIN,
                  PC_MISC, PC_AASIST, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm_kernel<128x128>", "gemm_kernel<128x64>", "gemm_kernel<256x256>",
-                                           "gemm_kernel<128x512,rowLN>", "gemm8_kernel<256x256>", "gemm8_kernel<128x512,rowLN>", "gemm_f32_kernel<128x128>", "conv0_kernel", "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel",
+                                           "gemm_kernel<128x512,rowLN>", "gemm8_kernel<256x256>", "gemm8_kernel<128x512,rowLN>", "gemm_f32_kernel<128x128>", "conv0_kernel", "posconv_kernel", "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel",
                                            "conf_dwconv_kernel", "conf_chain_kernel", "misc", "aasist_head"};
 struct ProfRec { int cls; hipEvent_t a, b; double flops; };
 struct Profiler {
@@ -632,6 +632,7 @@ struct Profiler {
 };
 static std::unordered_map<afx_engine*, Profiler> g_prof;
 static thread_local Profiler* t_prof = nullptr;
+static int g_posconv_sliding = 1;  // positional conv: sliding-window kernel (0: chunked-K GEMM)
 static int g_conf_attn_mfma = 1;   // Conformer attention on the matrix cores (0: the fp32 VALU kernel)
 static int g_fuse_conformer = 1;  // Conformer block: row-local chains fused (afx_conformer_fused.hip); 0 = per-op path
 static int g_fuse_conv_ln = 1;  // conv layers 1-6: LayerNorm+GELU in the GEMM epilogue (A/B knob)
@@ -782,7 +783,13 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
   }
   if (tap(e, "proj", w.x, (size_t)M * kD, false, s)) return 1;
   // positional conv (grouped, k=128) + GELU, added to x in place
-  {
+  if (g_posconv_sliding && dt != DT_FP32 && Tt <= 224) {
+    PosConvArgs pc;
+    memset(&pc, 0, sizeof pc);
+    pc.xpad = w.xpad; pc.xpad_batch = (long)(Tt + kPosK) * kD; pc.W = e->posw; pc.bias = e->F("ssl.encoder.pos_conv.0.bias");
+    pc.x = w.x; pc.B = B; pc.T = Tt;
+    KOK(timed(PC_POSCONV, 2.0 * M * kD * (kD / kPosG) * kPosK, s, [&] { return launch_posconv(pc, dt, s); }));
+  } else {
     const int cpg = kD / kPosG;
     GemmArgs g = plain_gemm(w.xpad, 0, e->posw, (long)cpg * kPosK, M, cpg, cpg * kPosK);
     g.rpb = Tt; g.a_batch = (long)(Tt + kPosK) * kD; g.a_row = kD;
@@ -1138,6 +1145,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
   }
   if (!strcmp(key, "conv0_mfma")) {
     conv0_set_mfma(value);
+    return 0;
+  }
+  if (!strcmp(key, "posconv_sliding")) {
+    g_posconv_sliding = value != 0;
     return 0;
   }
   if (!strcmp(key, "conf_attn_mfma")) {

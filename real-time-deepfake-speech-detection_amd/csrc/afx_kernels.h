@@ -95,6 +95,18 @@ const char* launch_pack_conv(const float* w, int N, int Cin, int k, void* out_h,
 const char* launch_pack_posconv(const float* v, const float* g, int C, int cpg, int k, float* norm_tmp /*[k]*/,
                                 void* out_h, int dtype, hipStream_t s);
 
+// ---- positional conv of the encoder as a sliding-window kernel (afx_posconv.hip) ---------------
+// x (B*T, 1024) fp32 += GELU(grouped conv over the time-padded operand copy xpad (B, T+128, 1024)); T <= 224
+struct PosConvArgs {
+  const void* xpad;  // operand type, rows [64, 64+T) = x, zero rows around
+  long xpad_batch;   // elements between utterances ((T + 128) * 1024)
+  const void* W;     // packed [1024][128 taps x 64 in] (launch_pack_posconv)
+  const float* bias;
+  float* x;
+  int B, T, slab_rows;  // slab_rows is filled in by the launcher
+};
+const char* launch_posconv(const PosConvArgs& p, int dtype, hipStream_t s);
+
 // ---- transformer self-attention (afx_attn.hip) -----------------------------------
 // qkv: (B*T, 3*H*64) operand type [q | k | v]; out: (B*T, H*64) operand type.
 const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t s);
