@@ -121,7 +121,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           va[r] = fmaf(acc[i][2 * jp][r] * rstd[i], ga0[r], be0[r]);
           vb[r] = fmaf(acc[i][2 * jp + 1][r] * rstd[i], ga1[r], be1[r]);
         }
-        if (p.act == ACT_GELU) {
+        if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
           const f32x2_t a0 = gelu_erf2(f32x2_t{va[0], va[1]}), a1 = gelu_erf2(f32x2_t{va[2], va[3]});
           const f32x2_t b0 = gelu_erf2(f32x2_t{vb[0], vb[1]}), b1 = gelu_erf2(f32x2_t{vb[2], vb[3]});
           va = f32x4{a0[0], a0[1], a1[0], a1[1]};
@@ -138,6 +138,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va[r]), __float_as_uint(vb[r]), false, false);
           va[r] = __uint_as_float(sw[0]);
           vb[r] = __uint_as_float(sw[1]);
+        }
+        if (p.dbg_nodma & 32) {  // timing only: no stores
+          asm volatile("" :: "v"(va), "v"(vb));
+          continue;
         }
         if (m >= p.M) continue;
         const int n = n0 + wc * WN + jp * 32 + cbw;
