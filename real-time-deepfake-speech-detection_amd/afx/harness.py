@@ -112,14 +112,47 @@ def write_score_file(save_path, utt_ids, scores):
             fh.write("{} {}\n".format(f, cm))
 
 
+def prefetch_to_device(batches, device):
+    """Iterate ``(meta, x_on_device)`` over ``(meta, x_host)`` pairs with the NEXT batch's H2D copy
+    (pinned staging buffer, side stream) running under the current batch's forward.  The compute
+    stream only waits on the copy's event, so a pass is bounded by max(compute, PCIe), not the sum."""
+    if not torch.cuda.is_available() or str(device) == "cpu":
+        for meta, x in batches:
+            yield meta, x.to(device)
+        return
+    side = torch.cuda.Stream()
+    it = iter(batches)
+
+    def stage(item):
+        meta, x = item
+        with torch.cuda.stream(side):
+            xd = x.pin_memory().to(device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return meta, xd, ev
+
+    cur = next(it, None)
+    cur = stage(cur) if cur is not None else None
+    while cur is not None:
+        nxt = next(it, None)
+        nxt = stage(nxt) if nxt is not None else None  # in flight while `cur` is consumed
+        meta, xd, ev = cur
+        torch.cuda.current_stream().wait_event(ev)
+        xd.record_stream(torch.cuda.current_stream())
+        yield meta, xd
+        cur = nxt
+
+
 def produce_evaluation_file(dataset, model, device, save_path, batch_size, num_workers=4):
     """main.py:199-221.  Scores stay on the GPU until the end of the pass (one D2H copy
-    instead of the reference's per-batch ``.cpu()``)."""
+    instead of the reference's per-batch ``.cpu()``), and the next batch's H2D copy overlaps the
+    current forward (the reference's ``batch_x.to(device)`` is blocking)."""
     model.eval()
     names, chunks = [], []
     with torch.no_grad():
-        for utt_id, batch_x, _label in _loader(dataset, batch_size, num_workers):
-            out = model(batch_x.to(device, non_blocking=True))
+        loader = ((utt_id, batch_x) for utt_id, batch_x, _label in _loader(dataset, batch_size, num_workers))
+        for utt_id, x in prefetch_to_device(loader, device):
+            out = model(x)
             chunks.append(out[:, 1])  # bonafide score (main.py:211-212)
             names.extend(utt_id)
     scores = torch.cat(chunks).cpu().numpy().ravel().tolist() if chunks else []
