@@ -833,6 +833,27 @@ bool gemm_is_narrow(int N) { return N <= 64 || (N > 128 && N < 256 && N % 128 !=
 // 256x256 tiles halve the operand bytes per FLOP (the per-CU L2->LDS rate is what bounds
 // this kernel) but quantise badly at M = B*199: measured faster only for the conv layers
 // (huge M, N = 512) and the K = 4096 FFN product (tools/bench_gemm.py, profiles/).
+// Row split for the 8-phase kernel: with T tiles on C CUs (one workgroup each) the last partial round
+// costs a whole tile time however few tiles it holds (M = 64 x 199 rows: FC1 800 tiles = 3 rounds +
+// 32, QKV 600 = 2 rounds + 88).  For a plain GEMM the leading rows that fill whole rounds exactly go
+// to the 8-phase kernel and the remaining rows to the 128x128 kernel (two workgroups per CU), when
+// those fit ONE round of it.  Returns the number of leading rows (0: no split).
+static int g_split = 1;  // A/B knob
+void gemm_set_split(int v) { g_split = v; }
+static int gemm_split_rows(const GemmArgs& p, int groups) {
+  constexpr int kCUs = 256;
+  if (!g_split || groups != 1 || p.ln_gamma || p.kchunk != p.K || p.rpb < p.M || gemm_is_narrow(p.N)) return 0;
+  const long nN = (p.N + 255) / 256, nM = (p.M + 255) / 256, tiles = nN * nM;
+  if (tiles <= kCUs || tiles % kCUs == 0) return 0;
+  const long nM1 = (tiles / kCUs) * kCUs / nN;  // whole rounds, whole row tiles
+  if (nM1 < 1 || nM1 >= nM) return 0;
+  const long rest = p.M - nM1 * 256;
+  const long rest128 = ((rest + 127) / 128) * ((p.N + 127) / 128);
+  if (rest128 > 2 * kCUs) return 0;  // the remainder would itself need a second round
+  if ((tiles % kCUs) * 2 > kCUs && nM1 * nN < (tiles / kCUs) * kCUs) return 0;  // last round is more than half full anyway
+  return (int)(nM1 * 256);
+}
+
 int gemm_tile_of(const GemmArgs& p, int groups) {
   if (p.ln_gamma) return g_deep != 0 && p.kchunk == p.K ? 8 : 3;
   if (gemm_is_narrow(p.N)) return 1;
@@ -846,6 +867,7 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
   const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   const long b256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   if (b128 < 384) return 1;  // small batches: halve the tile to spread over the chip
+  if (gemm_split_rows(p, groups) > 0) return 7;  // whole rounds on the 8-phase kernel + a 128x128 remainder
   const double e128 = (double)b128 / (double)(((b128 + 511) / 512) * 512);
   const double e256 = 1.15 * (double)b256 / (double)(((b256 + 255) / 256) * 256);
   if (e256 <= e128) return 0;
@@ -873,6 +895,20 @@ const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t
   const int tile = gemm_tile_of(p, groups);
   p.a_nt = g_ant_override >= 0 ? g_ant_override : (tile == 3 ? 1 : 0);
   p.dbg_nodma = g_nodma;
+  const int m1 = tile == 7 && g_tile_override < 0 ? gemm_split_rows(p, groups) : 0;
+  if (m1 > 0) {  // rows [0, m1) on the 8-phase kernel, rows [m1, M) on the 128x128 kernel
+    const size_t hs = 2;
+    GemmArgs a = p, b = p;
+    a.M = m1; a.rpb = m1; a.o_batch_rows = m1; a.oh_batch_rows = m1;
+    b.M = p.M - m1; b.rpb = b.M; b.o_batch_rows = b.M; b.oh_batch_rows = b.M;
+    b.A = (const char*)p.A + (size_t)m1 * p.a_row * hs;
+    if (p.resid) b.resid = p.resid + (size_t)m1 * p.ldr;
+    if (p.out_f) b.out_f = p.out_f + (size_t)m1 * p.ldo_f;
+    if (p.out_h) b.out_h = (char*)p.out_h + (size_t)m1 * p.ldo_h * hs;
+    hipError_t err = dtype == DT_BF16 ? dispatch<BF16>(a, 7, groups, s) : dispatch<FP16>(a, 7, groups, s);
+    if (err == hipSuccess) err = dtype == DT_BF16 ? dispatch<BF16>(b, 0, groups, s) : dispatch<FP16>(b, 0, groups, s);
+    return err == hipSuccess ? nullptr : hipGetErrorString(err);
+  }
   const hipError_t err = dtype == DT_BF16 ? dispatch<BF16>(p, tile, groups, s) : dispatch<FP16>(p, tile, groups, s);
   return err == hipSuccess ? nullptr : hipGetErrorString(err);
 }

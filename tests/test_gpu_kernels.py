@@ -101,6 +101,30 @@ def test_gemm_8phase_kernel_is_bit_identical_to_the_2stage_kernel(K, M, N, K_):
         check(lib().afx_debug_set(b"gemm_tile", -1))
 
 
+@pytest.mark.parametrize("M,N,K_,resid", [(12736, 3072, 1024, False), (12736, 4096, 1024, False), (6500, 2048, 512, True)])
+def test_gemm_round_split_matches_the_single_kernel(K, M, N, K_, resid):
+    """Default dispatch of a multi-round plain GEMM: whole rounds on the 8-phase kernel, remaining rows on the
+    128x128 kernel.  Same k order per element in both, so the result must equal the single-kernel one bit for bit."""
+    from afx._lib import check, lib
+    g = torch.Generator().manual_seed(N + K_)
+    A = torch.randn(M, K_, generator=g).half().cuda()
+    W = (torch.randn(N, K_, generator=g) / math.sqrt(K_)).half().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).cuda() if resid else None
+    try:
+        check(lib().afx_debug_set(b"gemm_tile", 0))
+        want_f, want_h = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
+        check(lib().afx_debug_set(b"gemm_tile", -1))
+        got_f, got_h = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
+        assert torch.equal(got_f, want_f) and torch.equal(got_h, want_h)
+        check(lib().afx_debug_set(b"gemm_split", 0))
+        got_f, _ = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
+        assert torch.equal(got_f, want_f)
+    finally:
+        check(lib().afx_debug_set(b"gemm_tile", -1))
+        check(lib().afx_debug_set(b"gemm_split", 1))
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_gemm_asymmetric_identity_catches_transposes(K, dtype):
     # A = I, asymmetric W: C must equal W^T exactly (cdna guide: A=I check with asymmetric B)

@@ -31,6 +31,7 @@ SHAPES = [
 SETS = {
     "tile": [("128x128", ("gemm_tile", 0)), ("256x128", ("gemm_tile", 2)), ("256x256", ("gemm_tile", 1))],
     "8ph": [("128x128", ("gemm_tile", 0)), ("256x256 2-stage", ("gemm_tile", 1)), ("256x256 8-phase", ("gemm_tile", 3))],
+    "split": [("single kernel", ("gemm_split", 0)), ("rounds + remainder", ("gemm_split", 1))],
     "map": [("map0", ("gemm_map", 0)), ("map1", ("gemm_map", 1)), ("map2", ("gemm_map", 2))],
     "nt": [("A default", ("gemm_a_nt", 0)), ("A nt", ("gemm_a_nt", 1))],
     "nodma": [("full", ("gemm_nodma", 0)), ("compute-only", ("gemm_nodma", 1))],
@@ -98,6 +99,7 @@ def main():
         check(lib().afx_debug_set(key.encode(), -1))
     check(lib().afx_debug_set(b"gemm_nodma", 0))
     check(lib().afx_debug_set(b"gemm_deep", -1))
+    check(lib().afx_debug_set(b"gemm_split", 1))
 
 
 if __name__ == "__main__":
