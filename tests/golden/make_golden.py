@@ -17,6 +17,8 @@ What is produced and from what:
 * ssl_tiny.npz        -- a tiny wav2vec2 (2 layers, D=64) from the in-container
   ``transformers`` implementation, weights renamed to fairseq keys (the third-
   party stand-in for the absent fairseq).
+* ssl_full_samples.npz -- the same implementation at the real XLS-R dimensions (2 layers), fed the seeded
+  synthetic weights (regenerable by name, so not stored); a strided sample of its outputs.
 * pre_eer.npz         -- pre-emphasis via F.pad(reflect)+F.conv1d exactly as
   data/preprocess.py:22-25 writes it, EER via the formula of trainer.py:134-139,
   tile/crop per data/test_set.py:201-227.
@@ -224,6 +226,60 @@ def gen_ssl_tiny():
     print("ssl_tiny.npz y", tuple(y.shape))
 
 
+def gen_ssl_full():
+    """XLS-R dimensions (1024 / 16 heads / 4096, conv 512 x 7, pos-conv k=128 g=16), 2 layers, weights =
+    the seeded synthetic state_dict (regenerated by name in the test, not stored), forward by the
+    in-container transformers wav2vec2; only a strided sample of the outputs is stored."""
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    cfg = Wav2Vec2Config(
+        hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096,
+        conv_dim=(512,) * 7, conv_stride=(5, 2, 2, 2, 2, 2, 2), conv_kernel=(10, 3, 3, 3, 3, 2, 2),
+        conv_bias=True, feat_extract_norm="layer", do_stable_layer_norm=True,
+        num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16,
+        hidden_dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, feat_proj_dropout=0.0,
+        layerdrop=0.0, mask_time_prob=0.0, hidden_act="gelu", layer_norm_eps=1e-5)
+    hf = Wav2Vec2Model(cfg).eval()
+    sd = {k[len(synth.SSL_PREFIX):]: v for k, v in synth.ssl_state_dict(2).items()}
+    hsd = {}
+    for i in range(7):
+        hsd[f"feature_extractor.conv_layers.{i}.conv.weight"] = sd[f"feature_extractor.conv_layers.{i}.0.weight"]
+        hsd[f"feature_extractor.conv_layers.{i}.conv.bias"] = sd[f"feature_extractor.conv_layers.{i}.0.bias"]
+        hsd[f"feature_extractor.conv_layers.{i}.layer_norm.weight"] = sd[f"feature_extractor.conv_layers.{i}.2.1.weight"]
+        hsd[f"feature_extractor.conv_layers.{i}.layer_norm.bias"] = sd[f"feature_extractor.conv_layers.{i}.2.1.bias"]
+    hsd["feature_projection.layer_norm.weight"] = sd["layer_norm.weight"]
+    hsd["feature_projection.layer_norm.bias"] = sd["layer_norm.bias"]
+    hsd["feature_projection.projection.weight"] = sd["post_extract_proj.weight"]
+    hsd["feature_projection.projection.bias"] = sd["post_extract_proj.bias"]
+    pc = "encoder.pos_conv_embed.conv."
+    hsd[pc + "parametrizations.weight.original0"] = sd["encoder.pos_conv.0.weight_g"]
+    hsd[pc + "parametrizations.weight.original1"] = sd["encoder.pos_conv.0.weight_v"]
+    hsd[pc + "bias"] = sd["encoder.pos_conv.0.bias"]
+    for n in range(2):
+        a, b = f"encoder.layers.{n}.", f"encoder.layers.{n}."
+        for pj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            hsd[b + f"attention.{pj}.weight"] = sd[a + f"self_attn.{pj}.weight"]
+            hsd[b + f"attention.{pj}.bias"] = sd[a + f"self_attn.{pj}.bias"]
+        hsd[b + "layer_norm.weight"] = sd[a + "self_attn_layer_norm.weight"]
+        hsd[b + "layer_norm.bias"] = sd[a + "self_attn_layer_norm.bias"]
+        hsd[b + "feed_forward.intermediate_dense.weight"] = sd[a + "fc1.weight"]
+        hsd[b + "feed_forward.intermediate_dense.bias"] = sd[a + "fc1.bias"]
+        hsd[b + "feed_forward.output_dense.weight"] = sd[a + "fc2.weight"]
+        hsd[b + "feed_forward.output_dense.bias"] = sd[a + "fc2.bias"]
+        hsd[b + "final_layer_norm.weight"] = sd[a + "final_layer_norm.weight"]
+        hsd[b + "final_layer_norm.bias"] = sd[a + "final_layer_norm.bias"]
+    hsd["encoder.layer_norm.weight"] = sd["encoder.layer_norm.weight"]
+    hsd["encoder.layer_norm.bias"] = sd["encoder.layer_norm.bias"]
+    missing, unexpected = hf.load_state_dict(hsd, strict=False)
+    assert not unexpected and all("masked_spec_embed" in m for m in missing), (missing, unexpected)
+    wave = synth.waveforms(2, 16000, batch_idx=321)
+    with torch.no_grad():
+        y = hf(wave).last_hidden_state
+        conv = hf.feature_extractor(wave).transpose(1, 2)
+    np.savez_compressed(os.path.join(HERE, "ssl_full_samples.npz"), y=y[:, ::6, ::41].numpy(), conv=conv[:, ::6, ::23].numpy(),
+                        y_mean=np.float64(y.double().mean()), y_absmean=np.float64(y.double().abs().mean()))
+    print("ssl_full_samples.npz y", tuple(y.shape), "abs mean", float(y.abs().mean()))
+
+
 def gen_pre_eer():
     from scipy.interpolate import interp1d
     from scipy.optimize import brentq
@@ -248,4 +304,5 @@ if __name__ == "__main__":
     gen_modules()
     gen_backend()
     gen_ssl_tiny()
+    gen_ssl_full()
     gen_pre_eer()
