@@ -1,8 +1,12 @@
 """Oracle: Conformer student head, fp32 torch CPU (TEST INFRASTRUCTURE).
 
-PARITY UNPINNED at the block level: ``conformer.ConformerBlock`` is the PyPI
+PARTIALLY PINNED at the block level: ``conformer.ConformerBlock`` is the PyPI
 package ``conformer`` (lucidrains/conformer; third-party, unpinned, absent from
-this image) and the reference holds no test/golden vector for it.  The block
+this image) and the reference holds no test/golden vector for it.  The block is
+checked against two in-container ``transformers`` implementations of the same
+algorithms (``tests/golden/conformer_block.npz``, ``conformer_attn_shaw.npz``);
+the (query - key) index convention of the relative-position table and the even-
+kernel padding remain PARITY UNPINNED.  The block
 below restates that package's published algorithm (SURVEY.md 8(a) row 12 and
 appendix A.3) and is anchored on the reference call site
 ``models/conformer_baseline.py:16-18`` (``ConformerBlock(dim=emb, dim_head=

@@ -19,6 +19,10 @@ What is produced and from what:
   party stand-in for the absent fairseq).
 * ssl_full_samples.npz -- the same implementation at the real XLS-R dimensions (2 layers), fed the seeded
   synthetic weights (regenerable by name, so not stored); a strided sample of its outputs.
+* conformer_block.npz -- transformers' Wav2Vec2ConformerEncoderLayer without position embeddings, weights renamed
+  to the lucidrains keys: pins the Conformer block restatement except its relative-position term.
+* conformer_attn_shaw.npz -- transformers' Wav2Vec2BertSelfAttention ("relative_key" = Shaw) for the relative-position
+  term of that block's attention (table reversed: it indexes by key - query).
 * pre_eer.npz         -- pre-emphasis via F.pad(reflect)+F.conv1d exactly as
   data/preprocess.py:22-25 writes it, EER via the formula of trainer.py:134-139,
   tile/crop per data/test_set.py:201-227.
@@ -280,6 +284,92 @@ def gen_ssl_full():
     print("ssl_full_samples.npz y", tuple(y.shape), "abs mean", float(y.abs().mean()))
 
 
+def gen_conformer_block():
+    """Partial pin of the Conformer block restatement (the lucidrains package is absent): the in-container
+    transformers Wav2Vec2ConformerEncoderLayer is the same macaron block -- half-step FF, MHSA, conv module
+    (LayerNorm, pointwise, GLU, depthwise "same", BatchNorm, Swish, pointwise), half-step FF, final LayerNorm --
+    when run without position embeddings.  Its weights are renamed to the lucidrains keys (conv expansion 1,
+    zero biases where transformers has none, zero Shaw table), so the fixture pins everything in
+    oracle/conformer.py except the relative-position term and the even-kernel padding."""
+    from transformers import Wav2Vec2ConformerConfig
+    from transformers.models.wav2vec2_conformer.modeling_wav2vec2_conformer import Wav2Vec2ConformerEncoderLayer
+    torch.manual_seed(23)
+    D, H, FFD, KS = 64, 4, 256, 15
+    cfg = Wav2Vec2ConformerConfig(hidden_size=D, num_attention_heads=H, intermediate_size=FFD, conv_depthwise_kernel_size=KS,
+                                  hidden_act="swish", position_embeddings_type=None, hidden_dropout=0.0, attention_dropout=0.0,
+                                  activation_dropout=0.0, conformer_conv_dropout=0.0, layer_norm_eps=1e-5)
+    lay = Wav2Vec2ConformerEncoderLayer(cfg).eval()
+    with torch.no_grad():
+        for n, p in lay.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.05)
+            elif "layer_norm" in n and n.endswith("weight"):
+                p.normal_(1, 0.1)
+        for pj in ("linear_q", "linear_k", "linear_v"):  # lucidrains' to_q / to_kv carry no bias
+            getattr(lay.self_attn, pj).bias.zero_()
+        bn = lay.conv_module.batch_norm
+        bn.weight.normal_(1, 0.1)
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 1.5)
+    h = lay.state_dict()
+    sd = {}
+    for ff, src in (("ff1", "ffn1"), ("ff2", "ffn2")):
+        sd[f"{ff}.fn.norm.weight"], sd[f"{ff}.fn.norm.bias"] = h[f"{src}_layer_norm.weight"], h[f"{src}_layer_norm.bias"]
+        sd[f"{ff}.fn.fn.net.0.weight"], sd[f"{ff}.fn.fn.net.0.bias"] = h[f"{src}.intermediate_dense.weight"], h[f"{src}.intermediate_dense.bias"]
+        sd[f"{ff}.fn.fn.net.3.weight"], sd[f"{ff}.fn.fn.net.3.bias"] = h[f"{src}.output_dense.weight"], h[f"{src}.output_dense.bias"]
+    sd["attn.norm.weight"], sd["attn.norm.bias"] = h["self_attn_layer_norm.weight"], h["self_attn_layer_norm.bias"]
+    sd["attn.fn.to_q.weight"] = h["self_attn.linear_q.weight"]
+    sd["attn.fn.to_kv.weight"] = torch.cat([h["self_attn.linear_k.weight"], h["self_attn.linear_v.weight"]], dim=0)
+    sd["attn.fn.to_out.weight"], sd["attn.fn.to_out.bias"] = h["self_attn.linear_out.weight"], h["self_attn.linear_out.bias"]
+    sd["attn.fn.rel_pos_emb.weight"] = torch.zeros(1025, D // H)
+    sd["conv.net.0.weight"], sd["conv.net.0.bias"] = h["conv_module.layer_norm.weight"], h["conv_module.layer_norm.bias"]
+    sd["conv.net.2.weight"], sd["conv.net.2.bias"] = h["conv_module.pointwise_conv1.weight"], torch.zeros(2 * D)
+    sd["conv.net.4.conv.weight"], sd["conv.net.4.conv.bias"] = h["conv_module.depthwise_conv.weight"], torch.zeros(D)
+    for k in ("weight", "bias", "running_mean", "running_var"):
+        sd[f"conv.net.5.{k}"] = h[f"conv_module.batch_norm.{k}"]
+    sd["conv.net.7.weight"], sd["conv.net.7.bias"] = h["conv_module.pointwise_conv2.weight"], torch.zeros(D)
+    sd["post_norm.weight"], sd["post_norm.bias"] = h["final_layer_norm.weight"], h["final_layer_norm.bias"]
+    x = torch.randn(2, 50, D)
+    with torch.no_grad():
+        y = lay(x)[0]
+    out = {f"sd.{k}": v.detach().numpy() for k, v in sd.items()}
+    out["x"], out["y"], out["heads"] = x.numpy(), y.numpy(), np.int64(H)
+    np.savez_compressed(os.path.join(HERE, "conformer_block.npz"), **out)
+    print("conformer_block.npz y", tuple(y.shape), float(y.abs().mean()))
+
+
+def gen_shaw_attention():
+    """The relative-position term of the Conformer attention against transformers' Wav2Vec2BertSelfAttention with
+    position_embeddings_type="relative_key" (Shaw et al.: scores += q . E[distance] / sqrt(dh)).  That class indexes
+    its table by (key - query) + left_max; the lucidrains block the reference uses indexes by (query - key) + 512
+    (SURVEY.md appendix A.3), so the stored table is the transformers one reversed."""
+    from transformers import Wav2Vec2BertConfig
+    from transformers.models.wav2vec2_bert.modeling_wav2vec2_bert import Wav2Vec2BertSelfAttention
+    torch.manual_seed(29)
+    D, H = 64, 4
+    cfg = Wav2Vec2BertConfig(hidden_size=D, num_attention_heads=H, position_embeddings_type="relative_key",
+                             left_max_position_embeddings=512, right_max_position_embeddings=512, attention_dropout=0.0)
+    att = Wav2Vec2BertSelfAttention(cfg).eval()
+    with torch.no_grad():
+        for pj in ("linear_q", "linear_k", "linear_v"):
+            getattr(att, pj).bias.zero_()
+        att.linear_out.bias.normal_(0, 0.05)
+        att.distance_embedding.weight.normal_(0, 0.5)
+    g, b = 1 + 0.1 * torch.randn(D), 0.1 * torch.randn(D)
+    x = torch.randn(2, 70, D)
+    with torch.no_grad():
+        y = att(F.layer_norm(x, (D,), g, b, 1e-5))[0]
+    h = att.state_dict()
+    sd = {"norm.weight": g, "norm.bias": b, "fn.to_q.weight": h["linear_q.weight"],
+          "fn.to_kv.weight": torch.cat([h["linear_k.weight"], h["linear_v.weight"]], dim=0),
+          "fn.to_out.weight": h["linear_out.weight"], "fn.to_out.bias": h["linear_out.bias"],
+          "fn.rel_pos_emb.weight": h["distance_embedding.weight"].flip(0).contiguous()}
+    out = {f"sd.{k}": v.detach().numpy() for k, v in sd.items()}
+    out["x"], out["y"], out["heads"] = x.numpy(), y.numpy(), np.int64(H)
+    np.savez_compressed(os.path.join(HERE, "conformer_attn_shaw.npz"), **out)
+    print("conformer_attn_shaw.npz y", tuple(y.shape), float(y.abs().mean()))
+
+
 def gen_pre_eer():
     from scipy.interpolate import interp1d
     from scipy.optimize import brentq
@@ -305,4 +395,6 @@ if __name__ == "__main__":
     gen_backend()
     gen_ssl_tiny()
     gen_ssl_full()
+    gen_conformer_block()
+    gen_shaw_attention()
     gen_pre_eer()

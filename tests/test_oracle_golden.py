@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from conftest import load_golden, sub_sd
-from oracle import aasist, pre, ssl_trunk
+from oracle import aasist, conformer, pre, ssl_trunk
 
 TOL = dict(rtol=1e-4, atol=2e-5)
 
@@ -92,6 +92,25 @@ def test_ssl_trunk_at_xlsr_dimensions_matches_transformers_wav2vec2():
     y = ssl_trunk.ssl_forward(sd, wave)
     np.testing.assert_allclose(y[:, ::6, ::41].numpy(), z["y"], rtol=2e-4, atol=5e-5)
     assert abs(float(y.double().abs().mean()) - float(z["y_absmean"])) < 1e-5
+
+
+def test_conformer_block_matches_transformers_conformer_layer():
+    """Macaron structure, half-step FFs, conv module (GLU, depthwise "same", BatchNorm, Swish), final LayerNorm:
+    transformers' Wav2Vec2ConformerEncoderLayer without position embeddings, weights under the lucidrains key names."""
+    z = load_golden("conformer_block.npz")
+    y = conformer.conformer_block(sub_sd(z, ""), "", _t(z["x"]), int(z["heads"]))
+    np.testing.assert_allclose(y.numpy(), z["y"], rtol=1e-5, atol=5e-6)
+
+
+def test_conformer_attention_shaw_term_matches_transformers_relative_key():
+    """The relative-position term: transformers' Wav2Vec2BertSelfAttention ("relative_key"), table reversed to the
+    (query - key) indexing of the lucidrains block; the reversed-back table must NOT match (the test sees the term)."""
+    z = load_golden("conformer_attn_shaw.npz")
+    sd = sub_sd(z, "")
+    y = conformer.attention(sd, "", _t(z["x"]), int(z["heads"]))
+    np.testing.assert_allclose(y.numpy(), z["y"], rtol=1e-5, atol=2e-6)
+    sd["fn.rel_pos_emb.weight"] = sd["fn.rel_pos_emb.weight"].flip(0)
+    assert (conformer.attention(sd, "", _t(z["x"]), int(z["heads"])) - _t(z["y"])).abs().max().item() > 1e-2
 
 
 def test_conv_lengths_for_baseline_clips():
