@@ -15,6 +15,10 @@
 #include "afx_common.h"
 #include "afx_kernels.h"
 
+#ifndef MHSA_DBG
+#define MHSA_DBG 0  // timing experiments only (wrong results): 1 no K/V staging, 2 no query-tile loop, 4 no V^T scatter
+#endif
+
 namespace afx {
 
 constexpr int ATT_KEYS = 224;       // padded key capacity (7 k-steps of 32)
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
       kreg[it] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
       for (int i = 0; i < 8; ++i) vreg[it][i] = (Tt)0.f;
-      if (key < T) {
+      if (key < T && !(MHSA_DBG & 1)) {
         kreg[it] = *(const u32x4*)(kbase + (long)key * ld + c * 8);
         vreg[it] = *(const V8*)(vbase + (long)key * ld + c * 8);
       }
@@ -61,11 +65,14 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
     for (int it = 0; it < IT; ++it) {
       const int idx = tid + it * 256, key = idx >> 3, c = idx & 7;
       *(u32x4*)(k_lds + key * 128 + ((c ^ ((key >> 1) & 7)) * 16)) = kreg[it];
+      if (!(MHSA_DBG & 4)) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) vt_lds[(c * 8 + i) * ATT_VT_STRIDE + key] = vreg[it][i];
+        for (int i = 0; i < 8; ++i) vt_lds[(c * 8 + i) * ATT_VT_STRIDE + key] = vreg[it][i];
+      }
     }
   }
   __syncthreads();
+  if (MHSA_DBG & 2) return;
 
   const int ql = lane & 15, g = lane >> 4;
   const int nqt = (T + 15) >> 4;
@@ -86,9 +93,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
     // flight, then 4 MFMAs on two accumulators): the sched_barriers stop hipcc from hoisting all 28
     // reads to the top, which cost 360 VGPRs and left one workgroup per CU.
     f32x4 s[NKT];
-#pragma unroll
-    for (int kp = 0; kp < NKT; kp += 2) {
-      V8 kf[2][2];
+    auto read_k = [&](int kp, V8 (&kf)[2][2]) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int krow = (kp + u) * 16 + ql;
@@ -96,13 +101,22 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) kf[u][ks] = *(const V8*)(k_lds + krow * 128 + (((ks * 4 + g) ^ sw) * 16));
       }
+    };
+    V8 kfa[2][2], kfb[2][2];
+    read_k(0, kfa);
+#pragma unroll
+    for (int kp = 0; kp < NKT; kp += 2) {
+      // the next pair's fragments are requested before this pair's MFMAs (counted lgkmcnt keeps them in flight)
+      V8(&cur)[2][2] = (kp & 2) ? kfb : kfa;
+      V8(&nxt)[2][2] = (kp & 2) ? kfa : kfb;
+      if (kp + 2 < NKT) read_k(kp + 2, nxt);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 2; ++u) s[kp + u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) s[kp + u] = HT::mfma(kf[u][ks], qf[ks], s[kp + u]);
+        for (int u = 0; u < 2; ++u) s[kp + u] = HT::mfma(cur[u][ks], qf[ks], s[kp + u]);
       __builtin_amdgcn_sched_barrier(0);
     }
     float mx = -1e30f;
@@ -132,15 +146,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
     f32x4 o[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) {
-      V8 pf;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pf[r] = (Tt)s[2 * s2][r];
-        pf[4 + r] = (Tt)s[2 * s2 + 1][r];
-      }
-      V8 vf[4];
+    auto read_v = [&](int s2, V8 (&vf)[4]) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const Tt* vr = vt_lds + (nt * 16 + ql) * ATT_VT_STRIDE + s2 * 32 + g * 4;
@@ -152,9 +158,23 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
           vf[nt][4 + r] = hi[r];
         }
       }
+    };
+    V8 vfa[4], vfb[4];
+    read_v(0, vfa);
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      V8(&cur)[4] = (s2 & 1) ? vfb : vfa;
+      V8(&nxt)[4] = (s2 & 1) ? vfa : vfb;
+      if (s2 + 1 < KS) read_v(s2 + 1, nxt);
+      V8 pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pf[r] = (Tt)s[2 * s2][r];
+        pf[4 + r] = (Tt)s[2 * s2 + 1][r];
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) o[nt] = HT::mfma(vf[nt], pf, o[nt]);  // O^T = V^T P^T: the lane keeps ONE query row
+      for (int nt = 0; nt < 4; ++nt) o[nt] = HT::mfma(cur[nt], pf, o[nt]);  // O^T = V^T P^T: the lane keeps ONE query row
       __builtin_amdgcn_sched_barrier(0);
     }
     // o[nt][r] = O[q0 + ql][16nt + 4g + r]: 4 consecutive head dims of the lane's own query row,
