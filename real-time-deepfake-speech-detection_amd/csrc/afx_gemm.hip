@@ -442,26 +442,22 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt landed for every wave; every wave is done with tile kt-1
-    if (kt + 1 < nk && !(p.dbg_nodma & 1)) stage((kt + 1) & 1, kt + 1);  // dbg_nodma: timing-only build of the compute phase
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
     const char* sb = smem + (kt & 1) * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int slot = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
       V8 af[MT], wf[NT];
-      if (!(p.dbg_nodma & 2) || kt == 0) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
+      for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
-      }
-      if (!(p.dbg_nodma & 4)) {
-        __builtin_amdgcn_s_setprio(1);
+      for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-      }
+        for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
     }
   }
 
@@ -807,7 +803,7 @@ static int g_ant_override = -1;  // non-temporal A loads: -1 auto (row-complete 
 void gemm_set_a_nt(int v) { g_ant_override = v; }
 static int g_deep = -1;  // row-complete conv tile: 0 = 2-stage kernel, otherwise (default) the 8-phase kernel (A/B knob)
 void gemm_set_deep(int v) { g_deep = v; }
-static int g_nodma = 0;  // timing-only: skip the operand DMA after the first K-tile (WRONG results)
+static int g_nodma = 0;  // timing-only epilogue knob bits (GemmArgs::dbg_nodma; WRONG results when set)
 void gemm_set_nodma(int v) { g_nodma = v; }
 
 // Host-side shape contract; anything else is a programming error in the caller.

@@ -46,7 +46,7 @@ struct GemmArgs {
   const float* ln_beta;
   float ln_eps;
   int a_nt;  // 1: non-temporal LDS-DMA for the A panel (set by launch_gemm)
-  int dbg_nodma;  // timing experiments only
+  int dbg_nodma;  // timing experiments only (wrong results): epilogue bits 8 no activation, 16 narrow stores, 32 no stores, 64 no epilogue
 };
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
 const char* launch_gemm_f32(const GemmArgs& p, int groups, hipStream_t s);  // afx_gemm_f32.hip (DT_FP32 operands)
@@ -57,7 +57,7 @@ void gemm_set_tile(int t);      // A/B knob: -1 default, 0: 128x128 tile, 1: 256
 void gemm_set_a_nt(int v);      // A/B knob: -1 auto, 0/1 non-temporal A-panel loads
 void gemm_set_split(int v);     // A/B knob: 1 (default) = whole rounds on the 8-phase kernel + 128x128 remainder rows
 void gemm_set_deep(int v);      // A/B knob, conv tile: 0 = 2-stage kernel, -1/2 = 8-phase kernel (default)
-void gemm_set_nodma(int v);     // timing-only knob: compute phase without operand DMA (wrong results)
+void gemm_set_nodma(int v);     // timing-only knob: epilogue parts off (bits above; wrong results)
 
 // ---- frontend / row kernels (afx_frontend.hip) ---------------------------------
 // conv layer 0 (Cin=1,k=10,s=5) + LayerNorm(512) + erf-GELU; optional pre-emphasis.

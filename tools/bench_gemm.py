@@ -34,16 +34,11 @@ SETS = {
     "split": [("single kernel", ("gemm_split", 0)), ("rounds + remainder", ("gemm_split", 1))],
     "map": [("map0", ("gemm_map", 0)), ("map1", ("gemm_map", 1)), ("map2", ("gemm_map", 2))],
     "nt": [("A default", ("gemm_a_nt", 0)), ("A nt", ("gemm_a_nt", 1))],
-    "nodma": [("full", ("gemm_nodma", 0)), ("compute-only", ("gemm_nodma", 1))],
     "deep": [("2-stage", ("gemm_deep", 0)), ("8-phase", ("gemm_deep", 2))],
     "epi": [("narrow stores", ("gemm_nodma", 16)), ("wide stores", ("gemm_nodma", 0))],
-    "attr": [("full", ("gemm_nodma", 0)), ("-dma", ("gemm_nodma", 1)), ("-dma-lds", ("gemm_nodma", 3)),
-             ("-dma-mfma", ("gemm_nodma", 5)), ("-dma-act", ("gemm_nodma", 9)), ("-dma-lds-mfma-act", ("gemm_nodma", 15))],
 }
 VARIANTS = SETS[os.environ.get("BENCH_SET", "tile")]
-if os.environ.get("BENCH_SET") == "attr":
-    SHAPES = [SHAPES[0], SHAPES[3], SHAPES[5], SHAPES[6]]
-if os.environ.get("BENCH_SET") in ("nt", "nodma", "deep"):  # the fused conv + LayerNorm kernel (row-complete tile)
+if os.environ.get("BENCH_SET") in ("nt", "deep"):  # the fused conv + LayerNorm kernel (row-complete tile)
     SHAPES = [("convln1 M=409536 K=1536", "convln", (B, 12799, 3, 2)), ("convln2 M=204736 K=1536", "convln", (B, 6399, 3, 2)),
               ("convln3 M=102336 K=1536", "convln", (B, 3199, 3, 2)), ("convln5 M=25536 K=1024", "convln", (B, 799, 2, 2))] + SHAPES[3:]
 
