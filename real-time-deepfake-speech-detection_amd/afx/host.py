@@ -78,22 +78,69 @@ class Wav2Vec2Trunk(nn.Module):
         raise RuntimeError("Wav2Vec2Trunk holds parameters only; call the owning XLSR_FE / model")
 
 
+class _StubPickle:
+    """``pickle_module`` for torch.load that tolerates classes of packages that are not installed
+    (fairseq / omegaconf / argparse-style config objects inside ``xlsr2_300m.pt``): an unknown
+    global becomes an inert stand-in, tensors and plain containers load as usual.  Nothing from the
+    stand-ins is executed -- only the ``model`` state_dict is read afterwards."""
+    import pickle as _pickle
+
+    __name__ = "afx_stub_pickle"
+
+    class Unpickler(_pickle.Unpickler):
+        def find_class(self, module, name):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                def __init__(self, *a, **k):
+                    pass
+
+                def __setstate__(self, state):
+                    self.__dict__.update(state if isinstance(state, dict) else {"state": state})
+                return type(name, (), {"__module__": module, "__init__": __init__, "__setstate__": __setstate__,
+                                       "__reduce__": None})
+
+    @staticmethod
+    def load(f, **kw):
+        return _StubPickle.Unpickler(f, **kw).load()
+
+
+_UNUSED_SSL = ("quantizer.", "project_q.", "final_proj.", "mask_emb", "target_glu.", "bn1.")
+
+
 def load_ssl_checkpoint(trunk, path):
-    """Best-effort load of a fairseq ``xlsr2_300m.pt`` or a plain state_dict file
-    (keys with or without the ``model.`` / ``ssl_model.model.`` prefix)."""
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+    """Load a fairseq ``xlsr2_300m.pt`` (``{"cfg"/"args": ..., "model": state_dict}``) or a plain
+    state_dict file into the trunk container -- without fairseq (models/fe.py:11-14 uses
+    ``fairseq.checkpoint_utils.load_model_ensemble_and_task``): config objects of absent packages are
+    stubbed while unpickling, only the tensors are used.  Keys may carry the ``module.`` /
+    ``ssl_model.`` / ``model.`` / ``w2v_encoder.w2v_model.`` prefixes; pre-training heads
+    (quantizer, project_q, final_proj, mask_emb) are ignored; a checkpoint with more encoder layers
+    than the trunk keeps the FIRST ``len(trunk.encoder.layers)`` (models/fe.py:72-74)."""
+    try:
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        ck = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_StubPickle)
     sd = ck.get("model", ck) if isinstance(ck, dict) else ck
+    if not isinstance(sd, dict):
+        raise KeyError(f"{path}: no state_dict found in the checkpoint")
     out = {}
     for k, v in sd.items():
-        for pre in ("module.", "ssl_model.", "model."):
+        if not torch.is_tensor(v):
+            continue
+        for pre in ("module.", "w2v_encoder.", "w2v_model.", "ssl_model.", "model."):
             if k.startswith(pre):
                 k = k[len(pre):]
+        if k.startswith(_UNUSED_SSL):
+            continue
         out[k] = v
     own = trunk.state_dict()
     missing = [k for k in own if k not in out]
     if missing:
         raise KeyError(f"{path}: checkpoint lacks {len(missing)} trunk tensors, e.g. {missing[:3]}")
-    trunk.load_state_dict({k: out[k] for k in own}, strict=True)
+    bad = [k for k in own if tuple(out[k].shape) != tuple(own[k].shape)]
+    if bad:
+        raise ValueError(f"{path}: shape mismatch for {bad[:3]}")
+    trunk.load_state_dict({k: out[k].to(torch.float32) for k in own}, strict=True)
 
 
 # ---- engine routing ---------------------------------------------------------------------

@@ -176,3 +176,42 @@ def test_harness_helpers_match_reference_semantics(tmp_path):
     p = tmp_path / "sub" / "scores.txt"
     harness.write_score_file(str(p), ["u1", "u2"], [-2.9056100845336914, 0.5])
     assert p.read_text() == "u1 -2.9056100845336914\nu2 0.5\n"  # format of results/**.txt
+
+
+def test_fairseq_style_checkpoint_loads_without_fairseq(tmp_path):
+    """an ``xlsr2_300m.pt``-style file -- {"cfg": <object of an absent package>, "model":
+    state_dict with pre-training heads} -- is read without fairseq: config objects are stubbed while
+    unpickling, the unused heads are dropped, extra encoder layers beyond the trunk's are ignored."""
+    import sys
+    import types
+    from afx import host, synth
+    sd = synth.ssl_state_dict(2, prefix="")
+    fake = types.ModuleType("fairseq_absent_pkg")
+
+    class Wav2Vec2Config:  # stands for fairseq.models.wav2vec.wav2vec2.Wav2Vec2Config
+        def __init__(self):
+            self.encoder_layers = 2
+    Wav2Vec2Config.__module__ = "fairseq_absent_pkg"
+    Wav2Vec2Config.__qualname__ = "Wav2Vec2Config"
+    fake.Wav2Vec2Config = Wav2Vec2Config
+    sys.modules["fairseq_absent_pkg"] = fake
+    try:
+        model = dict(sd)
+        model["mask_emb"] = torch.zeros(1024)
+        model["quantizer.vars"] = torch.zeros(1, 640, 384)
+        model["project_q.weight"] = torch.zeros(768, 768)
+        model["final_proj.weight"] = torch.zeros(768, 1024)
+        path = tmp_path / "xlsr_like.pt"
+        torch.save({"cfg": Wav2Vec2Config(), "args": None, "model": model}, path)
+    finally:
+        del sys.modules["fairseq_absent_pkg"]  # from here on the class cannot be imported, as on a box without fairseq
+    trunk = host.Wav2Vec2Trunk(n_layers=1)
+    with torch.no_grad():
+        for p in trunk.parameters():
+            p.zero_()
+    host.load_ssl_checkpoint(trunk, str(path))
+    own = trunk.state_dict()
+    assert all(torch.equal(own[k], sd[k]) for k in own)  # layer 0 of the 2-layer file, heads ignored
+    torch.save({"model": {k: v for k, v in sd.items() if "fc2" not in k}}, path)
+    with pytest.raises(KeyError, match="lacks"):
+        host.load_ssl_checkpoint(trunk, str(path))

@@ -162,3 +162,34 @@ def test_dropin_models_package_teacher_and_student():
     # decides a near-tie on the odd utterance (seen: 2e-5 on one logit) -- hence 1e-4, not 1e-5, here;
     # the seeded-head fixtures above hold 1e-5
     assert (exact - oa.aasist_backend(head, ref_feats)).abs().max().item() <= 1e-4
+
+
+def test_teacher_to_student_layer_copy_like_main_kd():
+    """main_kd.py:127-141: ``student.load_state_dict(teacher.state_dict(), strict=False)`` followed by per-layer
+    ``student...encoder.layers[i].load_state_dict(teacher...encoder.layers[j].state_dict())`` works on the drop-in
+    modules as on the reference's, and the native engine picks the new weights up."""
+    from afx import synth
+    from models.conformer_baseline import MyModel
+    from oracle import models as omodels
+    torch.manual_seed(7)
+    teacher = MyModel(device="cuda", ssl_cpkt_path=None, num_layers=3, order="first", n_encoders=1).to("cuda").eval()
+    teacher.load_state_dict(synth.model_state_dict("ConformerModel", n_layers=3, n_encoders=1))
+    student = MyModel(device="cuda", ssl_cpkt_path=None, num_layers=2, order="first", n_encoders=1).to("cuda").eval()
+    wave = synth.waveforms(2, 16000, batch_idx=9)
+    with torch.no_grad():
+        before = student(wave.cuda()).cpu()
+    res = student.load_state_dict(teacher.state_dict(), strict=False)
+    assert not res.missing_keys and all("encoder.layers.2." in k for k in res.unexpected_keys)
+    order = [2, 0]  # custom_order_copy_weights
+    for i, j in enumerate(order):
+        student.ssl_model.model.encoder.layers[i].load_state_dict(teacher.ssl_model.model.encoder.layers[j].state_dict(), strict=False)
+    with torch.no_grad():
+        got = student(wave.cuda()).cpu()
+    assert (got - before).abs().max().item() > 1e-4  # the engine saw the new weights
+    tsd = {k: v.detach().cpu() for k, v in teacher.state_dict().items()}
+    want_sd = {k: v for k, v in tsd.items() if "encoder.layers." not in k}
+    for i, j in enumerate(order):
+        pre_t, pre_s = f"ssl_model.model.encoder.layers.{j}.", f"ssl_model.model.encoder.layers.{i}."
+        want_sd.update({pre_s + k[len(pre_t):]: v for k, v in tsd.items() if k.startswith(pre_t)})
+    ref = omodels.conformer_forward(want_sd, wave)
+    assert (got - ref).abs().max().item() <= 1e-3
