@@ -16,7 +16,7 @@
 #include "afx_kernels.h"
 
 #ifndef MHSA_DBG
-#define MHSA_DBG 0  // timing experiments only (wrong results): 1 no K/V staging, 2 no query-tile loop, 4 no V^T scatter
+#define MHSA_DBG 0  // timing experiments only (wrong results): 1 no K/V staging, 2 no query-tile loop, 4 no V^T scatter, 8 no exp, 16 no P.V, 32 no Q.K^T, 64 no stores
 #endif
 
 namespace afx {
@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) s[kp + u] = HT::mfma(cur[u][ks], qf[ks], s[kp + u]);
+        for (int u = 0; u < 2; ++u) {
+          if (MHSA_DBG & 32) asm volatile("" :: "v"(cur[u][ks]));
+          else s[kp + u] = HT::mfma(cur[u][ks], qf[ks], s[kp + u]);
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
     float mx = -1e30f;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = __expf(s[kt][r] - mx);
+        const float e = (MHSA_DBG & 8) ? s[kt][r] - mx : __expf(s[kt][r] - mx);
         s[kt][r] = e;
         sum += e;
       }
@@ -174,7 +177,10 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) o[nt] = HT::mfma(cur[nt], pf, o[nt]);  // O^T = V^T P^T: the lane keeps ONE query row
+      for (int nt = 0; nt < 4; ++nt) {  // O^T = V^T P^T: the lane keeps ONE query row
+        if (MHSA_DBG & 16) asm volatile("" :: "v"(cur[nt]), "v"(pf));
+        else o[nt] = HT::mfma(cur[nt], pf, o[nt]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     // o[nt][r] = O[q0 + ql][16nt + 4g + r]: 4 consecutive head dims of the lane's own query row,
@@ -191,7 +197,9 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
         va[r] = __uint_as_float(sw[0]);
         vb[r] = __uint_as_float(sw[1]);
       }
-      if (q < T) {
+      if (MHSA_DBG & 64) {
+        asm volatile("" :: "v"(va), "v"(vb));
+      } else if (q < T) {
         V8 hv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
