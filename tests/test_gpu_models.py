@@ -247,3 +247,37 @@ def test_streaming_scores_equal_the_reference_on_every_window(afx_mod):
         assert (got - ref).abs().max().item() <= SCORE_TOL, f"hop {step}"
     with pytest.raises(ValueError):
         sc.push(torch.zeros(S, H))
+
+
+def test_distributed_scoring_over_rccl_with_one_rank(afx_mod, tmp_path):
+    """afx.harness.produce_evaluation_file_distributed through the real RCCL backend (world size 1 on the
+    one GPU of this box: same code path as N ranks -- shard, score, all-gather of (index, score) pairs,
+    merge, write); the file must equal the single-process one."""
+    import torch.distributed as dist
+    engine, synth = afx_mod
+    from afx import harness
+    sd = synth.model_state_dict("ConformerModel", n_layers=1, n_encoders=1)
+    eng = engine.Engine("conformer", n_layers=1, dtype="fp16", conf_blocks=1)
+    eng.load_state_dict(sd)
+
+    class Toy(torch.utils.data.Dataset):
+        def __len__(self):
+            return 7
+
+        def __getitem__(self, i):
+            return f"utt{i}", synth.waveforms(1, 16000, batch_idx=300 + i)[0], 0
+
+    class Wrap(torch.nn.Module):
+        def forward(self, x):
+            return eng.forward(x)
+
+    ref_names, ref_scores = harness.produce_evaluation_file(Toy(), Wrap(), "cuda", str(tmp_path / "a.txt"), batch_size=3, num_workers=0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        idx, sc = harness.produce_evaluation_file_distributed(Toy(), Wrap(), "cuda", str(tmp_path / "b.txt"), batch_size=3, num_workers=0)
+    finally:
+        dist.destroy_process_group()
+    assert idx.tolist() == list(range(7))
+    assert (tmp_path / "a.txt").read_text() == (tmp_path / "b.txt").read_text()
+    assert [f"utt{i}" for i in range(7)] == ref_names and len(ref_scores) == 7
