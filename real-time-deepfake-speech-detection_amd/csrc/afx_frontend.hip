@@ -278,52 +278,62 @@ template <class HT>
 __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
   typedef typename HT::T T;
   typedef typename HT::V4 V4;
+  constexpr int RPW = 2;  // rows per wave: both rows' loads are in flight before either is reduced
   const int lane = threadIdx.x & 63;
-  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= a.rows) return;
-  const float* x = a.x + r * a.ldx;
-  f32x4 v[4];
-  float sum = 0.f;
+  const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  if (r0 >= a.rows) return;
+  f32x4 v[RPW][4];
+  bool live[RPW];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int c = (it * 64 + lane) * 4;
-    v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c < a.C) {
-      v[it] = *(const f32x4*)(x + c);
-      sum += v[it][0] + v[it][1] + v[it][2] + v[it][3];
+  for (int u = 0; u < RPW; ++u) {
+    live[u] = r0 + u < a.rows;
+    const float* x = a.x + (live[u] ? r0 + u : r0) * a.ldx;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      v[u][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < a.C) v[u][it] = *(const f32x4*)(x + c);
     }
   }
   const float inv = 1.0f / (float)a.C;
-  const float mean = wave_sum(sum) * inv;
-  float sq = 0.f;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int c = (it * 64 + lane) * 4;
-    if (c < a.C) {
+  for (int u = 0; u < RPW; ++u) {
+    if (!live[u]) continue;  // wave-uniform
+    const long r = r0 + u;
+    float sum = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        v[it][i] -= mean;
-        sq = fmaf(v[it][i], v[it][i], sq);
+    for (int it = 0; it < 4; ++it) sum += (v[u][it][0] + v[u][it][1]) + (v[u][it][2] + v[u][it][3]);
+    const float mean = wave_sum(sum) * inv;
+    float sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if (c < a.C) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[u][it][i] -= mean;
+          sq = fmaf(v[u][it][i], v[u][it][i], sq);
+        }
       }
     }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv + a.eps);
-  const long orow = (r / a.rpb) * a.o_batch_rows + (r % a.rpb) + a.o_row_off;
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv + a.eps);
+    const long orow = (r / a.rpb) * a.o_batch_rows + (r % a.rpb) + a.o_row_off;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int c = (it * 64 + lane) * 4;
-    if (c < a.C) {
-      const f32x4 g = *(const f32x4*)(a.gamma + c);
-      const f32x4 b = *(const f32x4*)(a.beta + c);
-      f32x4 y;
+    for (int it = 0; it < 4; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if (c < a.C) {
+        const f32x4 g = *(const f32x4*)(a.gamma + c);
+        const f32x4 b = *(const f32x4*)(a.beta + c);
+        f32x4 y;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) y[i] = apply_act(fmaf(v[it][i] * rstd, g[i], b[i]), a.act);
-      if (a.out_f) *(f32x4*)(a.out_f + orow * a.ldo_f + c) = y;
-      if (a.out_h) {
-        V4 h;
+        for (int i = 0; i < 4; ++i) y[i] = apply_act(fmaf(v[u][it][i] * rstd, g[i], b[i]), a.act);
+        if (a.out_f) *(f32x4*)(a.out_f + orow * a.ldo_f + c) = y;
+        if (a.out_h) {
+          V4 h;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) h[i] = (T)y[i];
-        *(V4*)((T*)a.out_h + orow * a.ldo_h + c) = h;
+          for (int i = 0; i < 4; ++i) h[i] = (T)y[i];
+          *(V4*)((T*)a.out_h + orow * a.ldo_h + c) = h;
+        }
       }
     }
   }
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
 const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
   if (a.rows <= 0 || a.C <= 0 || a.C > 1024 || a.C % 4) return "rownorm: need 0 < C <= 1024, C % 4 == 0";
   if (!a.out_f && !a.out_h) return "rownorm: no output";
-  dim3 grid((a.rows + 3) / 4);
+  dim3 grid((a.rows + 7) / 8);  // 4 waves x 2 rows
   AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL(rownorm_kernel<HT>, grid, dim3(256), 0, s, a));
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
