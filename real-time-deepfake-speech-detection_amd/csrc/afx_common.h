@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -23,6 +24,12 @@ struct BF16 {
   static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
+  // 32x32x16: the full-rate form (measured 1.94 PFLOP/s on random operands against 1.32 for 16x16x32,
+  // tools/peak_probe.hip).  A: lane (r = l&31, h = l>>5) holds A[r][8h + j]; B likewise B[8h + j][r];
+  // D: col = l&31, row = (reg&3) + 8 (reg>>2) + 4 (l>>5).
+  static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
 };
 struct FP16 {
   typedef _Float16 T;
@@ -30,6 +37,9 @@ struct FP16 {
   typedef f16x4 V4;
   static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
 };
 
@@ -137,6 +147,11 @@ __device__ __forceinline__ float xor32_partner(float v) {
 __device__ __forceinline__ float rows_sum(float v) {
   const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   v = __uint_as_float(s[0]) + __uint_as_float(s[1]);
+  const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+// sum over the lane pair {l, l ^ 32} (the two halves that share an output row of a 32x32 MFMA tile)
+__device__ __forceinline__ float pair_sum(float v) {
   const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }

@@ -1135,6 +1135,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
     gemm_set_split(value);
     return 0;
   }
+  if (!strcmp(key, "gemm_x32")) {
+    gemm_set_x32(value);
+    return 0;
+  }
   if (!strcmp(key, "gemm_deep")) {
     gemm_set_deep(value);
     return 0;

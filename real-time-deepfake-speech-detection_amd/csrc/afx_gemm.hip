@@ -306,6 +306,242 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Epilogue for accumulators of v_mfma_f32_32x32x16 (8-phase kernels, 2 x 4 waves).  With the operands
+// swapped (W fragment first) a lane holds, for tile (i, j) of the wave's block, output row
+// m = 32 i + (lane & 31) and columns 32 j + 8 q + 4 h + c in register 4 q + c (h = lane >> 5): four
+// quads of 4 consecutive columns.  v_permlane32_swap pairs quads 2p / 2p+1 across the two half-waves so
+// that every lane ends up with 8 consecutive columns starting at 16 p + 8 h (16-B fp16 / 32-B fp32
+// stores).  Same contract as gemm_epilogue: bias hoisted, residual rows prefetched one step ahead.
+// ---------------------------------------------------------------------------------------
+template <class HT, int BM, int BN, bool ROWLN>
+__device__ __forceinline__ void gemm_epilogue32(const GemmArgs& p, f32x16 (&acc)[BM / 2 / 32][BN / 4 / 32], char* smem,
+                                                int m0, int n0, int g) {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+  constexpr int WR = 2, WC = 4, WM = BM / WR, WN = BN / WC, MT = WM / 32, NT = WN / 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int l31 = lane & 31, h = lane >> 5;
+  auto swap_pair = [&](f32x4& a, f32x4& b) {  // quads 2p (a) and 2p+1 (b) -> this lane's 8 consecutive columns (a | b)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[c]), __float_as_uint(b[c]), false, false);
+      a[c] = __uint_as_float(sw[0]);
+      b[c] = __uint_as_float(sw[1]);
+    }
+  };
+  auto quad = [&](const f32x16& t, int q) { return f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]}; };
+  auto gelu4 = [&](f32x4& v) {
+    const f32x2_t a = gelu_erf2(f32x2_t{v[0], v[1]}), b = gelu_erf2(f32x2_t{v[2], v[3]});
+    v = f32x4{a[0], a[1], b[0], b[1]};
+  };
+  if constexpr (ROWLN) {
+    __syncthreads();  // every wave is done reading the last K-tile: this LDS region becomes scratch
+    float* red = (float*)smem;   // [WC][BM] partial row sums
+    float* vec = red + WC * BM;  // [3][BN]: bias, gamma, beta through LDS (one global round trip per workgroup)
+    for (int t = tid; t < BN; t += 64 * WR * WC) {
+      vec[t] = p.bias[n0 + t];
+      vec[BN + t] = p.ln_gamma[n0 + t];
+      vec[2 * BN + t] = p.ln_beta[n0 + t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *(const f32x4*)(vec + wc * WN + j * 32 + 8 * q + 4 * h);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] += b[c];
+      }
+    float mean[MT], rstd[MT];
+    const float invn = 1.0f / (float)BN;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm += acc[i][j][r];
+      sm = pair_sum(sm);
+      if (h == 0) red[wc * BM + wr * WM + i * 32 + l31] = sm;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = wr * WM + i * 32 + l31;
+      float sm = 0.f;
+#pragma unroll
+      for (int c = 0; c < WC; ++c) sm += red[c * BM + row];
+      mean[i] = sm * invn;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[i][j][r] -= mean[i];
+          sm = fmaf(acc[i][j][r], acc[i][j][r], sm);
+        }
+      sm = pair_sum(sm);
+      if (h == 0) red[wc * BM + wr * WM + i * 32 + l31] = sm;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = wr * WM + i * 32 + l31;
+      float sm = 0.f;
+#pragma unroll
+      for (int c = 0; c < WC; ++c) sm += red[c * BM + row];
+      rstd[i] = 1.0f / sqrtf(sm * invn + p.ln_eps);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        const int ca = wc * WN + j * 32 + 16 * pp + 4 * h, cb2 = ca + 8;  // columns of quads 2p and 2p+1 before the swap
+        const f32x4 ga0 = *(const f32x4*)(vec + BN + ca), be0 = *(const f32x4*)(vec + 2 * BN + ca);
+        const f32x4 ga1 = *(const f32x4*)(vec + BN + cb2), be1 = *(const f32x4*)(vec + 2 * BN + cb2);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int m = m0 + wr * WM + i * 32 + l31;
+          f32x4 va = quad(acc[i][j], 2 * pp), vb = quad(acc[i][j], 2 * pp + 1);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            va[c] = fmaf(va[c] * rstd[i], ga0[c], be0[c]);
+            vb[c] = fmaf(vb[c] * rstd[i], ga1[c], be1[c]);
+          }
+          if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
+            gelu4(va);
+            gelu4(vb);
+          } else if (p.act != ACT_NONE) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              va[c] = apply_act(va[c], p.act);
+              vb[c] = apply_act(vb[c], p.act);
+            }
+          }
+          swap_pair(va, vb);
+          if (p.dbg_nodma & 32) {  // timing only: no stores
+            asm volatile("" :: "v"(va), "v"(vb));
+            continue;
+          }
+          if (m >= p.M) continue;
+          const int n = n0 + wc * WN + j * 32 + 16 * pp + 8 * h;
+          const long orow = (long)(m / p.rpb) * p.o_batch_rows + (m % p.rpb) + p.o_row_off;
+          const long hrow = (long)(m / p.rpb) * p.oh_batch_rows + (m % p.rpb) + p.oh_row_off;
+          if (p.out_f) {
+            float* op = p.out_f + orow * p.ldo_f + n;
+            *(f32x4*)op = va;
+            *(f32x4*)(op + 4) = vb;
+          }
+          if (p.out_h) {
+            V8 hv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              hv[c] = (T)va[c];
+              hv[4 + c] = (T)vb[c];
+            }
+            *(V8*)((T*)p.out_h + hrow * p.ldo_h + n) = hv;
+          }
+        }
+      }
+    return;
+  } else {
+    const int gcol = g * p.g_n;
+    const float alpha = p.alpha;
+    f32x4 bia[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wc * WN + j * 32 + 8 * q + 4 * h;
+        bia[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bia[j][q] = *(const f32x4*)(p.bias + gcol + n);
+      }
+    const bool one_batch = p.rpb >= p.M;
+    auto row_of = [&](int i, long& orow, long& hrow, bool& mok) {
+      const int m = m0 + wr * WM + i * 32 + l31;
+      mok = m < p.M;
+      const int mc = mok ? m : p.M - 1;
+      const int bq = one_batch ? 0 : mc / p.rpb, br = one_batch ? mc : mc - bq * p.rpb;
+      orow = (long)bq * p.o_batch_rows + br + p.o_row_off;
+      hrow = (long)bq * p.oh_batch_rows + br + p.oh_row_off;
+    };
+    constexpr int STEPS = MT * NT * 2;
+    auto col_of = [&](int step) { return n0 + wc * WN + ((step >> 1) % NT) * 32 + 16 * (step & 1) + 8 * h; };
+    auto load_resid = [&](int step, f32x4 (&r)[2]) {
+      long orow, hrow;
+      bool mok;
+      row_of(step / (2 * NT), orow, hrow, mok);
+      const int n = col_of(step);
+      r[0] = r[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (mok && n < p.N) {
+        const float* rp = p.resid + orow * p.ldr + gcol + n;
+        r[0] = *(const f32x4*)rp;
+        r[1] = *(const f32x4*)(rp + 4);
+      }
+    };
+    f32x4 rcur[2], rnxt[2];
+    if (p.resid) load_resid(0, rcur);
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+      const int i = step / (2 * NT), j = (step >> 1) % NT, pp = step & 1;
+      if (p.resid && step + 1 < STEPS) load_resid(step + 1, rnxt);
+      long orow, hrow;
+      bool mok;
+      row_of(i, orow, hrow, mok);
+      f32x4 va = quad(acc[i][j], 2 * pp) + bia[j][2 * pp], vb = quad(acc[i][j], 2 * pp + 1) + bia[j][2 * pp + 1];
+      if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
+        gelu4(va);
+        gelu4(vb);
+      } else if (p.act != ACT_NONE && !(p.dbg_nodma & 8)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          va[c] = apply_act(va[c], p.act);
+          vb[c] = apply_act(vb[c], p.act);
+        }
+      }
+      if (alpha != 1.f) {
+        va *= alpha;
+        vb *= alpha;
+      }
+      swap_pair(va, vb);
+      const int n = col_of(step);
+      if (p.dbg_nodma & 32) {  // timing only: no stores
+        asm volatile("" :: "v"(va), "v"(vb));
+      } else if (mok && n < p.N) {
+        if (p.resid) {
+          va += rcur[0];
+          vb += rcur[1];
+        }
+        if (p.out_f) {
+          float* op = p.out_f + orow * p.ldo_f + gcol + n;
+          *(f32x4*)op = va;
+          *(f32x4*)(op + 4) = vb;
+        }
+        if (p.out_h) {
+          V8 hv;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            hv[c] = (T)va[c];
+            hv[4 + c] = (T)vb[c];
+          }
+          *(V8*)((T*)p.out_h + hrow * p.ldo_h + gcol + n) = hv;
+        }
+      }
+      rcur[0] = rnxt[0];
+      rcur[1] = rnxt[1];
+    }
+  }
+}
+
 // WR x WC waves per workgroup; each wave owns a (BM/WR) x (BN/WC) block of the tile.
 // ROWLN: the tile spans the whole output row (BN == N), and the epilogue applies
 // LayerNorm over the row (two-pass fp32 statistics, partial sums exchanged through LDS
@@ -506,7 +742,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 //        were retired before the reading phase's first barrier (B0: ph1 reads are issued
 //        first and retired by lgkmcnt(8) there -> staged in ph2).
 // =======================================================================================
-template <class HT, int BM, int BN, bool ROWLN>
+template <class HT, int BM, int BN, bool ROWLN, bool X32>
 __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
@@ -519,11 +755,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   //     phase 4: --                stage R1(t+2)   MFMA (F1,R0)
   constexpr bool WIDE = BN > BM;              // A is the resident operand
   constexpr int RA = BM / 2, RB = BN / 2;     // rows of an A / B half-tile
-  constexpr int MTH = RA / 2 / 16, NTH = RB / 4 / 16;  // 16-row fragments per half per wave
+  // X32: v_mfma_f32_32x32x16 (32-row fragments, 4 k-steps of 16 per K-tile) -- the full-rate instruction;
+  // otherwise v_mfma_f32_16x16x32 (16-row fragments, 2 k-steps of 32), which issues at half that rate.
+  constexpr int FR = X32 ? 32 : 16, KSN = X32 ? 4 : 2;
+  constexpr int MTH = RA / 2 / FR, NTH = RB / 4 / FR;  // fragments per half per wave
   constexpr int DA = RA / 64, DB = RB / 64;   // LDS-DMA instructions per thread per half-tile
   constexpr int OFF_A0 = 0, OFF_A1 = RA * 128, OFF_B0 = 2 * RA * 128, OFF_B1 = OFF_B0 + RB * 128;
   constexpr int BUF = 2 * (RA + RB) * 128;
-  static_assert((WIDE ? MTH : NTH) == 2 && (WIDE ? NTH : MTH) == 4, "resident operand: 4 reads per half, flowing: 8");
+  static_assert((WIDE ? MTH : NTH) * KSN == 4 && (WIDE ? NTH : MTH) * KSN == 8, "resident operand: 4 reads per half, flowing: 8");
   static_assert(2 * (WIDE ? DA : DB) + (WIDE ? DB : DA) == 6, "vmcnt(6) leaves R0, F0, R1 of tile t+2 in flight");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -602,40 +841,48 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     for (int i = 0; i < DB; ++i) dma16(srcB[h][i] + kt * 64, buf * BUF + (h ? OFF_B1 : OFF_B0) + (i * 8 + wave) * 1024);
   };
 
-  // fragment read addresses (bytes): row (lane & 15) of a 16-row tile, logical chunk ks*4 + lane>>4
-  const int frow = lane & 15, fsw = (frow >> 1) & 7, kq = lane >> 4;
-  const int slot[2] = {(kq ^ fsw) * 16, ((4 + kq) ^ fsw) * 16};
+  // fragment read addresses (bytes): row (lane & (FR-1)) of an FR-row tile; the lane's 8 k-values of k-step
+  // ks are logical chunk ks * (64 / 8 / KSN) + (lane / FR)
+  const int frow = lane & (FR - 1), fsw = (frow >> 1) & 7, kq = lane / FR;
+  int slot[KSN];
+#pragma unroll
+  for (int ks = 0; ks < KSN; ++ks) slot[ks] = ((ks * (8 / KSN) + kq) ^ fsw) * 16;
   const char* aR = smem + (wr * (RA / 2) + frow) * 128;
   const char* bR = smem + (wc * (RB / 4) + frow) * 128;
 
-  f32x4 acc[2 * MTH][2 * NTH];
+  typename std::conditional<X32, f32x16, f32x4>::type acc[2 * MTH][2 * NTH];
   // the resident operand keeps both halves in registers, the flowing one a single half
-  V8 af[WIDE ? 2 : 1][MTH][2], wf[WIDE ? 1 : 2][NTH][2];
+  V8 af[WIDE ? 2 : 1][MTH][KSN], wf[WIDE ? 1 : 2][NTH][KSN];
 
   auto readA = [&](int buf, int h) {
 #pragma unroll
     for (int mi = 0; mi < MTH; ++mi)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        af[WIDE ? h : 0][mi][ks] = *(const V8*)(aR + buf * BUF + (h ? OFF_A1 : OFF_A0) + mi * 2048 + slot[ks]);
+      for (int ks = 0; ks < KSN; ++ks)
+        af[WIDE ? h : 0][mi][ks] = *(const V8*)(aR + buf * BUF + (h ? OFF_A1 : OFF_A0) + mi * (FR * 128) + slot[ks]);
   };
   auto readB = [&](int buf, int h) {
 #pragma unroll
     for (int nj = 0; nj < NTH; ++nj)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        wf[WIDE ? 0 : h][nj][ks] = *(const V8*)(bR + buf * BUF + (h ? OFF_B1 : OFF_B0) + nj * 2048 + slot[ks]);
+      for (int ks = 0; ks < KSN; ++ks)
+        wf[WIDE ? 0 : h][nj][ks] = *(const V8*)(bR + buf * BUF + (h ? OFF_B1 : OFF_B0) + nj * (FR * 128) + slot[ks]);
   };
   auto quadrant = [&](int ah, int bh) {  // 16 MFMAs: (A half ah) x (B half bh) x K = 64
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KSN; ++ks)
 #pragma unroll
       for (int mi = 0; mi < MTH; ++mi)
 #pragma unroll
-        for (int nj = 0; nj < NTH; ++nj)
-          acc[ah * MTH + mi][bh * NTH + nj] =
-              HT::mfma(wf[WIDE ? 0 : bh][nj][ks], af[WIDE ? ah : 0][mi][ks], acc[ah * MTH + mi][bh * NTH + nj]);
+        for (int nj = 0; nj < NTH; ++nj) {
+          if constexpr (X32)
+            acc[ah * MTH + mi][bh * NTH + nj] =
+                HT::mfma32(wf[WIDE ? 0 : bh][nj][ks], af[WIDE ? ah : 0][mi][ks], acc[ah * MTH + mi][bh * NTH + nj]);
+          else
+            acc[ah * MTH + mi][bh * NTH + nj] =
+                HT::mfma(wf[WIDE ? 0 : bh][nj][ks], af[WIDE ? ah : 0][mi][ks], acc[ah * MTH + mi][bh * NTH + nj]);
+        }
     __builtin_amdgcn_s_setprio(0);
   };
   // R / F views of the two operands
@@ -725,7 +972,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 2 * MTH; ++i)
 #pragma unroll
-      for (int j = 0; j < 2 * NTH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 2 * NTH; ++j) acc[i][j] = 0.f;
     for (int t = 0; t < nk; t += 2) {
       ktile(std::integral_constant<int, 0>{}, t);
       if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
@@ -744,9 +991,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < 2 * MTH; ++i)
 #pragma unroll
-        for (int j = 0; j < 2 * NTH; ++j) asm volatile("" :: "v"(acc[i][j]));
+        for (int j = 0; j < 2 * NTH; ++j)  // (element-wise: a 512-bit "v" operand is not a valid constraint in the host pass)
+#pragma unroll
+          for (int r = 0; r < (X32 ? 16 : 4); ++r) asm volatile("" :: "v"(acc[i][j][r]));
     } else {
-      gemm_epilogue<HT, BM, BN, 2, 4, ROWLN>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
+      if constexpr (X32) gemm_epilogue32<HT, BM, BN, ROWLN>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
+      else gemm_epilogue<HT, BM, BN, 2, 4, ROWLN>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
     }
     if (vn >= nwg) break;
     v = vn;
@@ -754,13 +1004,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 #undef AFX_BAR
 }
 
-template <class HT, int BM, int BN, bool ROWLN>
+template <class HT, int BM, int BN, bool ROWLN, bool X32>
 static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static_assert(lds <= 160 * 1024, "two K-tile buffers must fit the 160 KB LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm8_kernel<HT, BM, BN, ROWLN>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm8_kernel<HT, BM, BN, ROWLN, X32>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -775,7 +1025,7 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   }
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
   dim3 grid(tiles < n_cu ? tiles : n_cu, 1, groups);  // persistent: at most one workgroup per CU
-  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN>), grid, dim3(512), lds, s, p);
+  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN, X32>), grid, dim3(512), lds, s, p);
   return hipGetLastError();
 }
 
@@ -803,6 +1053,8 @@ static int g_ant_override = -1;  // non-temporal A loads: -1 auto (row-complete 
 void gemm_set_a_nt(int v) { g_ant_override = v; }
 static int g_deep = -1;  // row-complete conv tile: 0 = 2-stage kernel, otherwise (default) the 8-phase kernel (A/B knob)
 void gemm_set_deep(int v) { g_deep = v; }
+static int g_x32 = 1;  // 8-phase kernels: 1 = v_mfma 32x32x16 (full rate), 0 = 16x16x32 (A/B knob)
+void gemm_set_x32(int v) { g_x32 = v != 0; }
 static int g_nodma = 0;  // timing-only epilogue knob bits (GemmArgs::dbg_nodma; WRONG results when set)
 void gemm_set_nodma(int v) { g_nodma = v; }
 
@@ -877,8 +1129,8 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
     case 4: return launch_gemm_t<HT, 256, 128, 4, 2>(p, groups, s);
-    case 7: return launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
-    case 8: return launch_gemm8_t<HT, 128, 512, true>(p, groups, s);
+    case 7: return g_x32 ? launch_gemm8_t<HT, 256, 256, false, true>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false, false>(p, groups, s);
+    case 8: return g_x32 ? launch_gemm8_t<HT, 128, 512, true, true>(p, groups, s) : launch_gemm8_t<HT, 128, 512, true, false>(p, groups, s);
     default: return launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
   }
 }
