@@ -1053,7 +1053,7 @@ static int g_ant_override = -1;  // non-temporal A loads: -1 auto (row-complete 
 void gemm_set_a_nt(int v) { g_ant_override = v; }
 static int g_deep = -1;  // row-complete conv tile: 0 = 2-stage kernel, otherwise (default) the 8-phase kernel (A/B knob)
 void gemm_set_deep(int v) { g_deep = v; }
-static int g_x32 = 1;  // 8-phase kernels: 1 = v_mfma 32x32x16 (full rate), 0 = 16x16x32 (A/B knob)
+static int g_x32 = 0;  // 8-phase kernels: 0 = v_mfma 16x16x32 (default: its 512-cycle segments balance the schedule), 1 = 32x32x16 (A/B knob)
 void gemm_set_x32(int v) { g_x32 = v != 0; }
 static int g_nodma = 0;  // timing-only epilogue knob bits (GemmArgs::dbg_nodma; WRONG results when set)
 void gemm_set_nodma(int v) { g_nodma = v; }
