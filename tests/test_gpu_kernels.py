@@ -98,7 +98,7 @@ def test_gemm_8phase_kernel_is_bit_identical_to_the_2stage_kernel(K, M, N, K_):
         for _ in range(12):
             got, _ = K.gemm("fp16", A, W, bias=bias, act="gelu")
             assert torch.equal(got, want)
-        # 32x32x16 form (the default): another summation order, so close to `want`, and -- the race
+        # 32x32x16 form (knob): another summation order, so close to `want`, and -- the race
         # screen -- identical to itself launch after launch
         check(lib().afx_debug_set(b"gemm_x32", 1))
         first, _ = K.gemm("fp16", A, W, bias=bias, act="gelu")
@@ -108,7 +108,7 @@ def test_gemm_8phase_kernel_is_bit_identical_to_the_2stage_kernel(K, M, N, K_):
             assert torch.equal(got, first)
     finally:
         check(lib().afx_debug_set(b"gemm_tile", -1))
-        check(lib().afx_debug_set(b"gemm_x32", 1))
+        check(lib().afx_debug_set(b"gemm_x32", 0))
 
 
 @pytest.mark.parametrize("M,N,K_,resid", [(12736, 3072, 1024, False), (12736, 4096, 1024, False), (6500, 2048, 512, True)])
@@ -133,7 +133,7 @@ def test_gemm_round_split_matches_the_single_kernel(K, M, N, K_, resid):
         assert torch.equal(got_f, want_f)
         # default dispatch (split, 32x32x16 form): close to the single-kernel result and deterministic
         check(lib().afx_debug_set(b"gemm_split", 1))
-        check(lib().afx_debug_set(b"gemm_x32", 1))
+        check(lib().afx_debug_set(b"gemm_x32", 0))
         a_f, a_h = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
         _close(a_f, want_f, 1e-4, 2e-4)
         _close(a_h, want_h, 4e-3, 1e-3)
@@ -142,7 +142,7 @@ def test_gemm_round_split_matches_the_single_kernel(K, M, N, K_, resid):
     finally:
         check(lib().afx_debug_set(b"gemm_tile", -1))
         check(lib().afx_debug_set(b"gemm_split", 1))
-        check(lib().afx_debug_set(b"gemm_x32", 1))
+        check(lib().afx_debug_set(b"gemm_x32", 0))
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -224,7 +224,7 @@ def test_conv_layernorm_8phase_tile_is_bit_identical_to_the_2stage_tile(K):
             for _ in range(8):
                 got, _ = K.conv_ln_act("fp16", x, wp, k, 2, bias, ga, be, out_f=True, out_h=False)
                 assert torch.equal(got, want)
-            check(lib().afx_debug_set(b"gemm_x32", 1))  # default 32x32x16 form: close, and deterministic
+            check(lib().afx_debug_set(b"gemm_x32", 1))  # 32x32x16 form: close, and deterministic
             first, _ = K.conv_ln_act("fp16", x, wp, k, 2, bias, ga, be, out_f=True, out_h=False)
             _close(first, want, 2e-4, 2e-4)
             for _ in range(8):
@@ -232,7 +232,7 @@ def test_conv_layernorm_8phase_tile_is_bit_identical_to_the_2stage_tile(K):
                 assert torch.equal(got, first)
         finally:
             check(lib().afx_debug_set(b"gemm_deep", -1))
-            check(lib().afx_debug_set(b"gemm_x32", 1))
+            check(lib().afx_debug_set(b"gemm_x32", 0))
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -97,7 +97,7 @@ def main():
     check(lib().afx_debug_set(b"gemm_nodma", 0))
     check(lib().afx_debug_set(b"gemm_deep", -1))
     check(lib().afx_debug_set(b"gemm_split", 1))
-    check(lib().afx_debug_set(b"gemm_x32", 1))
+    check(lib().afx_debug_set(b"gemm_x32", 0))
 
 
 if __name__ == "__main__":
