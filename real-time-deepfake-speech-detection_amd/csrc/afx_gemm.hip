@@ -314,12 +314,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 // that every lane ends up with 8 consecutive columns starting at 16 p + 8 h (16-B fp16 / 32-B fp32
 // stores).  Same contract as gemm_epilogue: bias hoisted, residual rows prefetched one step ahead.
 // ---------------------------------------------------------------------------------------
-template <class HT, int BM, int BN, bool ROWLN>
-__device__ __forceinline__ void gemm_epilogue32(const GemmArgs& p, f32x16 (&acc)[BM / 2 / 32][BN / 4 / 32], char* smem,
+template <class HT, int BM, int BN, bool ROWLN, int WR = 2, int WC = 4>
+__device__ __forceinline__ void gemm_epilogue32(const GemmArgs& p, f32x16 (&acc)[BM / WR / 32][BN / WC / 32], char* smem,
                                                 int m0, int n0, int g) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
-  constexpr int WR = 2, WC = 4, WM = BM / WR, WN = BN / WC, MT = WM / 32, NT = WN / 32;
+  constexpr int WM = BM / WR, WN = BN / WC, MT = WM / 32, NT = WN / 32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WC, wc = wave % WC;
@@ -420,12 +420,6 @@ __device__ __forceinline__ void gemm_epilogue32(const GemmArgs& p, f32x16 (&acc)
           if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
             gelu4(va);
             gelu4(vb);
-          } else if (p.act != ACT_NONE) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              va[c] = apply_act(va[c], p.act);
-              vb[c] = apply_act(vb[c], p.act);
-            }
           }
           swap_pair(va, vb);
           if (p.dbg_nodma & 32) {  // timing only: no stores
@@ -491,23 +485,21 @@ __device__ __forceinline__ void gemm_epilogue32(const GemmArgs& p, f32x16 (&acc)
     f32x4 rcur[2], rnxt[2];
     if (p.resid) load_resid(0, rcur);
 #pragma unroll
-    for (int step = 0; step < STEPS; ++step) {
-      const int i = step / (2 * NT), j = (step >> 1) % NT, pp = step & 1;
-      if (p.resid && step + 1 < STEPS) load_resid(step + 1, rnxt);
+    for (int i = 0; i < MT; ++i) {
       long orow, hrow;
       bool mok;
       row_of(i, orow, hrow, mok);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {  // (nested so that each level unrolls fully: one flat 2 MT NT loop does not at 4 x 4)
+      const int step = (i * NT + j) * 2 + pp;
+      if (p.resid && step + 1 < STEPS) load_resid(step + 1, rnxt);
       f32x4 va = quad(acc[i][j], 2 * pp) + bia[j][2 * pp], vb = quad(acc[i][j], 2 * pp + 1) + bia[j][2 * pp + 1];
       if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
         gelu4(va);
         gelu4(vb);
-      } else if (p.act != ACT_NONE && !(p.dbg_nodma & 8)) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          va[c] = apply_act(va[c], p.act);
-          vb[c] = apply_act(vb[c], p.act);
-        }
-      }
+      }  // (other activations: the launcher keeps them on the 16x16x32 kernels)
       if (alpha != 1.f) {
         va *= alpha;
         vb *= alpha;
@@ -538,6 +530,7 @@ __device__ __forceinline__ void gemm_epilogue32(const GemmArgs& p, f32x16 (&acc)
       }
       rcur[0] = rnxt[0];
       rcur[1] = rnxt[1];
+    }
     }
   }
 }
@@ -1029,6 +1022,166 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   return hipGetLastError();
 }
 
+// =======================================================================================
+// Full-rate tile kernel: v_mfma_f32_32x32x16 with ONE wave per SIMD.
+// tools/peak_probe.hip: the 16x16x32 instruction issues at half the rate of 32x32x16 (1.32 against 1.94
+// PFLOP/s sustained on random operands), so every kernel above tops out near 1.3 PFLOP/s however well
+// it is scheduled; and the 8-phase schedule cannot simply switch instruction -- its MFMA segments halve
+// to 256 cycles and no longer cover the other wave row's LDS reads (measured slower, profiles/).
+// Here 4 waves (one per SIMD, up to 512 registers each) own 128 x 128 outputs apiece: 16 accumulator tiles
+// (256 registers), 8 fragment reads per 16 MFMAs, issued one k-step (16 wide) ahead into a second register
+// set so that a wave's own LDS reads ride in the shadow of its MFMAs.  Two 64-wide K-tiles in LDS; the
+// operand DMA of tile t+2 goes out, and the first fragments of tile t+1 are requested, just before the LAST
+// k-step of tile t (one barrier + one vmcnt(0) per K-tile, both already satisfied in steady state).
+// Instances: 256 x 256 (2 x 2 waves) and the row-complete 128 x 512 conv tile (1 x 4 waves).
+// MEASURED (profiles/r01_gemm32_ab.txt): correct and deterministic, but 1.10 PFLOP/s at 8192^3 against 1.30
+// for the 8-phase 16x16x32 kernel, and 15-25 % slower on the path's K = 1024 / 1536 shapes: with one wave
+// per SIMD nothing covers the wave's own barrier + 16 DMA issues per K-tile (~300 of 2048 cycles) or its
+// epilogue.  Kept behind the gemm_x32 = 2 knob as the A/B baseline for the next attempt (DMA and fragment
+// reads slotted between the MFMAs); the default dispatch does not use it.
+// =======================================================================================
+template <class HT, int BM, int BN, int WR, int WC, bool ROWLN>
+__global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs p) {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+  constexpr int NW = WR * WC;
+  static_assert(NW == 4, "one wave per SIMD");
+  constexpr int WM = BM / WR, WN = BN / WC, MT = WM / 32, NT = WN / 32;
+  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+  constexpr int AI = BM / (8 * NW), WI = BN / (8 * NW);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int g = blockIdx.z;
+  int pm, pn;
+  {
+    const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
+    const int nwg = nM * nN;
+    int L = blockIdx.x;
+    if (p.map_mode >= 1) {
+      const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    }
+    if (p.map_mode == 2) {
+      constexpr int GM = 8;
+      const int width = GM * nN, grp = L / width, first = grp * GM;
+      const int gsz = nM - first < GM ? nM - first : GM;
+      pm = first + (L % width) % gsz;
+      pn = (L % width) / gsz;
+    } else {
+      pm = L / nN;
+      pn = L % nN;
+    }
+  }
+  const int m0 = pm * BM, n0 = pn * BN;
+  const T* Ag = (const T*)p.A + (long)g * p.g_a;
+  const T* Wg = (const T*)p.W + (long)g * p.g_w;
+  const T* a_src[AI];
+  const T* w_src[WI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;
+    a_src[i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int n = n0 + row;
+    n = n < p.N ? n : p.N - 1;
+    w_src[i] = Wg + (long)n * p.ldw + c * 8;
+  }
+  const unsigned lds_base = (unsigned)(size_t)smem;
+  auto dma16 = [&](const T* src, unsigned lds_off) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + lds_off);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
+  auto stage = [&](int buf, int kt) {
+    const unsigned base = (unsigned)(buf * STAGE);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) dma16(a_src[i] + kt * 64, base + (i * NW + wave) * 1024);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) dma16(w_src[i] + kt * 64, base + A_BYTES + (i * NW + wave) * 1024);
+  };
+  // fragment reads: lane (r = l & 31, h = l >> 5) takes row r of a 32-row tile, k = 16 ks + 8 h .. +7
+  const int l31 = lane & 31, hh = lane >> 5, fsw = (l31 >> 1) & 7;
+  const int a_off = (wr * WM + l31) * 128, w_off = A_BYTES + (wc * WN + l31) * 128;
+  int slot[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) slot[ks] = ((2 * ks + hh) ^ fsw) * 16;
+  V8 af[2][MT], wf[2][NT];
+  auto read_frags = [&](int buf, int ks, int set) {
+    const char* sb = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wf[set][j] = *(const V8*)(sb + w_off + j * 32 * 128 + slot[ks]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[set][i] = *(const V8*)(sb + a_off + i * 32 * 128 + slot[ks]);
+  };
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = 0.f;
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma32(wf[set][j], af[set][i], acc[i][j]);
+  };
+
+  const int nk = p.K >> 6;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (nk > 1) stage(1, 1);
+  read_frags(0, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      read_frags(buf, ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kt + 1 < nk) {
+      // every wave has its last fragments of this tile; tile kt+1 has landed; its first fragments and the
+      // DMA of tile kt+2 (into this tile's buffer) are requested before the last k-step's MFMAs
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 2 < nk) stage(buf, kt + 2);
+      read_frags(buf ^ 1, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  gemm_epilogue32<HT, BM, BN, ROWLN, WR, WC>(p, acc, smem, m0, n0, g);
+}
+
+template <class HT, int BM, int BN, int WR, int WC, bool ROWLN>
+static hipError_t launch_gemm32_t(const GemmArgs& p, int groups, hipStream_t s) {
+  constexpr int lds = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm32_kernel<HT, BM, BN, WR, WC, ROWLN>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
+  hipLaunchKernelGGL((gemm32_kernel<HT, BM, BN, WR, WC, ROWLN>), grid, dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
 template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false>
 static hipError_t launch_gemm_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
@@ -1054,7 +1207,7 @@ void gemm_set_a_nt(int v) { g_ant_override = v; }
 static int g_deep = -1;  // row-complete conv tile: 0 = 2-stage kernel, otherwise (default) the 8-phase kernel (A/B knob)
 void gemm_set_deep(int v) { g_deep = v; }
 static int g_x32 = 0;  // 8-phase kernels: 0 = v_mfma 16x16x32 (default: its 512-cycle segments balance the schedule), 1 = 32x32x16 (A/B knob)
-void gemm_set_x32(int v) { g_x32 = v != 0; }
+void gemm_set_x32(int v) { g_x32 = v; }  // 2 = the one-wave-per-SIMD 32x32x16 kernel (gemm32_kernel)
 static int g_nodma = 0;  // timing-only epilogue knob bits (GemmArgs::dbg_nodma; WRONG results when set)
 void gemm_set_nodma(int v) { g_nodma = v; }
 
@@ -1129,8 +1282,16 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
     case 4: return launch_gemm_t<HT, 256, 128, 4, 2>(p, groups, s);
-    case 7: return g_x32 ? launch_gemm8_t<HT, 256, 256, false, true>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false, false>(p, groups, s);
-    case 8: return g_x32 ? launch_gemm8_t<HT, 128, 512, true, true>(p, groups, s) : launch_gemm8_t<HT, 128, 512, true, false>(p, groups, s);
+    case 7: {
+      const int x = (p.act == ACT_NONE || p.act == ACT_GELU) ? g_x32 : 0;  // the 32x32 epilogue carries these two only
+      if (x == 2) return launch_gemm32_t<HT, 256, 256, 2, 2, false>(p, groups, s);
+      return x ? launch_gemm8_t<HT, 256, 256, false, true>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false, false>(p, groups, s);
+    }
+    case 8: {
+      const int x = (p.act == ACT_NONE || p.act == ACT_GELU) ? g_x32 : 0;
+      if (x == 2) return launch_gemm32_t<HT, 128, 512, 1, 4, true>(p, groups, s);
+      return x ? launch_gemm8_t<HT, 128, 512, true, true>(p, groups, s) : launch_gemm8_t<HT, 128, 512, true, false>(p, groups, s);
+    }
     default: return launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
   }
 }

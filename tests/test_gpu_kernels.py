@@ -100,12 +100,13 @@ def test_gemm_8phase_kernel_is_bit_identical_to_the_2stage_kernel(K, M, N, K_):
             assert torch.equal(got, want)
         # 32x32x16 form (knob): another summation order, so close to `want`, and -- the race
         # screen -- identical to itself launch after launch
-        check(lib().afx_debug_set(b"gemm_x32", 1))
-        first, _ = K.gemm("fp16", A, W, bias=bias, act="gelu")
-        _close(first, want, 1e-4, 2e-4)
-        for _ in range(12):
-            got, _ = K.gemm("fp16", A, W, bias=bias, act="gelu")
-            assert torch.equal(got, first)
+        for x32 in (1, 2):  # 1: inside the 8-phase schedule; 2: the one-wave-per-SIMD kernel (gemm32_kernel)
+            check(lib().afx_debug_set(b"gemm_x32", x32))
+            first, _ = K.gemm("fp16", A, W, bias=bias, act="gelu")
+            _close(first, want, 1e-4, 2e-4)
+            for _ in range(12):
+                got, _ = K.gemm("fp16", A, W, bias=bias, act="gelu")
+                assert torch.equal(got, first)
     finally:
         check(lib().afx_debug_set(b"gemm_tile", -1))
         check(lib().afx_debug_set(b"gemm_x32", 0))
@@ -133,12 +134,13 @@ def test_gemm_round_split_matches_the_single_kernel(K, M, N, K_, resid):
         assert torch.equal(got_f, want_f)
         # the split with the 32x32x16 form of the 8-phase kernel: close to the single-kernel result and deterministic
         check(lib().afx_debug_set(b"gemm_split", 1))
-        check(lib().afx_debug_set(b"gemm_x32", 1))
-        a_f, a_h = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
-        _close(a_f, want_f, 1e-4, 2e-4)
-        _close(a_h, want_h, 4e-3, 1e-3)
-        b_f, b_h = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
-        assert torch.equal(a_f, b_f) and torch.equal(a_h, b_h)
+        for x32 in (1, 2):
+            check(lib().afx_debug_set(b"gemm_x32", x32))
+            a_f, a_h = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
+            _close(a_f, want_f, 1e-4, 2e-4)
+            _close(a_h, want_h, 4e-3, 1e-3)
+            b_f, b_h = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
+            assert torch.equal(a_f, b_f) and torch.equal(a_h, b_h)
     finally:
         check(lib().afx_debug_set(b"gemm_tile", -1))
         check(lib().afx_debug_set(b"gemm_split", 1))
@@ -224,12 +226,14 @@ def test_conv_layernorm_8phase_tile_is_bit_identical_to_the_2stage_tile(K):
             for _ in range(8):
                 got, _ = K.conv_ln_act("fp16", x, wp, k, 2, bias, ga, be, out_f=True, out_h=False)
                 assert torch.equal(got, want)
-            check(lib().afx_debug_set(b"gemm_x32", 1))  # 32x32x16 form: close, and deterministic
-            first, _ = K.conv_ln_act("fp16", x, wp, k, 2, bias, ga, be, out_f=True, out_h=False)
-            _close(first, want, 2e-4, 2e-4)
-            for _ in range(8):
-                got, _ = K.conv_ln_act("fp16", x, wp, k, 2, bias, ga, be, out_f=True, out_h=False)
-                assert torch.equal(got, first)
+            for x32 in (1, 2):  # 32x32x16 forms: close, and deterministic
+                check(lib().afx_debug_set(b"gemm_x32", x32))
+                first, firsth = K.conv_ln_act("fp16", x, wp, k, 2, bias, ga, be, out_f=True, out_h=True)
+                _close(first, want, 2e-4, 2e-4)
+                _close(firsth, want, 4e-3, 1e-3)
+                for _ in range(8):
+                    got, _ = K.conv_ln_act("fp16", x, wp, k, 2, bias, ga, be, out_f=True, out_h=False)
+                    assert torch.equal(got, first)
         finally:
             check(lib().afx_debug_set(b"gemm_deep", -1))
             check(lib().afx_debug_set(b"gemm_x32", 0))

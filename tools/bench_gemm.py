@@ -31,8 +31,9 @@ SHAPES = [
 SETS = {
     "tile": [("128x128", ("gemm_tile", 0)), ("256x128", ("gemm_tile", 2)), ("256x256", ("gemm_tile", 1))],
     "8ph": [("128x128", ("gemm_tile", 0)), ("256x256 2-stage", ("gemm_tile", 1)), ("256x256 8-phase", ("gemm_tile", 3))],
-    "x32": [("8-phase 16x16x32", [("gemm_tile", 3), ("gemm_x32", 0)]), ("8-phase 32x32x16", [("gemm_tile", 3), ("gemm_x32", 1)])],
-    "x32ln": [("16x16x32", ("gemm_x32", 0)), ("32x32x16", ("gemm_x32", 1))],
+    "x32": [("8-phase 16x16x32", [("gemm_tile", 3), ("gemm_x32", 0)]), ("8-phase 32x32x16", [("gemm_tile", 3), ("gemm_x32", 1)]),
+            ("1 wave/SIMD 32x32x16", [("gemm_tile", 3), ("gemm_x32", 2)])],
+    "x32ln": [("16x16x32", ("gemm_x32", 0)), ("32x32x16", ("gemm_x32", 1)), ("1 wave/SIMD 32x32x16", ("gemm_x32", 2))],
     "split": [("single kernel", ("gemm_split", 0)), ("rounds + remainder", ("gemm_split", 1))],
     "map": [("map0", ("gemm_map", 0)), ("map1", ("gemm_map", 1)), ("map2", ("gemm_map", 2))],
     "nt": [("A default", ("gemm_a_nt", 0)), ("A nt", ("gemm_a_nt", 1))],
