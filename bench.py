@@ -36,6 +36,9 @@ import torch  # noqa: E402
 
 # dense matrix-core peaks, MI355X_MICROARCH.md "Chip-level parameters" (fp32: the exact-mode MFMA, 1/16 of fp16)
 MFMA_PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}
+# measured issue ceiling of the instruction the GEMM kernels use (v_mfma_f32_16x16x32_{f16,bf16} issues at half
+# the rate of 32x32x16; v_mfma_f32_16x16x4_f32 for exact mode): tools/peak_probe.hip, profiles/r01_peak_probe.txt
+MFMA_INSTR_CEILING_TFLOPS = {"fp16": 1316.7, "bf16": 1316.7, "fp32": 135.0}
 
 WORKLOADS = {
     # name: (engine arch, oracle model name, trunk layers, GFLOP per utterance)
@@ -135,6 +138,11 @@ def main():
         "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
         "all_gemm_instances_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
     }
+    # what the MFMA instruction these kernels issue sustains on this chip with nothing else in the loop
+    # (tools/peak_probe.hip, random operands, profiles/r01_peak_probe.txt); `peak`/`frac` stay the nominal ones
+    if args.dtype in MFMA_INSTR_CEILING_TFLOPS:
+        roofline["instr_ceiling"] = MFMA_INSTR_CEILING_TFLOPS[args.dtype]
+        roofline["frac_of_instr_ceiling"] = round(gemm_tflops / MFMA_INSTR_CEILING_TFLOPS[args.dtype], 4)
     breakdown = {k: round(v["ms"] / args.steps, 4) for k, v in prof.items() if v["launches"]}
     # HBM traffic of that kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: FETCH_SIZE x 2
     # + WRITE_SIZE, mean bytes per launch on this workload); counters cannot be read from inside this process
