@@ -13,7 +13,6 @@ namespace afx {
 // (B, AAS_HP, AAS_WP, C): logical pixel (h, w) sits at (h+1, w+1).
 constexpr int AAS_F = 42;       // spectral bins after max_pool2d(3,3): 128 // 3
 constexpr int AAS_HP = 46;      // padded rows (43 conv1 rows + 1 top + slack)
-constexpr int AAS_WP_MAX = 80;  // padded cols capacity: T//3 + 2 <= 80 (T <= 234)
 
 struct AasistWeights {
   bool ready = false;

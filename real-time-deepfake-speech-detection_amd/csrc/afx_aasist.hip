@@ -275,11 +275,13 @@ struct GatArgs {
 template <int DIN, int DOUT>
 __global__ __launch_bounds__(256) void gat_kernel(GatArgs p) {
   constexpr int JPW = 64 / DOUT;  // nodes handled at once by one wave
-  __shared__ __attribute__((aligned(16))) float xs[AAS_WP_MAX * 64];
-  __shared__ float att[AAS_WP_MAX + 8];
-  __shared__ __attribute__((aligned(16))) float agg[64];
+  // dynamic LDS, sized by the launcher for this graph: node features, attention row, aggregate
+  extern __shared__ __attribute__((aligned(16))) float gat_lds[];
   const int b = blockIdx.y, i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = p.N;
+  float* xs = gat_lds;                     // [N][DIN]
+  float* agg = xs + (long)N * DIN;         // [64]
+  float* att = agg + 64;                   // [N]
   const bool is_master = i == N;
   const float* xb = p.x + (long)b * N * DIN;
   for (int idx = tid; idx < N * DIN / 4; idx += 256) *(f32x4*)(xs + idx * 4) = *(const f32x4*)(xb + idx * 4);
@@ -311,15 +313,18 @@ __global__ __launch_bounds__(256) void gat_kernel(GatArgs p) {
     if (o == 0 && j < N) att[j] = t / p.temp;
   }
   __syncthreads();
-  if (wave == 0) {  // softmax over j (N <= 128: two per lane)
-    const float a0 = lane < N ? att[lane] : -INFINITY;
-    const float a1 = lane + 64 < N ? att[lane + 64] : -INFINITY;
-    const float mx = wave_max(fmaxf(a0, a1));
-    const float e0 = lane < N ? expf(a0 - mx) : 0.f;
-    const float e1 = lane + 64 < N ? expf(a1 - mx) : 0.f;
-    const float den = wave_sum(e0 + e1);
-    if (lane < N) att[lane] = e0 / den;
-    if (lane + 64 < N) att[lane + 64] = e1 / den;
+  if (wave == 0) {  // softmax over j: lane l takes nodes l, l + 64, ...
+    float mx = -INFINITY;
+    for (int j = lane; j < N; j += 64) mx = fmaxf(mx, att[j]);
+    mx = wave_max(mx);
+    float part = 0.f;
+    for (int j = lane; j < N; j += 64) {
+      const float e = expf(att[j] - mx);
+      att[j] = e;
+      part += e;
+    }
+    const float den = wave_sum(part);
+    for (int j = lane; j < N; j += 64) att[j] = att[j] / den;
   }
   __syncthreads();
   if (tid < DIN) {
@@ -351,17 +356,31 @@ __global__ __launch_bounds__(256) void gat_kernel(GatArgs p) {
 }
 
 static const char* launch_gat(const GatArgs& a, int B, int din, int dout, hipStream_t s) {
-  if (a.N < 1 || a.N > AAS_WP_MAX) return "aasist: graph has too many nodes for the LDS slab (clip too long)";
+  // one workgroup per node keeps the whole graph's features in LDS: 4-s clips have <= 66 nodes (17 KB); the
+  // 160 KB of a CU hold 630 nodes = clips of about 37 s (test_duration_sec is a free config value)
+  const int lds = (int)(((long)a.N * din + 64 + a.N + 8) * sizeof(float));
+  if (a.N < 1 || lds > 160 * 1024) return "aasist: graph has too many nodes for the LDS slab (clip longer than ~37 s)";
   dim3 grid(a.N + (a.master ? 1 : 0), B);
+  hipError_t e = hipSuccess;
+  static int lds_set[3] = {0, 0, 0};
+#define AFX_GAT(IDX, DI, DO)                                                                                          \
+  do {                                                                                                                \
+    if (lds > 48 * 1024 && lds > lds_set[IDX]) {                                                                      \
+      e = hipFuncSetAttribute((const void*)gat_kernel<DI, DO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      \
+      if (e == hipSuccess) lds_set[IDX] = lds;                                                                        \
+    }                                                                                                                 \
+    if (e == hipSuccess) hipLaunchKernelGGL((gat_kernel<DI, DO>), grid, dim3(256), lds, s, a);                        \
+  } while (0)
   if (din == 64 && dout == 64)
-    hipLaunchKernelGGL((gat_kernel<64, 64>), grid, dim3(256), 0, s, a);
+    AFX_GAT(0, 64, 64);
   else if (din == 64 && dout == 32)
-    hipLaunchKernelGGL((gat_kernel<64, 32>), grid, dim3(256), 0, s, a);
+    AFX_GAT(1, 64, 32);
   else if (din == 32 && dout == 32)
-    hipLaunchKernelGGL((gat_kernel<32, 32>), grid, dim3(256), 0, s, a);
+    AFX_GAT(2, 32, 32);
   else
     return "aasist: unsupported graph layer dims";
-  hipError_t e = hipGetLastError();
+#undef AFX_GAT
+  if (e == hipSuccess) e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
 
@@ -369,7 +388,7 @@ static const char* launch_gat(const GatArgs& a, int B, int din, int dout, hipStr
 // max(int(N*k),1) nodes in DESCENDING score order; out = h * s.  One block per utterance.
 __global__ void graph_pool_kernel(const float* __restrict__ h, int N, int D, int keep, const float* __restrict__ w,
                                   const float* __restrict__ bias, float* __restrict__ out) {
-  __shared__ float sc[AAS_WP_MAX + 8];
+  extern __shared__ float sc[];  // [N]; one thread per node (block = N rounded up to a wave)
   const int b = blockIdx.x, j = threadIdx.x;
   const float* hb = h + (long)b * N * D;
   if (j < N) {
@@ -580,7 +599,7 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
   int wd, wp, img;
   dims(T, &wd, &wp, &img);
   if (wd < 2) return "aasist: clip too short (need at least 6 SSL frames)";
-  if (wp > AAS_WP_MAX) return "aasist: clip too long for the graph kernels (T <= 234 frames)";
+  if (wd > 630) return "aasist: clip too long for the graph kernels (about 37 s: T <= 1890 frames)";
   const int M = B * img;
   const size_t pixbytes = ((size_t)M + 3 * (size_t)wp + 16) * 4;
   // ---- LL: (B*T,1024) x [128][1024] on the fp32 matrix cores ------------------------
@@ -674,7 +693,7 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
     return launch_gat(a, B, 64, 64, s);
   };
   auto run_pool = [&](const AasistWeights::Pool& P, const float* h, int N, int Dm, int keep, float* out) {
-    hipLaunchKernelGGL(graph_pool_kernel, dim3(B), dim3(128), 0, s, h, N, Dm, keep, P.w, P.b, out);
+    hipLaunchKernelGGL(graph_pool_kernel, dim3(B), dim3((N + 63) & ~63), (N + 8) * sizeof(float), s, h, N, Dm, keep, P.w, P.b, out);
   };
   AOK(run_gat(w.gatS, ws.eS, AAS_F, ws.gS));
   run_pool(w.pS, ws.gS, AAS_F, 64, nS, ws.oS);
@@ -806,11 +825,11 @@ extern "C" int afx_k_hgat(const float* x1, int n1, const float* x2, int n2, int 
 extern "C" int afx_k_graph_pool(const float* h, int B, int N, int D, int keep, const float* w, const float* b,
                                 float* out, void* stream) {
   using namespace afx;
-  if (N < 1 || N > 128 || keep < 1 || keep > N) {
-    aasist_last = "graph_pool: need 1 <= keep <= N <= 128";
+  if (N < 1 || N > 1024 || keep < 1 || keep > N) {
+    aasist_last = "graph_pool: need 1 <= keep <= N <= 1024";
     return 1;
   }
-  hipLaunchKernelGGL(graph_pool_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, h, N, D, keep, w, b, out);
+  hipLaunchKernelGGL(graph_pool_kernel, dim3(B), dim3((N + 63) & ~63), (N + 8) * sizeof(float), (hipStream_t)stream, h, N, D, keep, w, b, out);
   hipError_t e = hipGetLastError();
   aasist_last = e == hipSuccess ? nullptr : hipGetErrorString(e);
   return aasist_last ? 1 : 0;

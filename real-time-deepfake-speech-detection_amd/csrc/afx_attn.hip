@@ -212,11 +212,175 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same attention for clips of ANY length (T > 224: the reference's test_duration_sec is a free
+// config value, data/test_set.py:16,78,153): keys go through LDS in blocks of 128 with the usual running
+// maximum / running sum per query row.  One workgroup = one (utterance, head, 64-query chunk); a wave
+// keeps ONE 16-query tile (Q fragments, the 16 x 64 output accumulators and the row statistics stay in
+// registers across all key blocks); per block it computes the 8 S^T tiles, rescales, and feeds the
+// probabilities straight back as the B-operand of V^T P^T exactly as mhsa_kernel does.  LDS 33 KB.
+// ---------------------------------------------------------------------------------------
+constexpr int ATTL_KB = 128;         // keys per block
+constexpr int ATTL_VT_STRIDE = 136;  // halfs per V^T row (68 words: conflict-free ds_read_b64 per half-wave)
+
+template <class HT>
+__global__ __launch_bounds__(256, 2) void mhsa_long_kernel(const typename HT::T* __restrict__ qkv,
+                                                        typename HT::T* __restrict__ out, int T, int H, float scale) {
+  typedef typename HT::T Tt;
+  typedef typename HT::V8 V8;
+  typedef typename HT::V4 V4;
+  constexpr int KS = ATTL_KB / 32, NKT = KS * 2;
+  __shared__ __attribute__((aligned(16))) char k_lds[ATTL_KB * 128];
+  __shared__ __attribute__((aligned(16))) Tt vt_lds[64 * ATTL_VT_STRIDE];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long ld = 3L * H * 64;
+  const Tt* base = qkv + (long)b * T * ld + h * 64;
+  const Tt* kbase = base + (long)H * 64;
+  const Tt* vbase = base + 2L * H * 64;
+  const int ql = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.z * 64 + wave * 16;
+  const int q = q0 + ql;
+  V8 qf[2];
+  {
+    const int qrow = q < T ? q : T - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const V8*)(base + (long)qrow * ld + ks * 32 + g * 8);
+  }
+  float m = -1e30f, l = 0.f;
+  f32x4 o[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int j0 = 0; j0 < T; j0 += ATTL_KB) {
+    if (j0) __syncthreads();  // every wave is done with the previous block
+    {
+      constexpr int IT = ATTL_KB * 8 / 256;
+      u32x4 kreg[IT];
+      V8 vreg[IT];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 256, key = idx >> 3, c = idx & 7;
+        kreg[it] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vreg[it][i] = (Tt)0.f;
+        if (j0 + key < T) {
+          kreg[it] = *(const u32x4*)(kbase + (long)(j0 + key) * ld + c * 8);
+          vreg[it] = *(const V8*)(vbase + (long)(j0 + key) * ld + c * 8);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 256, key = idx >> 3, c = idx & 7;
+        *(u32x4*)(k_lds + key * 128 + ((c ^ ((key >> 1) & 7)) * 16)) = kreg[it];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vt_lds[(c * 8 + i) * ATTL_VT_STRIDE + key] = vreg[it][i];
+      }
+    }
+    __syncthreads();
+    if (q0 >= T) continue;  // wave-uniform: a tile past the end only helps staging
+
+    f32x4 s[NKT];
+#pragma unroll
+    for (int kp = 0; kp < NKT; kp += 2) {
+      V8 kf[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int krow = (kp + u) * 16 + ql;
+        const int sw = (krow >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kf[u][ks] = *(const V8*)(k_lds + krow * 128 + (((ks * 4 + g) ^ sw) * 16));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) s[kp + u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) s[kp + u] = HT::mfma(kf[u][ks], qf[ks], s[kp + u]);
+    }
+    float bm = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + kt * 16 + g * 4 + r;
+        const float v = key < T ? s[kt][r] * scale : -1e30f;
+        s[kt][r] = v;
+        bm = fmaxf(bm, v);
+      }
+    const float mn = fmaxf(m, rows_max(bm));
+    const float corr = __expf(m - mn);
+    float bl = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[kt][r] - mn);
+        s[kt][r] = e;
+        bl += e;
+      }
+    l = fmaf(l, corr, rows_sum(bl));
+    m = mn;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) o[nt] *= corr;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      V8 vf[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const Tt* vr = vt_lds + (nt * 16 + ql) * ATTL_VT_STRIDE + s2 * 32 + g * 4;
+        const V4 lo = *(const V4*)vr;
+        const V4 hi = *(const V4*)(vr + 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vf[nt][r] = lo[r];
+          vf[nt][4 + r] = hi[r];
+        }
+      }
+      V8 pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pf[r] = (Tt)s[2 * s2][r];
+        pf[4 + r] = (Tt)s[2 * s2 + 1][r];
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) o[nt] = HT::mfma(vf[nt], pf, o[nt]);
+    }
+  }
+  if (q0 >= T) return;
+  const float rinv = 1.0f / l;
+  const int cb = (g & 1) * 16 + (g >> 1) * 8;
+#pragma unroll
+  for (int np = 0; np < 2; ++np) {
+    f32x4 va = o[2 * np] * rinv, vb = o[2 * np + 1] * rinv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va[r]), __float_as_uint(vb[r]), false, false);
+      va[r] = __uint_as_float(sw[0]);
+      vb[r] = __uint_as_float(sw[1]);
+    }
+    if (q < T) {
+      V8 hv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        hv[r] = (Tt)va[r];
+        hv[4 + r] = (Tt)vb[r];
+      }
+      *(V8*)(out + ((long)b * T + q) * (H * 64) + h * 64 + np * 32 + cb) = hv;
+    }
+  }
+}
+
+static int g_mhsa_force_long = 0;  // test knob: the blocked kernel at any length
+void mhsa_set_force_long(int v) { g_mhsa_force_long = v != 0; }
+
 template <class HT>
 static void launch_mhsa_t(const void* qkv, void* out, int B, int T, int H, float scale, hipStream_t s) {
   typedef typename HT::T Tt;
   dim3 grid(H, B), blk(256);
-  if (T <= 64)
+  if (T > ATT_KEYS || g_mhsa_force_long)
+    hipLaunchKernelGGL((mhsa_long_kernel<HT>), dim3(H, B, (T + 63) / 64), blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale);
+  else if (T <= 64)
     hipLaunchKernelGGL((mhsa_kernel<HT, 2>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale);
   else if (T <= 128)
     hipLaunchKernelGGL((mhsa_kernel<HT, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale);
@@ -225,8 +389,8 @@ static void launch_mhsa_t(const void* qkv, void* out, int B, int T, int H, float
 }
 
 const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t s) {
-  if (T <= 0 || T > ATT_KEYS) return "mhsa: sequence length must be in 1..224 frames (<= 4.5 s clips)";
-  if (B <= 0 || H <= 0) return "mhsa: bad shape";
+  if (T <= 0 || B <= 0 || H <= 0) return "mhsa: bad shape";
+  if (B > 65535 || (T + 63) / 64 > 65535) return "mhsa: batch / length beyond the launch grid";
   const float scale = 0.125f;  // 64^-0.5
   if (dtype == DT_FP32) {  // exact mode: fp32 VALU attention (afx_conformer.hip), q | k | v fp32 rows
     const float* f = (const float*)qkv;

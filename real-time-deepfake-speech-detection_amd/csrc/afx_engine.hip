@@ -1135,6 +1135,14 @@ extern "C" int afx_debug_set(const char* key, int value) {
     gemm_set_split(value);
     return 0;
   }
+  if (!strcmp(key, "mhsa_force_long")) {
+    mhsa_set_force_long(value);
+    return 0;
+  }
+  if (!strcmp(key, "conf_attn_block")) {
+    conf_attn_set_block(value);
+    return 0;
+  }
   if (!strcmp(key, "gemm_x32")) {
     gemm_set_x32(value);
     return 0;

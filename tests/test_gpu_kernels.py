@@ -285,11 +285,37 @@ def test_transformer_attention(K, dtype, T):
     _close(got, ref, 2e-2 if dtype == "bf16" else 4e-3, 2e-2 if dtype == "bf16" else 3e-3)
 
 
-def test_transformer_attention_rejects_long_sequences(K):
-    from afx._lib import AfxError
-    qkv = torch.zeros(300, 3 * 64, dtype=torch.float16, device="cuda")
-    with pytest.raises(AfxError, match="sequence length"):
-        K.mhsa("fp16", qkv, 1, 300, 1)
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("T", [225, 300, 499, 1000])
+def test_transformer_attention_any_length(K, dtype, T):
+    """Clips longer than 4.5 s (the reference's test_duration_sec is a free config value): keys stream through
+    LDS in blocks of 128 with running row statistics (mhsa_long_kernel)."""
+    B, H = 2, 3
+    g = torch.Generator().manual_seed(T)
+    qkv = (torch.randn(B * T, 3 * H * 64, generator=g)).to(_td(dtype))
+    got = K.mhsa(dtype, qkv.cuda(), B, T, H).float().cpu().view(B, T, H, 64)
+    q, k, v = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v).permute(0, 2, 1, 3)
+    _close(got, ref, 2e-2 if dtype == "bf16" else 4e-3, 2e-2 if dtype == "bf16" else 3e-3)
+
+
+@pytest.mark.parametrize("T", [1, 17, 128, 129, 199, 224])
+def test_transformer_attention_blocked_kernel_agrees_with_the_one_pass_kernel(K, T):
+    """The any-length kernel forced onto short clips: same probabilities up to the rounding of P (relative to the
+    running instead of the final row maximum), block edges at 128 included; and launch-to-launch identical."""
+    from afx._lib import check, lib
+    B, H = 3, 4
+    g = torch.Generator().manual_seed(1000 + T)
+    qkv = torch.randn(B * T, 3 * H * 64, generator=g).half().cuda()
+    want = K.mhsa("fp16", qkv, B, T, H).float()
+    try:
+        check(lib().afx_debug_set(b"mhsa_force_long", 1))
+        got = K.mhsa("fp16", qkv, B, T, H).float()
+        again = K.mhsa("fp16", qkv, B, T, H).float()
+    finally:
+        check(lib().afx_debug_set(b"mhsa_force_long", 0))
+    _close(got, want, 2e-3, 2e-3)
+    assert torch.equal(got, again)
 
 
 @pytest.mark.parametrize("N,H,dh", [(200, 4, 36), (50, 4, 36), (13, 4, 32)])
@@ -308,6 +334,46 @@ def test_conformer_relative_attention(K, N, H, dh):
     dots = (torch.einsum("bhid,bhjd->bhij", qq, kk) + torch.einsum("bhnd,nrd->bhnr", qq, rel[dist])) * dh ** -0.5
     ref = torch.einsum("bhij,bhjd->bhid", torch.softmax(dots, -1), vv).transpose(1, 2).reshape(B * N, H * dh)
     _close(got, ref, 2e-3, 2e-3)
+
+
+@pytest.mark.parametrize("N,H,dh", [(300, 4, 36), (700, 2, 36), (257, 2, 64), (1200, 1, 36)])
+def test_conformer_relative_attention_any_length(K, N, H, dh):
+    """Beyond 256 tokens the fp32 kernel takes 256-query chunks and 64-key LDS blocks; beyond 513 the Shaw
+    distance clamp (max_pos_emb = 512) is active."""
+    B = 2
+    g = torch.Generator().manual_seed(N)
+    q = torch.randn(B * N, H * dh, generator=g)
+    kv = torch.randn(B * N, 2 * H * dh, generator=g)
+    rel = torch.randn(1025, dh, generator=g)
+    got = K.conf_attn("fp16", q.cuda(), kv.cuda(), rel.cuda(), B, N, H, dh).float().cpu()
+    qq = q.view(B, N, H, dh).transpose(1, 2)
+    kk = kv[:, : H * dh].reshape(B, N, H, dh).transpose(1, 2)
+    vv = kv[:, H * dh:].reshape(B, N, H, dh).transpose(1, 2)
+    seq = torch.arange(N)
+    dist = (seq[:, None] - seq[None, :]).clamp(-512, 512) + 512
+    dots = torch.einsum("bhid,bhjd->bhij", qq, kk)
+    for b in range(B):  # (N, N, dh) gather per utterance: bounded memory
+        dots[b] += torch.einsum("hnd,nrd->hnr", qq[b], rel[dist])
+    ref = torch.einsum("bhij,bhjd->bhid", torch.softmax(dots * dh ** -0.5, -1), vv).transpose(1, 2).reshape(B * N, H * dh)
+    _close(got, ref, 2e-3, 2e-3)
+
+
+@pytest.mark.parametrize("N,block", [(200, 64), (200, 12), (50, 48), (13, 4)])
+def test_conformer_relative_attention_blocked_form_is_bit_identical(K, N, block):
+    """Keys are walked in the same order whether they sit in LDS all at once or a block at a time."""
+    from afx._lib import check, lib
+    B, H, dh = 2, 4, 36
+    g = torch.Generator().manual_seed(N + block)
+    q = torch.randn(B * N, H * dh, generator=g).cuda()
+    kv = torch.randn(B * N, 2 * H * dh, generator=g).cuda()
+    rel = torch.randn(1025, dh, generator=g).cuda()
+    want = K.conf_attn("fp16", q, kv, rel, B, N, H, dh)
+    try:
+        check(lib().afx_debug_set(b"conf_attn_block", block))
+        got = K.conf_attn("fp16", q, kv, rel, B, N, H, dh)
+    finally:
+        check(lib().afx_debug_set(b"conf_attn_block", 0))
+    assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("dtype", DT)
