@@ -155,7 +155,7 @@ def main():
                 roofline["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json)"
 
     result = {
-        "metric": "utterances/sec (4 s @ 16 kHz)", "value": round(value, 2), "unit": "utterances/s",
+        "metric": "utterances/sec (4 s @ 16 kHz)" if args.seconds == 4.0 else f"utterances/sec ({args.seconds:g} s @ 16 kHz)", "value": round(value, 2), "unit": "utterances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.workload}: {oname} ({n_layers}-layer XLS-R trunk), batch {B} per GPU, "

@@ -397,13 +397,222 @@ __global__ __launch_bounds__(256) void conf_attn_mfma_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------
+// The matrix-core Shaw attention for sequences of any length (clips beyond 4 s): one workgroup per
+// (utterance, head, 64-query chunk), a wave keeps ONE 16-query tile -- Q fragments, output accumulators and
+// row statistics in registers -- while the keys pass through LDS 128 at a time.  Per (query tile, key
+// block) the relative term is needed for the 143 distances i - j in [q0 - j0 - 127, q0 - j0 + 15]:
+// nine 16-row tiles of E (clamped to +-max_pos, fragments from L2) times Q^T, skewed through the wave's
+// own LDS tile exactly as in the one-pass kernel; then the running maximum / sum update of mhsa_long_kernel.
+// LDS 66 KB: two workgroups per CU.
+// ---------------------------------------------------------------------------------
+constexpr int CAL_KB = 128, CAL_VT_STRIDE = 136, CAL_RS = 148, CAL_NKT = 8, CAL_KS = 4, CAL_RT = 9;
+
+template <class HT, int DH>
+__global__ __launch_bounds__(256, 2) void conf_attn_mfma_long_kernel(const float* __restrict__ q, long ldq,
+                                                                  const float* __restrict__ kv, long ldkv,
+                                                                  const typename HT::T* __restrict__ rel_h, int max_pos,
+                                                                  int N, int H, typename HT::T* __restrict__ out, long ldo) {
+  typedef typename HT::T Tt;
+  typedef typename HT::V8 V8;
+  typedef typename HT::V4 V4;
+  constexpr int DT = (DH + 15) / 16;
+  static_assert(DH % 4 == 0 && DH <= 64, "head dim");
+  extern __shared__ __attribute__((aligned(16))) float sm_f[];
+  char* sm = (char*)sm_f;
+  char* k_lds = sm;                                                           // [128][128 B]
+  Tt* vt_lds = (Tt*)(sm + CAL_KB * 128);                                      // [16 DT][136]
+  float* r_lds = (float*)(sm + CAL_KB * 128 + 16 * DT * CAL_VT_STRIDE * 2);   // [4 waves][16][148]
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int inner = H * DH;
+  const int ql = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.z * 64 + wave * 16;
+  const float scale = 1.0f / sqrtf((float)DH);
+  float* rw = r_lds + wave * 16 * CAL_RS;
+  // head dims DH..63 of K and rows DH..16 DT of V^T are never written again: zero once
+  for (int i = tid; i < (CAL_KB * 128 + 16 * DT * CAL_VT_STRIDE * 2) / 16; i += 256) ((u32x4*)sm)[i] = u32x4{0u, 0u, 0u, 0u};
+  V8 qf[2];
+  {
+    const int qrow = q0 + ql < N ? q0 + ql : N - 1;
+    const float* qp = q + ((long)b * N + qrow) * ldq + h * DH;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int d = ks * 32 + g * 8 + half * 4;
+        f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (d < DH) t = *(const f32x4*)(qp + d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qf[ks][half * 4 + i] = (Tt)(t[i] * scale);
+      }
+  }
+  float m = -1e30f, l = 0.f;
+  f32x4 o[DT];
+#pragma unroll
+  for (int nt = 0; nt < DT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int j0 = 0; j0 < N; j0 += CAL_KB) {
+    __syncthreads();  // the zero fill (first block) / every wave done with the previous block
+    {
+      const int nk = min(CAL_KB, N - j0);
+      constexpr int IT = (CAL_KB * (DH / 4) + 255) / 256;
+      f32x4 kreg[IT], vreg[IT];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < nk * (DH / 4)) {
+          const int key = idx / (DH / 4), q4 = idx % (DH / 4);
+          const float* row = kv + ((long)b * N + j0 + key) * ldkv + h * DH + q4 * 4;
+          kreg[it] = *(const f32x4*)row;
+          vreg[it] = *(const f32x4*)(row + inner);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < nk * (DH / 4)) {
+          const int key = idx / (DH / 4), q4 = idx % (DH / 4);
+          V4 kh;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) kh[i] = (Tt)kreg[it][i];
+          const int c = q4 >> 1;
+          *(V4*)(k_lds + key * 128 + ((c ^ ((key >> 1) & 7)) * 16) + (q4 & 1) * 8) = kh;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) vt_lds[(q4 * 4 + i) * CAL_VT_STRIDE + key] = (Tt)vreg[it][i];
+        }
+      }
+    }
+    __syncthreads();
+    if (q0 >= N) continue;  // wave-uniform: a tile past the end only helps staging (keys past N keep finite stale values: p = 0)
+
+    // relative term: window row r <-> distance base + r
+    const int base = q0 - j0 - (CAL_KB - 1);
+#pragma unroll
+    for (int rp = 0; rp < CAL_RT; ++rp) {
+      int er = base + rp * 16 + ql;
+      er = er < -max_pos ? -max_pos : (er > max_pos ? max_pos : er);
+      const Tt* ep = rel_h + (long)(er + max_pos) * 64 + g * 8;
+      const V8 e0 = *(const V8*)ep, e1 = *(const V8*)(ep + 32);
+      f32x4 r2 = f32x4{0.f, 0.f, 0.f, 0.f};
+      r2 = HT::mfma(e0, qf[0], r2);
+      r2 = HT::mfma(e1, qf[1], r2);
+      *(f32x4*)(rw + ql * CAL_RS + rp * 16 + g * 4) = r2;
+    }
+    f32x4 s[CAL_NKT];
+#pragma unroll
+    for (int kp = 0; kp < CAL_NKT; kp += 2) {
+      V8 kf[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int krow = (kp + u) * 16 + ql;
+        const int sw = (krow >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kf[u][ks] = *(const V8*)(k_lds + krow * 128 + (((ks * 4 + g) ^ sw) * 16));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) s[kp + u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) s[kp + u] = HT::mfma(kf[u][ks], qf[ks], s[kp + u]);
+    }
+    float bm = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < CAL_NKT; ++kt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int kl = kt * 16 + g * 4 + c;
+        const float v = j0 + kl < N ? s[kt][c] + rw[ql * CAL_RS + ql + (CAL_KB - 1) - kl] : -1e30f;
+        s[kt][c] = v;
+        bm = fmaxf(bm, v);
+      }
+    const float mn = fmaxf(m, rows_max(bm));
+    const float corr = __expf(m - mn);
+    float bl = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < CAL_NKT; ++kt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float e = __expf(s[kt][c] - mn);
+        s[kt][c] = e;
+        bl += e;
+      }
+    l = fmaf(l, corr, rows_sum(bl));
+    m = mn;
+#pragma unroll
+    for (int nt = 0; nt < DT; ++nt) o[nt] *= corr;
+#pragma unroll
+    for (int s2 = 0; s2 < CAL_KS; ++s2) {
+      V8 pf;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        pf[c] = (Tt)s[2 * s2][c];
+        pf[4 + c] = (Tt)s[2 * s2 + 1][c];
+      }
+      V8 vf[DT];
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) {
+        const Tt* vr = vt_lds + (nt * 16 + ql) * CAL_VT_STRIDE + s2 * 32 + g * 4;
+        const V4 lo = *(const V4*)vr;
+        const V4 hi = *(const V4*)(vr + 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          vf[nt][c] = lo[c];
+          vf[nt][4 + c] = hi[c];
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) o[nt] = HT::mfma(vf[nt], pf, o[nt]);
+    }
+  }
+  const int qi = q0 + ql;
+  if (qi < N) {
+    const float rinv = 1.0f / l;
+#pragma unroll
+    for (int nt = 0; nt < DT; ++nt) {
+      const int d = nt * 16 + g * 4;
+      if (d < DH) {
+        V4 hv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hv[c] = (Tt)(o[nt][c] * rinv);
+        *(V4*)(out + ((long)b * N + qi) * ldo + h * DH + d) = hv;
+      }
+    }
+  }
+}
+
+static int g_conf_attn_force_long = 0;  // test knob: the blocked kernel at every length
+void conf_attn_mfma_set_force_long(int v) { g_conf_attn_force_long = v != 0; }
+
 const char* launch_conf_attn_mfma(const float* q, long ldq, const float* kv, long ldkv, const void* rel_h, int max_pos,
                                   int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s) {
   if (dh != 36) return "conf_attn_mfma: built for head dim 36 (emb 144 / 4 heads)";
-  if (N <= 0 || N + 15 > CA_KEYS) return "conf_attn_mfma: at most 209 tokens";
+  if (N <= 0 || B <= 0 || B > 65535) return "conf_attn_mfma: bad shape";
   if (dtype == DT_FP32) return "conf_attn_mfma: half-precision operands only";
   if ((ldq % 4) || (ldkv % 4) || (ldo % 4)) return "conf_attn_mfma: row strides must be multiples of 4";
   constexpr int DT = 3;
+  if (N + 15 > CA_KEYS || g_conf_attn_force_long) {  // beyond 209 tokens: keys in blocks of 128
+    const int ldsl = CAL_KB * 128 + 16 * DT * CAL_VT_STRIDE * 2 + 4 * 16 * CAL_RS * 4;
+    hipError_t el = hipSuccess;
+    static int setl[2] = {0, 0};
+    dim3 grid(H, B, (N + 63) / 64);
+    if (dtype == DT_BF16) {
+      if (!setl[0]) el = hipFuncSetAttribute((const void*)conf_attn_mfma_long_kernel<BF16, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsl);
+      setl[0] = 1;
+      if (el == hipSuccess)
+        hipLaunchKernelGGL((conf_attn_mfma_long_kernel<BF16, 36>), grid, dim3(256), ldsl, s, q, ldq, kv, ldkv, (const __bf16*)rel_h,
+                           max_pos, N, H, (__bf16*)out_h, ldo);
+    } else {
+      if (!setl[1]) el = hipFuncSetAttribute((const void*)conf_attn_mfma_long_kernel<FP16, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsl);
+      setl[1] = 1;
+      if (el == hipSuccess)
+        hipLaunchKernelGGL((conf_attn_mfma_long_kernel<FP16, 36>), grid, dim3(256), ldsl, s, q, ldq, kv, ldkv, (const _Float16*)rel_h,
+                           max_pos, N, H, (_Float16*)out_h, ldo);
+    }
+    if (el == hipSuccess) el = hipGetLastError();
+    return el == hipSuccess ? nullptr : hipGetErrorString(el);
+  }
   const int lds = CA_KEYS * 128 + 16 * DT * CA_VT_STRIDE * 2 + 4 * 16 * CA_RS * 4;
   hipError_t e = hipSuccess;
   static int set[2] = {0, 0};
@@ -434,7 +643,7 @@ template <class HT>
 __global__ __launch_bounds__(256) void conf_dwconv_kernel(const float* __restrict__ x, long ldx,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           const float* __restrict__ bn_scale,
-                                                          const float* __restrict__ bn_shift, int N, int C, int k,
+                                                          const float* __restrict__ bn_shift, int N, int NC, int C, int k,
                                                           typename HT::T* __restrict__ out, long ldo) {
   typedef typename HT::T Tt;
   constexpr bool EXACT = sizeof(Tt) == 4;  // fp32 "exact mode": accurate exp / division
@@ -443,13 +652,16 @@ __global__ __launch_bounds__(256) void conf_dwconv_kernel(const float* __restric
   float* sm = sm_f;
   const int c0 = blockIdx.x * 32, b = blockIdx.y, tid = threadIdx.x;
   const int pl = k / 2;
-  const int rows = N + KMAX - 1 + TB;  // zero rows behind the sequence let the last window read freely
-  float* us = sm;                      // [rows][32]: gated activations, row r <-> frame r - pl
+  // blockIdx.z walks the sequence NC frames at a time (NC = N up to 1024 frames; longer clips take several
+  // chunks, each staging its own k - 1 halo rows)
+  const int f0 = blockIdx.z * NC, nc = min(NC, N - f0);
+  const int rows = nc + KMAX - 1 + TB;  // zero rows behind the chunk let the last window read freely
+  float* us = sm;                       // [rows][32]: gated activations, row r <-> frame f0 + r - pl
   const int cl = tid & 31, tl = tid >> 5;
   const int c = c0 + cl;
   const bool cok = c < C;
   for (int r = tl; r < rows; r += 8) {
-    const int t = r - pl;
+    const int t = f0 + r - pl;
     float u = 0.f;
     if (cok && t >= 0 && t < N) {
       const float* row = x + ((long)b * N + t) * ldx;
@@ -466,8 +678,8 @@ __global__ __launch_bounds__(256) void conf_dwconv_kernel(const float* __restric
   // each thread owns a contiguous run of frames and walks it TB outputs at a time: one window of
   // TB + 30 inputs comes from LDS, the TB x 31 FMAs run from registers (the per-tap LDS reads of
   // the first version, two per FMA, were what bounded this kernel)
-  const int per = (N + 7) / 8;
-  const int t_end = min(N, (tl + 1) * per);
+  const int per = (nc + 7) / 8;
+  const int t_end = min(nc, (tl + 1) * per);
   for (int t0 = tl * per; t0 < t_end; t0 += TB) {
     float win[TB + KMAX - 1];
 #pragma unroll
@@ -483,7 +695,7 @@ __global__ __launch_bounds__(256) void conf_dwconv_kernel(const float* __restric
 #pragma unroll
       for (int u = 0; u < TB; ++u) {
         const float y = fmaf(acc[u], sc, sh);
-        if (t0 + u < t_end) out[((long)b * N + t0 + u) * ldo + c] = (Tt)(EXACT ? swish(y) : swish_fast(y));
+        if (t0 + u < t_end) out[((long)b * N + f0 + t0 + u) * ldo + c] = (Tt)(EXACT ? swish(y) : swish_fast(y));
       }
     }
   }
@@ -493,9 +705,10 @@ const char* launch_conf_dwconv(const float* x, long ldx, const float* w, const f
                                const float* bn_shift, int B, int N, int C, int k, void* out_h, long ldo, int dtype,
                                hipStream_t s) {
   if (k > 31) return "conf_dwconv: depthwise kernels up to 31 taps";
-  const int lds = (N + 31 - 1 + 8) * 32 * (int)sizeof(float);
-  if (lds > 160 * 1024) return "conf_dwconv: sequence too long for the LDS slab";
-  dim3 grid((C + 31) / 32, B);
+  if (N <= 0 || B <= 0 || B > 65535) return "conf_dwconv: bad shape";
+  const int NC = N < 1024 ? N : 1024;
+  const int lds = (NC + 31 - 1 + 8) * 32 * (int)sizeof(float);
+  dim3 grid((C + 31) / 32, B, (N + NC - 1) / NC);
   hipError_t e = hipSuccess;
   static int lds_set[3] = {0, 0, 0};
   if (dtype < 0 || dtype > 2) return "conf_dwconv: unknown dtype";
@@ -505,7 +718,7 @@ const char* launch_conf_dwconv(const float* x, long ldx, const float* w, const f
       if (e == hipSuccess) lds_set[dtype] = lds;
     }
     if (e == hipSuccess)
-      hipLaunchKernelGGL(conf_dwconv_kernel<HT>, grid, dim3(256), lds, s, x, ldx, w, bias, bn_scale, bn_shift, N, C, k,
+      hipLaunchKernelGGL(conf_dwconv_kernel<HT>, grid, dim3(256), lds, s, x, ldx, w, bias, bn_scale, bn_shift, N, NC, C, k,
                          (HT::T*)out_h, ldo);
   });
   if (e == hipSuccess) e = hipGetLastError();

@@ -880,7 +880,7 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     c.out2 = w.qkv32; c.ld_out2 = 3 * e->inner;
     KOK(timed(PC_CONF_CHAIN, ff_fl + 2.0 * M * E * 3 * e->inner, s, [&] { return launch_conf_chain(c, 0, dt, s); }));
     KOK(timed(PC_CONF_ATTN, 6.0 * B * e->heads * (double)N * N * e->dh, s, [&] {
-      if (g_conf_attn_mfma && dt != DT_FP32 && e->dh == 36 && N + 15 <= 224)
+      if (g_conf_attn_mfma && dt != DT_FP32 && e->dh == 36)
         return launch_conf_attn_mfma(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner, K.rel_h, 512, B, N, e->heads,
                                      e->dh, w.ao, Ep, dt, s);
       return launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
@@ -937,7 +937,7 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     q.out_f = w.qkv32; q.ldo_f = 3 * e->inner;
     KOK(launch_gemm(q, dt, 1, s));
     KOK(timed(PC_CONF_ATTN, 6.0 * B * e->heads * (double)N * N * e->dh, s, [&] {
-      if (g_conf_attn_mfma && dt != DT_FP32 && e->dh == 36 && N + 15 <= 224)
+      if (g_conf_attn_mfma && dt != DT_FP32 && e->dh == 36)
         return launch_conf_attn_mfma(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner, K.rel_h, 512, B, N, e->heads,
                                      e->dh, w.ao, Ep, dt, s);
       return launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
@@ -1137,6 +1137,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
   }
   if (!strcmp(key, "mhsa_force_long")) {
     mhsa_set_force_long(value);
+    return 0;
+  }
+  if (!strcmp(key, "conf_attn_force_long")) {
+    conf_attn_mfma_set_force_long(value);
     return 0;
   }
   if (!strcmp(key, "conf_attn_block")) {

@@ -57,6 +57,7 @@ void gemm_set_tile(int t);      // A/B knob: -1 default, 0: 128x128 tile, 1: 256
 void gemm_set_a_nt(int v);      // A/B knob: -1 auto, 0/1 non-temporal A-panel loads
 void gemm_set_split(int v);     // A/B knob: 1 (default) = whole rounds on the 8-phase kernel + 128x128 remainder rows
 void mhsa_set_force_long(int v);   // test knob: the blocked any-length trunk attention kernel at every length
+void conf_attn_mfma_set_force_long(int v);  // test knob: the blocked matrix-core Shaw attention at every length
 void conf_attn_set_block(int v);   // test knob: keys per LDS block of the fp32 attention (0 = automatic)
 void gemm_set_x32(int v);       // A/B knob: 0 (default) = 16x16x32, 1 = 8-phase kernels on v_mfma 32x32x16, 2 = gemm32_kernel
 void gemm_set_deep(int v);      // A/B knob, conv tile: 0 = 2-stage kernel, -1/2 = 8-phase kernel (default)

@@ -377,7 +377,7 @@ def test_conformer_relative_attention_blocked_form_is_bit_identical(K, N, block)
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("N", [200, 50, 209, 13])
+@pytest.mark.parametrize("N", [200, 50, 209, 13, 210, 400, 700, 1200])  # > 209: keys in blocks of 128; > 513: distance clamp
 def test_conformer_relative_attention_on_matrix_cores(K, dtype, N):
     """The MFMA form (S1 = K Q^T, R = E_win Q^T skewed through LDS, P V): against the fp32 definition
     computed from the ROUNDED q, k, v, E (the kernel rounds them to the operand type)."""
@@ -393,17 +393,36 @@ def test_conformer_relative_attention_on_matrix_cores(K, dtype, N):
     vv = rnd(kv[:, H * dh:]).reshape(B, N, H, dh).transpose(1, 2)
     seq = torch.arange(N)
     dist = (seq[:, None] - seq[None, :]).clamp(-512, 512) + 512
-    dots = torch.einsum("bhid,bhjd->bhij", qq, kk) + torch.einsum("bhnd,nrd->bhnr", qq, rnd(rel)[dist])
+    dots = torch.einsum("bhid,bhjd->bhij", qq, kk)
+    for bi in range(B):  # (N, N, dh) gather per utterance: bounded memory
+        dots[bi] += torch.einsum("hnd,nrd->hnr", qq[bi], rnd(rel)[dist])
     ref = torch.einsum("bhij,bhjd->bhid", torch.softmax(dots, -1), vv).transpose(1, 2).reshape(B * N, H * dh)
     _close(got, ref, _eps(dtype) * 6, _eps(dtype) * 6)
-    from afx._lib import AfxError
-    with pytest.raises(AfxError, match="209 tokens"):
-        K.conf_attn_mfma(dtype, torch.zeros(2 * 210, H * dh).cuda(), torch.zeros(2 * 210, 2 * H * dh).cuda(), rel.cuda(), 2, 210, H, dh)
+
+
+@pytest.mark.parametrize("N", [200, 129, 128, 50, 13])
+def test_conformer_relative_attention_blocked_matrix_core_kernel_agrees_with_the_one_pass_kernel(K, N):
+    from afx._lib import check, lib
+    B, H, dh = 2, 4, 36
+    g = torch.Generator().manual_seed(7 * N)
+    q = torch.randn(B * N, H * dh, generator=g).cuda()
+    kv = torch.randn(B * N, 2 * H * dh, generator=g).cuda()
+    rel = torch.randn(1025, dh, generator=g).cuda()
+    want = K.conf_attn_mfma("fp16", q, kv, rel, B, N, H, dh).float()
+    try:
+        check(lib().afx_debug_set(b"conf_attn_force_long", 1))
+        got = K.conf_attn_mfma("fp16", q, kv, rel, B, N, H, dh).float()
+        again = K.conf_attn_mfma("fp16", q, kv, rel, B, N, H, dh).float()
+    finally:
+        check(lib().afx_debug_set(b"conf_attn_force_long", 0))
+    _close(got, want, 3e-3, 3e-3)
+    assert torch.equal(got, again)
 
 
 @pytest.mark.parametrize("k", [31, 16])
-def test_conformer_glu_depthwise_bn_swish(K, k):
-    B, N, C = 2, 200, 288
+@pytest.mark.parametrize("N", [200, 1024, 1025, 2500])  # one chunk; the chunk size; chunks with halos
+def test_conformer_glu_depthwise_bn_swish(K, k, N):
+    B, C = 2, 288
     g = torch.Generator().manual_seed(k)
     x = torch.randn(B * N, 2 * C, generator=g)
     w = torch.randn(C, 1, k, generator=g) / math.sqrt(k)

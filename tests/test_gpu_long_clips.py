@@ -63,6 +63,19 @@ def test_conformer_student_on_8s_clips(afx_mod):
     assert e32 <= 2e-5
 
 
+def test_conformer_student_on_a_30s_clip(afx_mod):
+    """T = 1499: every length-dependent kernel in its blocked form at once (1 trunk layer, 1 block)."""
+    engine, synth = afx_mod
+    from oracle import models
+    sd = synth.model_state_dict("ConformerModel", n_layers=1, n_encoders=1)
+    wave = synth.waveforms(1, 480000, batch_idx=30)
+    ref = models.conformer_forward(sd, wave)
+    eng = engine.Engine("conformer", n_layers=1, dtype="fp16", conf_blocks=1)
+    eng.load_state_dict(sd)
+    err = (eng.forward(wave.cuda()).cpu() - ref).abs().max().item()
+    assert err <= SCORE_TOL, f"max |dlogit| {err:.3e}"
+
+
 def test_conformer_head_beyond_the_relative_distance_clamp(afx_mod):
     """T = 700 frames (14 s): distances beyond max_pos_emb = 512 share the edge embeddings (lucidrains
     conformer Attention: dist.clamp(-max_pos_emb, max_pos_emb))."""
