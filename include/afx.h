@@ -68,7 +68,9 @@ int afx_finalize(afx_handle h, void* stream);
 /* ---- forward ------------------------------------------------------------------ */
 int afx_num_frames(int n_samples);                       /* T after the 7 conv layers */
 size_t afx_workspace_bytes(afx_handle h, int B, int L);  /* scratch needed by one call */
-/* wave: device (B,L) fp32.  logits: device (B,2) fp32. */
+/* wave: device (B,L) fp32.  logits: device (B,2) fp32.  L is free (test_duration_sec, config.py:75): at least
+ * 400 samples (one SSL frame); the AASIST head needs >= 6 frames and holds at most 630 temporal graph nodes
+ * (clips up to about 37 s); beyond either bound the call fails with a message, it never truncates. */
 int afx_forward(afx_handle h, const float* wave, int B, int L, float* logits, void* ws, size_t ws_bytes,
                 void* stream);
 /* SSL features only: feats device (B,T,1024) fp32 == extract_feat() of models/fe.py:17-21 */
