@@ -10,11 +10,11 @@
 // epilogue), which leaves lane l with 8 consecutive columns starting at
 // kb(l) = 16 ((l>>4)&1) + 8 (l>>5) -- the weight fragment is simply fetched with the same
 // permutation, so both MFMA operands agree on which k every slot carries.  Weights stream
-// through LDS: the eight waves of a workgroup (128 rows) fill chunks of <= 32 fragment blocks by
+// through LDS: the NWAVE (4) waves of a workgroup (64 rows) fill chunks of <= 32 fragment blocks by
 // LDS-DMA, already in MFMA fragment order (1 KB per 16 x 32 block = the 64 lanes' 16-byte
-// pieces), into a ring of four 32-KB buffers: every wave issues exactly 4 DMA instructions
+// pieces), into a ring of four 32-KB buffers: every wave issues exactly DPW = 32 / NWAVE DMA instructions
 // per chunk (padding goes to a dump block), so "chunk i has landed" is the counted wait
-// vmcnt(8) with chunks i+1 and i+2 still in flight, chunk i+3 is issued behind the barrier
+// vmcnt(2 DPW) with chunks i+1 and i+2 still in flight, chunk i+3 is issued behind the barrier
 // that frees its buffer.  Each weight byte leaves L2 once per workgroup and every fragment
 // read is a conflict-free ds_read_b128.  (Measured: weights from L2 per wave 81 us per chain,
 // double-buffered LDS chunks 40 us, this ring: see DESIGN.md.)
@@ -43,7 +43,22 @@ constexpr int EK = 5;   // 32-wide k-steps covering E (144 -> 160, the pad colum
 constexpr int HT6 = 6;  // the FF hidden layer is walked in 6 parts of 6 tiles (96 columns = 3 k-steps)
 constexpr int RING = 4, BUFSZ = 32 * 1024, DUMP = RING * BUFSZ;  // + one 1-KB dump block
 constexpr int PARAMS = DUMP + 1024;  // byte offset of the parameter block behind the ring and the dump block
-constexpr int NWAVE = 8;  // 128 token rows per workgroup: each weight byte is fetched once per 128 rows
+// Waves per workgroup (16 token rows each).  The chain is a latency path per wave, not a throughput one: at
+// B = 64 there are only 796 row tiles, so 8 waves per workgroup fill 100 of the 256 CUs with two waves per SIMD
+// contending for the LDS fragment reads, 4 waves fill 199 CUs with one wave per SIMD: 30.9 -> 27.3 us per
+// launch, bit-identical results (tools/chain_ab.py; each weight byte is then fetched once per 64 rows
+// instead of 128 -- from L2, 0.66 MB per chain, not a cost).
+#ifndef CHAIN_NWAVE
+#define CHAIN_NWAVE 4
+#endif
+constexpr int NWAVE = CHAIN_NWAVE;
+constexpr int DPW = 32 / NWAVE;     // LDS-DMA instructions per wave per weight chunk
+static_assert(NWAVE == 8 || NWAVE == 4, "wave count");
+template <int N>
+__device__ __forceinline__ void chain_wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 struct ChunkDesc {  // NT x KS fragment blocks of matrix W: rows n0 .. n0 + 16 NT, k-steps k0 .. k0 + KS
   const void* W;
@@ -117,17 +132,19 @@ struct Chain {
   // for one of its own loads would be vmcnt(0) and drain the weight ring every time (measured:
   // 36 us per chain with the bias vectors read from global inside the chain).
   __device__ __forceinline__ void prologue() {
-    {
+#pragma unroll
+    for (int pb = 0; pb < 8 / NWAVE; ++pb) {  // the 8-KB parameter block: 1-KB pieces
       unsigned keep;
-      const float* src = p.params + wave * 256 + lane * 4;
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + PARAMS + wave * 1024);
+      const int piece = pb * NWAVE + wave;
+      const float* src = p.params + piece * 256 + lane * 4;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + PARAMS + piece * 1024);
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     }
-    static_assert(kChunks<STAGE> >= RING - 1 && NWAVE * 256 == kChainParamFloats, "prologue shape");
+    static_assert(kChunks<STAGE> >= RING - 1 && 8 * 256 == kChainParamFloats, "prologue shape");
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i) issue(i);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // the parameter block (oldest) has landed; 3 chunks x 4 stay in flight
+    chain_wait_vmcnt<3 * DPW>();  // the parameter block (oldest) has landed; 3 chunks stay in flight
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
@@ -137,11 +154,10 @@ struct Chain {
   __device__ __forceinline__ const char* next_chunk() {
     const int i = consumed++;
     const int after = kChunks<STAGE> - 1 - i;  // chunks issued behind this one
-    static_assert(32 / NWAVE == 4, "the counted waits below assume 4 DMA instructions per wave per chunk");
     if constexpr ((CHAIN_DBG & 1) == 0) {
-      if (after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (after >= 2) chain_wait_vmcnt<2 * DPW>();
+      else if (after == 1) chain_wait_vmcnt<DPW>();
+      else chain_wait_vmcnt<0>();
     }
     if constexpr ((CHAIN_DBG & 4) == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
