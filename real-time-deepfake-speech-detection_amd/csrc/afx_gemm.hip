@@ -30,7 +30,10 @@ namespace afx {
 // swapped so a lane holds 4 consecutive columns of one row) -> bias / activation / residual
 // / LayerNorm -> wide stores.
 // ---------------------------------------------------------------------------------------
-template <class HT, int BM, int BN, int WR, int WC, bool ROWLN>
+// LEAN (the 8-phase kernels): only what the launcher sends them -- no activation or erf-GELU, N % 8 == 0.
+// The general form inlines the other activations at every one of the 32 steps and carries the 4-column
+// fallback: ~300 KB of code around a 12-KB K-loop, refetched through the instruction cache after every tile.
+template <class HT, int BM, int BN, int WR, int WC, bool ROWLN, bool LEAN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / WR / 16][BN / WC / 16], char* smem,
                                               int m0, int n0, int g) {
   typedef typename HT::T T;
@@ -126,7 +129,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           const f32x2_t b0 = gelu_erf2(f32x2_t{vb[0], vb[1]}), b1 = gelu_erf2(f32x2_t{vb[2], vb[3]});
           va = f32x4{a0[0], a0[1], a1[0], a1[1]};
           vb = f32x4{b0[0], b0[1], b1[0], b1[1]};
-        } else if (p.act != ACT_NONE) {
+        } else if (!LEAN && p.act != ACT_NONE) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             va[r] = apply_act(va[r], p.act);
@@ -168,7 +171,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
   const int gcol = g * p.g_n;
   const float alpha = p.alpha;
   const int kq = lane >> 4;
-  if ((p.N & 7) == 0 && !(p.dbg_nodma & 16)) {
+  if (LEAN || ((p.N & 7) == 0 && !(p.dbg_nodma & 16))) {
     // Wide-store epilogue.  After the MFMAs a lane holds 4 consecutive columns of one row
     // (8 B of fp16); v_permlane16_swap exchanges 16-lane rows between the registers of two
     // adjacent 16-column tiles so that every lane ends up with 8 consecutive columns:
@@ -230,7 +233,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           const f32x2_t b0 = gelu_erf2(f32x2_t{vb[0], vb[1]}), b1 = gelu_erf2(f32x2_t{vb[2], vb[3]});
           va = f32x4{a0[0], a0[1], a1[0], a1[1]};
           vb = f32x4{b0[0], b0[1], b1[0], b1[1]};
-        } else if (p.act != ACT_NONE && !(p.dbg_nodma & 8)) {
+        } else if (!LEAN && p.act != ACT_NONE && !(p.dbg_nodma & 8)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             va[r] = apply_act(va[r], p.act);
@@ -540,7 +543,7 @@ __device__ __forceinline__ void gemm_epilogue32(const GemmArgs& p, f32x16 (&acc)
 // LayerNorm over the row (two-pass fp32 statistics, partial sums exchanged through LDS
 // between the WC waves of a row) followed by the activation -- the conv feature
 // extractor's "conv -> LayerNorm(512) -> GELU" in one kernel, no fp32 round trip.
-template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false>
+template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false, bool LEAN = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
     }
   }
 
-  gemm_epilogue<HT, BM, BN, WR, WC, ROWLN>(p, acc, smem, m0, n0, g);
+  gemm_epilogue<HT, BM, BN, WR, WC, ROWLN, LEAN>(p, acc, smem, m0, n0, g);
 }
 
 template <int N>
@@ -989,7 +992,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
           for (int r = 0; r < (X32 ? 16 : 4); ++r) asm volatile("" :: "v"(acc[i][j][r]));
     } else {
       if constexpr (X32) gemm_epilogue32<HT, BM, BN, ROWLN>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
-      else gemm_epilogue<HT, BM, BN, 2, 4, ROWLN>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
+      else gemm_epilogue<HT, BM, BN, 2, 4, ROWLN, true>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
     }
     if (vn >= nwg) break;
     v = vn;
@@ -1182,18 +1185,18 @@ static hipError_t launch_gemm32_t(const GemmArgs& p, int groups, hipStream_t s) 
   return hipGetLastError();
 }
 
-template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false>
+template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false, bool LEAN = false>
 static hipError_t launch_gemm_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<HT, BM, BN, WR, WC, ROWLN>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<HT, BM, BN, WR, WC, ROWLN, LEAN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
-  hipLaunchKernelGGL((gemm_kernel<HT, BM, BN, WR, WC, ROWLN>), grid, dim3(64 * WR * WC), lds, s, p);
+  hipLaunchKernelGGL((gemm_kernel<HT, BM, BN, WR, WC, ROWLN, LEAN>), grid, dim3(64 * WR * WC), lds, s, p);
   return hipGetLastError();
 }
 
@@ -1277,8 +1280,10 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
 
 template <class HT>
 static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t s) {
+  // lean epilogue (no activation or erf-GELU, N % 8 == 0: every GEMM of the two models' fast paths) where it applies
+  const bool lean = (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0 && !(p.dbg_nodma & 16);
   switch (tile) {
-    case 1: return launch_gemm_t<HT, 128, 64, 2, 2>(p, groups, s);
+    case 1: return lean ? launch_gemm_t<HT, 128, 64, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 64, 2, 2>(p, groups, s);
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
     case 4: return launch_gemm_t<HT, 256, 128, 4, 2>(p, groups, s);
@@ -1292,7 +1297,7 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
       if (x == 2) return launch_gemm32_t<HT, 128, 512, 1, 4, true>(p, groups, s);
       return x ? launch_gemm8_t<HT, 128, 512, true, true>(p, groups, s) : launch_gemm8_t<HT, 128, 512, true, false>(p, groups, s);
     }
-    default: return launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
+    default: return lean ? launch_gemm_t<HT, 128, 128, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
   }
 }
 
@@ -1301,7 +1306,9 @@ const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t
   if (const char* e = check_gemm(p_in, groups)) return e;
   GemmArgs p = p_in;
   p.map_mode = g_map_override >= 0 ? g_map_override : 2;
-  const int tile = gemm_tile_of(p, groups);
+  int tile = gemm_tile_of(p, groups);
+  if ((tile == 7 || tile == 8) && ((p.act != ACT_NONE && p.act != ACT_GELU) || (p.N & 7)))
+    tile = tile == 7 ? 0 : 3;  // the 8-phase kernels carry the lean epilogue: everything else stays on the 2-stage tiles
   p.a_nt = g_ant_override >= 0 ? g_ant_override : (tile == 3 ? 1 : 0);
   p.dbg_nodma = g_nodma;
   const int m1 = tile == 7 && g_tile_override < 0 ? gemm_split_rows(p, groups) : 0;
