@@ -216,66 +216,81 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         r[1] = *(const f32x4*)(rp + 4);
       }
     };
-    f32x4 rcur[2], rnxt[2];
-    if (p.resid) load_resid(0, rcur);
-#pragma unroll
-    for (int step = 0; step < STEPS; ++step) {
+    // One step = (row tile i, column pair jp).  HAS_R is a compile-time copy of "p.resid != nullptr" so that the
+    // no-residual form contains no load at all: on gfx9 stores and loads share vmcnt and return out of order with
+    // respect to each other, so ANY wait for a load issued before a store is vmcnt(0) = wait for the store's
+    // acknowledgement.  The one-step-ahead residual prefetch of the first version (and the unconditional
+    // register copy behind it) cost exactly that at each of the 16 steps, residual or not (~1 us each, the bulk
+    // of the exposed epilogue time).  The residual rows now come in chunks of RCH steps, loaded together
+    // before the chunk's first store: STEPS / RCH = 8 waits per tile instead of 16, and none without a residual.
+    auto do_step = [&](int step, auto has_r, const f32x4 (&rr)[2]) {
+      constexpr bool HAS_R = decltype(has_r)::value;
       const int i = step / (NT / 2), jp = step % (NT / 2);
-      if (p.resid && step + 1 < STEPS) load_resid(step + 1, rnxt);
       long orow, hrow;
       bool mok;
       row_of(i, orow, hrow, mok);
-      {
-        const int nb = n0 + wc * WN + jp * 32;  // first column of the tile pair
-        f32x4 va = acc[i][2 * jp] + bia[jp][0], vb = acc[i][2 * jp + 1] + bia[jp][1];
-        if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
-          const f32x2_t a0 = gelu_erf2(f32x2_t{va[0], va[1]}), a1 = gelu_erf2(f32x2_t{va[2], va[3]});
-          const f32x2_t b0 = gelu_erf2(f32x2_t{vb[0], vb[1]}), b1 = gelu_erf2(f32x2_t{vb[2], vb[3]});
-          va = f32x4{a0[0], a0[1], a1[0], a1[1]};
-          vb = f32x4{b0[0], b0[1], b1[0], b1[1]};
-        } else if (!LEAN && p.act != ACT_NONE && !(p.dbg_nodma & 8)) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            va[r] = apply_act(va[r], p.act);
-            vb[r] = apply_act(vb[r], p.act);
-          }
-        }
-        if (alpha != 1.f) {
-          va *= alpha;
-          vb *= alpha;
-        }
+      const int nb = n0 + wc * WN + jp * 32;  // first column of the tile pair
+      f32x4 va = acc[i][2 * jp] + bia[jp][0], vb = acc[i][2 * jp + 1] + bia[jp][1];
+      if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
+        const f32x2_t a0 = gelu_erf2(f32x2_t{va[0], va[1]}), a1 = gelu_erf2(f32x2_t{va[2], va[3]});
+        const f32x2_t b0 = gelu_erf2(f32x2_t{vb[0], vb[1]}), b1 = gelu_erf2(f32x2_t{vb[2], vb[3]});
+        va = f32x4{a0[0], a0[1], a1[0], a1[1]};
+        vb = f32x4{b0[0], b0[1], b1[0], b1[1]};
+      } else if (!LEAN && p.act != ACT_NONE && !(p.dbg_nodma & 8)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va[r]), __float_as_uint(vb[r]), false, false);
-          va[r] = __uint_as_float(sw[0]);
-          vb[r] = __uint_as_float(sw[1]);
-        }
-        const int n = nb + cb;  // this lane now owns columns n .. n+7 (va | vb)
-        if (p.dbg_nodma & 32) {  // timing only: no stores
-          asm volatile("" :: "v"(va), "v"(vb));
-        } else if (mok && n < p.N) {
-          if (p.resid) {
-            va += rcur[0];
-            vb += rcur[1];
-          }
-          if (p.out_f) {
-            float* op = p.out_f + orow * p.ldo_f + gcol + n;
-            *(f32x4*)op = va;
-            *(f32x4*)(op + 4) = vb;
-          }
-          if (p.out_h) {
-            V8 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              h[r] = (T)va[r];
-              h[4 + r] = (T)vb[r];
-            }
-            *(V8*)((T*)p.out_h + hrow * p.ldo_h + gcol + n) = h;
-          }
+          va[r] = apply_act(va[r], p.act);
+          vb[r] = apply_act(vb[r], p.act);
         }
       }
-      rcur[0] = rnxt[0];
-      rcur[1] = rnxt[1];
+      if (alpha != 1.f) {
+        va *= alpha;
+        vb *= alpha;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va[r]), __float_as_uint(vb[r]), false, false);
+        va[r] = __uint_as_float(sw[0]);
+        vb[r] = __uint_as_float(sw[1]);
+      }
+      const int n = nb + cb;  // this lane now owns columns n .. n+7 (va | vb)
+      if (p.dbg_nodma & 32) {  // timing only: no stores
+        asm volatile("" :: "v"(va), "v"(vb));
+      } else if (mok && n < p.N) {
+        if (HAS_R) {
+          va += rr[0];
+          vb += rr[1];
+        }
+        if (p.out_f) {
+          float* op = p.out_f + orow * p.ldo_f + gcol + n;
+          *(f32x4*)op = va;
+          *(f32x4*)(op + 4) = vb;
+        }
+        if (p.out_h) {
+          V8 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            h[r] = (T)va[r];
+            h[4 + r] = (T)vb[r];
+          }
+          *(V8*)((T*)p.out_h + hrow * p.ldo_h + gcol + n) = h;
+        }
+      }
+    };
+    if (p.resid) {
+      constexpr int RCH = STEPS % 2 == 0 ? 2 : 1;  // 2 steps = 16 registers of residual in flight: 4 already spill the 256x256 tile (245 VGPRs)
+#pragma unroll
+      for (int c0 = 0; c0 < STEPS; c0 += RCH) {
+        f32x4 rr[RCH][2];
+#pragma unroll
+        for (int u = 0; u < RCH; ++u) load_resid(c0 + u, rr[u]);
+#pragma unroll
+        for (int u = 0; u < RCH; ++u) do_step(c0 + u, std::true_type{}, rr[u]);
+      }
+    } else {
+      const f32x4 none[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int step = 0; step < STEPS; ++step) do_step(step, std::false_type{}, none);
     }
     return;
   }
