@@ -128,13 +128,19 @@ __global__ __launch_bounds__(64 * PC_NW) void posconv_kernel(PosConvArgs p) {
     const int t = rt * 16 + l15;
     if (t >= p.T) continue;
     float* xr = p.x + ((long)(u0 + slot) * p.T + t) * PC_C + grp * PC_CPG;
+    f32x4 bv[4], rv[4];  // every load of the tile before its first store (shared vmcnt: afx_gemm.hip epilogue note)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int col = c * 16 + kq * 4;
-      const f32x4 b = *(const f32x4*)(p.bias + grp * PC_CPG + col);
-      f32x4 v = acc[i][c] + b;
+      bv[c] = *(const f32x4*)(p.bias + grp * PC_CPG + col);
+      rv[c] = *(const f32x4*)(xr + col);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = c * 16 + kq * 4;
+      const f32x4 v = acc[i][c] + bv[c];
       const f32x2_t g0 = gelu_erf2(f32x2_t{v[0], v[1]}), g1 = gelu_erf2(f32x2_t{v[2], v[3]});
-      f32x4 r = *(const f32x4*)(xr + col);
+      f32x4 r = rv[c];
       r[0] += g0[0]; r[1] += g0[1]; r[2] += g1[0]; r[3] += g1[1];
       *(f32x4*)(xr + col) = r;
     }
