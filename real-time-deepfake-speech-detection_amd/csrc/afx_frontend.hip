@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
     V8 o;
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {  // two channels per packed-math GELU
-      const f32x2_t y = gelu_erf2(f32x2_t{fmaf(v[i] * rstd, ga[i], be[i]), fmaf(v[i + 1] * rstd, ga[i + 1], be[i + 1])});
+      const f32x2_t yin = f32x2_t{fmaf(v[i] * rstd, ga[i], be[i]), fmaf(v[i + 1] * rstd, ga[i + 1], be[i + 1])};
+      const f32x2_t y = sizeof(T) == 4 ? gelu_erf2(yin) : gelu_poly2(yin);  // fp32 = exact mode
       o[i] = (T)y[0];
       o[i + 1] = (T)y[1];
     }
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
         const f32x4 g1 = *(const f32x4*)(pv + 512 + cp * 32 + 16 + kq * 4), b1 = *(const f32x4*)(pv + 1024 + cp * 32 + 16 + kq * 4);
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
-          const f32x2_t ya = gelu_erf2(f32x2_t{fmaf(acc[2 * cp][r] * rstd, g0[r], b0[r]), fmaf(acc[2 * cp][r + 1] * rstd, g0[r + 1], b0[r + 1])});
-          const f32x2_t yb = gelu_erf2(f32x2_t{fmaf(acc[2 * cp + 1][r] * rstd, g1[r], b1[r]), fmaf(acc[2 * cp + 1][r + 1] * rstd, g1[r + 1], b1[r + 1])});
+          const f32x2_t ya = gelu_poly2(f32x2_t{fmaf(acc[2 * cp][r] * rstd, g0[r], b0[r]), fmaf(acc[2 * cp][r + 1] * rstd, g0[r + 1], b0[r + 1])});
+          const f32x2_t yb = gelu_poly2(f32x2_t{fmaf(acc[2 * cp + 1][r] * rstd, g1[r], b1[r]), fmaf(acc[2 * cp + 1][r + 1] * rstd, g1[r + 1], b1[r + 1])});
           if constexpr ((CONV0_DBG & 1) != 0) {
             va[r] = acc[2 * cp][r] * rstd; va[r + 1] = acc[2 * cp][r + 1] * rstd;
             vb[r] = acc[2 * cp + 1][r] * rstd; vb[r + 1] = acc[2 * cp + 1][r + 1] * rstd;

@@ -157,6 +157,21 @@ def test_gemm_asymmetric_identity_catches_transposes(K, dtype):
     assert torch.equal(of.cpu(), W.float().t())
 
 
+def test_epilogue_gelu_polynomial_is_erf_gelu_to_3e6(K):
+    """The half-precision epilogues evaluate erf-GELU without transcendentals (afx_common.h gelu_poly2).  A = I passes
+    a dense grid of fp16 values (|x| <= 12, clamp region included) through the GEMM untouched: the fp32 output must
+    be the exact erf-GELU of those values to 3e-6 absolute, and exactly x / exactly 0 beyond the clamp at +-5."""
+    n = 256
+    A = torch.eye(n).half()
+    W = (torch.linspace(-12, 12, n * n).reshape(n, n)).half()
+    of, _ = K.gemm("fp16", A.cuda(), W.cuda(), act="gelu")
+    x = W.float().t().double()
+    ref = 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+    got = of.cpu().double()
+    assert (got - ref).abs().max().item() <= 3e-6
+    assert torch.equal(got[x >= 5], x[x >= 5]) and bool((got[x <= -5] == 0).all())
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_weight_packing_layouts(K, dtype):
     g = torch.Generator().manual_seed(1)
