@@ -180,17 +180,11 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
         const f32x4 g0 = *(const f32x4*)(pv + 512 + cp * 32 + kq * 4), b0 = *(const f32x4*)(pv + 1024 + cp * 32 + kq * 4);
         const f32x4 g1 = *(const f32x4*)(pv + 512 + cp * 32 + 16 + kq * 4), b1 = *(const f32x4*)(pv + 1024 + cp * 32 + 16 + kq * 4);
 #pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-          const f32x2_t ya = gelu_poly2(f32x2_t{fmaf(acc[2 * cp][r] * rstd, g0[r], b0[r]), fmaf(acc[2 * cp][r + 1] * rstd, g0[r + 1], b0[r + 1])});
-          const f32x2_t yb = gelu_poly2(f32x2_t{fmaf(acc[2 * cp + 1][r] * rstd, g1[r], b1[r]), fmaf(acc[2 * cp + 1][r + 1] * rstd, g1[r + 1], b1[r + 1])});
-          if constexpr ((CONV0_DBG & 1) != 0) {
-            va[r] = acc[2 * cp][r] * rstd; va[r + 1] = acc[2 * cp][r + 1] * rstd;
-            vb[r] = acc[2 * cp + 1][r] * rstd; vb[r + 1] = acc[2 * cp + 1][r + 1] * rstd;
-          } else {
-            va[r] = ya[0]; va[r + 1] = ya[1];
-            vb[r] = yb[0]; vb[r + 1] = yb[1];
-          }
+        for (int r = 0; r < 4; ++r) {
+          va[r] = fmaf(acc[2 * cp][r] * rstd, g0[r], b0[r]);
+          vb[r] = fmaf(acc[2 * cp + 1][r] * rstd, g1[r], b1[r]);
         }
+        if constexpr ((CONV0_DBG & 1) == 0) gelu_poly8(va, vb);  // all 8 values step by step together
       }
       V8 h;
 #pragma unroll

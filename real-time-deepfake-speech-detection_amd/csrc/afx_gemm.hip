@@ -125,10 +125,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           vb[r] = fmaf(acc[i][2 * jp + 1][r] * rstd[i], ga1[r], be1[r]);
         }
         if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
-          const f32x2_t a0 = gelu_poly2(f32x2_t{va[0], va[1]}), a1 = gelu_poly2(f32x2_t{va[2], va[3]});
-          const f32x2_t b0 = gelu_poly2(f32x2_t{vb[0], vb[1]}), b1 = gelu_poly2(f32x2_t{vb[2], vb[3]});
-          va = f32x4{a0[0], a0[1], a1[0], a1[1]};
-          vb = f32x4{b0[0], b0[1], b1[0], b1[1]};
+          gelu_poly8(va, vb);
         } else if (!LEAN && p.act != ACT_NONE) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -232,10 +229,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       const int nb = n0 + wc * WN + jp * 32;  // first column of the tile pair
       f32x4 va = acc[i][2 * jp] + bia[jp][0], vb = acc[i][2 * jp + 1] + bia[jp][1];
       if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
-        const f32x2_t a0 = gelu_poly2(f32x2_t{va[0], va[1]}), a1 = gelu_poly2(f32x2_t{va[2], va[3]});
-        const f32x2_t b0 = gelu_poly2(f32x2_t{vb[0], vb[1]}), b1 = gelu_poly2(f32x2_t{vb[2], vb[3]});
-        va = f32x4{a0[0], a0[1], a1[0], a1[1]};
-        vb = f32x4{b0[0], b0[1], b1[0], b1[1]};
+        gelu_poly8(va, vb);
       } else if (!LEAN && p.act != ACT_NONE && !(p.dbg_nodma & 8)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -351,10 +345,7 @@ __device__ __forceinline__ void gemm_epilogue32(const GemmArgs& p, f32x16 (&acc)
     }
   };
   auto quad = [&](const f32x16& t, int q) { return f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]}; };
-  auto gelu4 = [&](f32x4& v) {
-    const f32x2_t a = gelu_poly2(f32x2_t{v[0], v[1]}), b = gelu_poly2(f32x2_t{v[2], v[3]});
-    v = f32x4{a[0], a[1], b[0], b[1]};
-  };
+  auto gelu4 = [&](f32x4& v) { v = gelu_poly4(v); };
   if constexpr (ROWLN) {
     __syncthreads();  // every wave is done reading the last K-tile: this LDS region becomes scratch
     float* red = (float*)smem;   // [WC][BM] partial row sums

@@ -138,11 +138,7 @@ __global__ __launch_bounds__(64 * PC_NW) void posconv_kernel(PosConvArgs p) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int col = c * 16 + kq * 4;
-      const f32x4 v = acc[i][c] + bv[c];
-      const f32x2_t g0 = gelu_poly2(f32x2_t{v[0], v[1]}), g1 = gelu_poly2(f32x2_t{v[2], v[3]});
-      f32x4 r = rv[c];
-      r[0] += g0[0]; r[1] += g0[1]; r[2] += g1[0]; r[3] += g1[1];
-      *(f32x4*)(xr + col) = r;
+      *(f32x4*)(xr + col) = rv[c] + gelu_poly4(acc[i][c] + bv[c]);
     }
   }
 }
