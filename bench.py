@@ -137,6 +137,10 @@ def main():
         "launches_per_step": g["launches"] // args.steps,
         "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
         "all_gemm_instances_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
+        # the QKV and FC1 products run as the 8-phase kernel on the rows that fill whole rounds of CUs plus a
+        # 128x128-tile kernel on the remaining rows; the pair is ONE timed launch here, two rows in rocprofv3's
+        # kernel stats: avg_launch_us = avg(8-phase) + (remainder launches / 8-phase launches) x avg(remainder)
+        "launch_note": "one launch = one GEMM of the path; round-split GEMMs (8-phase kernel + 128x128 remainder kernel) are timed as one",
     }
     # what the MFMA instruction these kernels issue sustains on this chip with nothing else in the loop
     # (tools/peak_probe.hip, random operands, profiles/r01_peak_probe.txt); `peak`/`frac` stay the nominal ones
