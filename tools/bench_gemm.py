@@ -25,6 +25,9 @@ SHAPES = [
     ("fc1   M=12736 K=1024 N=4096", "lin", (12736, 4096, 1024)),
     ("fc2   M=12736 K=4096 N=1024", "lin", (12736, 1024, 4096)),
     ("teacher fc1 M=3184 K=1024 N=4096", "lin", (3184, 4096, 1024)),
+    ("teacher qkv M=3184 K=1024 N=3072", "lin", (3184, 3072, 1024)),
+    ("teacher out M=3184 K=1024 N=1024", "lin", (3184, 1024, 1024)),
+    ("teacher fc2 M=3184 K=4096 N=1024", "lin", (3184, 1024, 4096)),
     ("square 4096^3", "lin", (4096, 4096, 4096)),
     ("square 8192^3", "lin", (8192, 8192, 8192)),
 ]
@@ -34,6 +37,7 @@ SETS = {
     "x32": [("8-phase 16x16x32", [("gemm_tile", 3), ("gemm_x32", 0)]), ("8-phase 32x32x16", [("gemm_tile", 3), ("gemm_x32", 1)]),
             ("1 wave/SIMD 32x32x16", [("gemm_tile", 3), ("gemm_x32", 2)])],
     "x32ln": [("16x16x32", ("gemm_x32", 0)), ("32x32x16", ("gemm_x32", 1)), ("1 wave/SIMD 32x32x16", ("gemm_x32", 2))],
+    "small": [("default", ("gemm_tile", -1)), ("128x128", ("gemm_tile", 0)), ("256x128", ("gemm_tile", 2)), ("8-phase 256x256", ("gemm_tile", 3))],
     "split": [("single kernel", ("gemm_split", 0)), ("rounds + remainder", ("gemm_split", 1))],
     "map": [("map0", ("gemm_map", 0)), ("map1", ("gemm_map", 1)), ("map2", ("gemm_map", 2))],
     "nt": [("A default", ("gemm_a_nt", 0)), ("A nt", ("gemm_a_nt", 1))],
