@@ -56,7 +56,11 @@ __global__ __launch_bounds__(64 * PC_NW) void posconv_kernel(PosConvArgs p) {
     const T* xb = xp + (long)(u0 + s) * p.xpad_batch + grp * PC_CPG;
     for (int q = wave; q < rows / 8; q += PC_NW) {
       int row = q * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      // slab swizzle: 16-byte chunk c of row r sits at c ^ (((r >> 1) & 3) << 1).  The fragment rows of tap j start
+      // at ANY row (abase + j); the K-style swizzle c ^ ((r >> 1) & 7) of the weight ring is conflict-free only for
+      // 16-row-aligned fragments (measured: 0.25 bank-conflict cycles per LDS cycle here), this one at every offset
+      // (bit 0 of the chunk stays the lane's kq bit, so the two kq values of a ds_read_b128 group never meet).
+      const int c = (lane & 7) ^ (((row >> 1) & 3) << 1);
       row = row < last_row ? row : last_row;
       dma16(xb + (long)row * PC_C + c * 8, s * slab_bytes + q * 1024);
     }
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(64 * PC_NW) void posconv_kernel(PosConvArgs p) {
     for (int i = 0; i < PC_MAXT; ++i) {
       if (wave + PC_NW * i < ntiles) {  // wave-uniform
         const int R = abase[i] + j;  // slab-local row: the swizzle is the one its DMA used
-        const int sw = (R >> 1) & 7;
+        const int sw = ((R >> 1) & 3) << 1;
         const V8 a0 = *(const V8*)(smem + aoff[i] + R * 128 + ((kq ^ sw) * 16));
         const V8 a1 = *(const V8*)(smem + aoff[i] + R * 128 + (((4 + kq) ^ sw) * 16));
 #pragma unroll
