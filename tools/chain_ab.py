@@ -1,4 +1,4 @@
-"""conf_chain_kernel A/B for a library variant (AFX_LIB): per-launch time from the engine's hipEvent classes and
+"""Kernel-class A/B (AFX_CLASS, default conf_chain_kernel) for a library variant (AFX_LIB): per-launch time from the engine's hipEvent classes and
 the student's logits on a fixed batch (printed so that two processes can be compared)."""
 import os
 import sys
@@ -19,6 +19,6 @@ for B, L in ((64, 64000), (64, 16000), (7, 64000)):
     eng.profile_begin()
     for _ in range(10):
         eng.forward(wave)
-    c = eng.profile_end()["conf_chain_kernel"]
+    c = eng.profile_end()[os.environ.get("AFX_CLASS", "conf_chain_kernel")]
     print(f"{os.environ.get('AFX_LIB', 'default')[-16:]:18s} B={B:3d} L={L:6d}: {c['ms'] / c['launches'] * 1e3:7.1f} us per launch; "
           f"logit checksum {out.double().sum().item():+.9f} first {out[0].tolist()}", flush=True)
