@@ -37,4 +37,30 @@ for Tin in (12799, 3199):
             times[name].append(e0.elapsed_time(e1) / 10 * 1e3)
     for name, _ in VARIANTS:
         print(f"Tin={Tin:6d} {name:22s} {statistics.median(times[name]):8.1f} us", flush=True)
+# the same attribution for the dominant kernel class (8-phase 256x256 + round split): FC1 (GELU, operand-type
+# output) and the out-projection (fp32 residual in and out)
+for name, (M, N, K_), kw in (("fc1 12736x4096x1024 gelu", (12736, 4096, 1024), dict(act="gelu", out_f=False, out_h=True)),
+                             ("qkv 12736x3072x1024", (12736, 3072, 1024), dict(out_f=False, out_h=True)),
+                             ("out 12736x1024x1024 +resid", (12736, 1024, 1024), dict(out_f=True, out_h=False)),
+                             ("fc2 12736x1024x4096 +resid", (12736, 1024, 4096), dict(out_f=True, out_h=False))):
+    a = torch.randn(M, K_, generator=g, device="cuda").half()
+    w = (torch.randn(N, K_, generator=g, device="cuda") * 0.03).half()
+    bias = torch.randn(N, generator=g, device="cuda")
+    resid = torch.randn(M, N, generator=g, device="cuda") if kw.get("out_f") else None
+    fn = lambda: K.gemm("fp16", a, w, bias=bias, resid=resid, **kw)
+    for _ in range(40):
+        fn()
+    times = {v: [] for v, _ in VARIANTS}
+    for _ in range(5):
+        for v, bits in VARIANTS:
+            check(lib().afx_debug_set(b"gemm_nodma", bits))
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            times[v].append(e0.elapsed_time(e1) / 10 * 1e3)
+    print(f"{name:30s} " + "  ".join(f"{v}: {statistics.median(t):6.1f}" for v, t in times.items()) + "  (us)", flush=True)
 check(lib().afx_debug_set(b"gemm_nodma", 0))
