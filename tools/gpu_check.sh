@@ -8,15 +8,19 @@ shift || true
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 ROOT=$(pwd)
+WL=${WORKLOAD:-conformer_student}   # bench.py --workload (xlsr_aasist = BASELINE config 3)
+: > "$OUT/summary.txt"
 
-echo "== pytest -m gpu $*" | tee "$OUT/summary.txt"
+if [ "${SKIP_TESTS:-0}" != "1" ]; then
+echo "== pytest -m gpu $*" | tee -a "$OUT/summary.txt"
 timeout -k 10 900 python -m pytest tests -m gpu -q --timeout 600 "$@" > "$OUT/pytest.log" 2>&1
 rc=$?
 tail -n 3 "$OUT/pytest.log" | tee -a "$OUT/summary.txt"
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pytest killed (rc=$rc): stopping" | tee -a "$OUT/summary.txt"; exit $rc; fi
+fi
 
-echo "== bench.py (N=1)" | tee -a "$OUT/summary.txt"
-timeout -k 10 600 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
+echo "== bench.py (N=1, $WL)" | tee -a "$OUT/summary.txt"
+timeout -k 10 600 python bench.py --workload $WL --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 rc=$?
 cat "$OUT/bench.json" | tee -a "$OUT/summary.txt"
 if [ $rc -ne 0 ]; then tail -n 20 "$OUT/bench.err" | tee -a "$OUT/summary.txt"; fi
@@ -25,7 +29,7 @@ if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "bench killed (rc=$rc): stoppin
 echo "== rocprofv3 --kernel-trace --stats" | tee -a "$OUT/summary.txt"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/prof" -- \
-  python3 "$ROOT/bench.py" --steps 10 --warmup 3 --cpu-sample 0 > "$ROOT/$OUT/prof.log" 2>&1
+  python3 "$ROOT/bench.py" --workload $WL --steps 10 --warmup 3 --cpu-sample 0 > "$ROOT/$OUT/prof.log" 2>&1
 rc=$?
 cd "$ROOT"
 STATS=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -n 1)

@@ -1,5 +1,6 @@
-"""Two forwards of the bench workload (Conformer student, B = 64, 4 s clips) for
-rocprofv3 --pmc passes (tools/pmc_traffic.sh): HBM traffic per kernel launch."""
+"""Three forwards of a bench workload for rocprofv3 --pmc passes (tools/pmc_traffic.sh, tools/pmc_lds.sh):
+HBM traffic / LDS conflicts per kernel launch.  AFX_WORKLOAD = conformer_student (B = 64, default) or
+xlsr_aasist (BASELINE config 3: 24-layer trunk + AASIST, B = 16); 4-s clips."""
 import os
 import sys
 
@@ -9,10 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "real-time-deepfake-speech-detection_amd")]
 from afx import engine, synth  # noqa: E402
 
-sd = synth.model_state_dict("ConformerModel", n_layers=6)
-eng = engine.Engine("conformer", n_layers=6, dtype=os.environ.get("AFX_DTYPE", "fp16"))
+wl = os.environ.get("AFX_WORKLOAD", "conformer_student")
+arch, oname, nl, B = {"conformer_student": ("conformer", "ConformerModel", 6, 64),
+                      "xlsr_aasist": ("xlsr_aasist", "XLSR_AASIST", 24, 16)}[wl]
+sd = synth.model_state_dict(oname, n_layers=nl)
+eng = engine.Engine(arch, n_layers=nl, dtype=os.environ.get("AFX_DTYPE", "fp16"))
 eng.load_state_dict(sd)
-wave = synth.waveforms(64, 64000).cuda()
+wave = synth.waveforms(B, 64000).cuda()
 for _ in range(3):
     eng.forward(wave)
 torch.cuda.synchronize()

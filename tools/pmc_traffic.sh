@@ -2,7 +2,7 @@
 # HBM traffic per kernel launch of the bench workload: two rocprofv3 PMC passes (FETCH_SIZE,
 # WRITE_SIZE -- they do not fit one pass; counters only, no trace domain beside --kernel-trace),
 # corrected as MI355X_MICROARCH.md "HBM" prescribes (gfx950: FETCH_SIZE x 2; both in KB).
-# Usage: bash tools/pmc_traffic.sh <tag>   ->  gpurun_out/<tag>/pmc_traffic.json
+# Usage: [AFX_WORKLOAD=xlsr_aasist] bash tools/pmc_traffic.sh <tag>   ->  gpurun_out/<tag>/pmc_traffic.json
 set -u
 TAG=${1:-pmc_traffic}
 ROOT=$(pwd)
@@ -36,8 +36,9 @@ for k, d in sorted(agg.items()):
     res[k] = {"launches_sampled": len(f), "fetch_bytes_per_launch": 2 * 1024 * sum(f) / len(f),
               "write_bytes_per_launch": 1024 * sum(w) / len(w)}
     print(f"{k[:70]:70s} n={len(f):4d} fetch {res[k]['fetch_bytes_per_launch']/1e6:9.1f} MB  write {res[k]['write_bytes_per_launch']/1e6:9.1f} MB")
-json.dump({"note": "FETCH_SIZE x2 (gfx950 correction) and WRITE_SIZE, KB -> bytes, mean per launch over 3 forwards of the "
-                   "Conformer student at B=64 (tools/pmc_forward.py)", "kernels": res}, open(out + "/pmc_traffic.json", "w"), indent=1)
+import os
+json.dump({"note": "FETCH_SIZE x2 (gfx950 correction) and WRITE_SIZE, KB -> bytes, mean per launch over 3 forwards of "
+                   "workload " + os.environ.get("AFX_WORKLOAD", "conformer_student") + " (tools/pmc_forward.py)", "kernels": res}, open(out + "/pmc_traffic.json", "w"), indent=1)
 PYEOF
 find "$OUT" -name "*counter_collection.csv" -size +20M -delete 2>/dev/null
 exit 0
