@@ -10,6 +10,11 @@
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// The loop body is ONE asm statement of 8 MFMAs on 8 accumulators held in place ("+v"): left to hipcc the
+// eight f32x4 accumulators are shuffled through v_accvgpr_read / v_accvgpr_write every iteration (round 1's
+// probe: 8 MFMA + 52 accvgpr moves + 3 s_nop per iteration, which measured the moves, not the instruction
+// -- its "1.32 PFLOP/s ceiling of 16x16x32" was an artefact).  Check with
+//   /opt/rocm/lib/llvm/bin/llvm-objdump -d --offloading ... : the loop must be 8 v_mfma + s_add + s_cmp + s_cbranch.
 template <bool ZERO>
 __global__ __launch_bounds__(256) void mfma_f16(float* out, int iters) {
   const int l = threadIdx.x;
@@ -18,15 +23,22 @@ __global__ __launch_bounds__(256) void mfma_f16(float* out, int iters) {
     a[i] = ZERO ? (_Float16)0.f : (_Float16)(((l * 37 + i * 11) % 61 - 30) * 0.03125f);
     b[i] = ZERO ? (_Float16)0.f : (_Float16)(((l * 53 + i * 7) % 59 - 29) * 0.03125f);
   }
-  f32x4 c[8];
-  for (int j = 0; j < 8; ++j) c[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
   for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c[j], 0, 0, 0);
+    asm volatile(
+        "v_mfma_f32_16x16x32_f16 %0, %8, %9, %0\n\t"
+        "v_mfma_f32_16x16x32_f16 %1, %8, %9, %1\n\t"
+        "v_mfma_f32_16x16x32_f16 %2, %8, %9, %2\n\t"
+        "v_mfma_f32_16x16x32_f16 %3, %8, %9, %3\n\t"
+        "v_mfma_f32_16x16x32_f16 %4, %8, %9, %4\n\t"
+        "v_mfma_f32_16x16x32_f16 %5, %8, %9, %5\n\t"
+        "v_mfma_f32_16x16x32_f16 %6, %8, %9, %6\n\t"
+        "v_mfma_f32_16x16x32_f16 %7, %8, %9, %7"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7)
+        : "v"(a), "v"(b));
   }
-  float s = 0.f;
-  for (int j = 0; j < 8; ++j) s += c[j][0] + c[j][1] + c[j][2] + c[j][3];
-  out[blockIdx.x * 256 + l] = s;
+  const f32x4 t = ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7));
+  out[blockIdx.x * 256 + l] = t[0] + t[1] + t[2] + t[3];
 }
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 template <bool ZERO>
