@@ -52,11 +52,18 @@ def graph_attention(sd, p, x, temp):
     return F.selu(_bn(sd, p + "bn.", y, 2))
 
 
-def graph_pool(sd, p, h, k):
-    """GraphPool, models/aasist_modules.py:296-338 (descending top-k order)."""
+def graph_pool(sd, p, h, k, taps=None):
+    """GraphPool, models/aasist_modules.py:296-338 (descending top-k order).  With ``taps``: the kept indices and,
+    per utterance, the smallest score gap that decides membership or order of the kept nodes (the discontinuity of
+    the reference model: a perturbation larger than that gap changes which nodes are paired downstream)."""
     s = torch.sigmoid(F.linear(h, sd[p + "proj.weight"], sd[p + "proj.bias"]))
     n = max(int(h.shape[1] * k), 1)
     _, idx = torch.topk(s, n, dim=1)
+    if taps is not None:
+        v, _ = torch.sort(s.squeeze(-1), dim=1, descending=True)
+        gap = (v[:, :n] - v[:, 1:n + 1]).min(dim=1)[0] if v.shape[1] > n else (v[:, :n - 1] - v[:, 1:n]).min(dim=1)[0]
+        taps.setdefault("pool_idx", {})[p] = idx.squeeze(-1)
+        taps.setdefault("pool_margin", {})[p] = gap
     return torch.gather(h * s, 1, idx.expand(-1, -1, h.shape[2]))
 
 
@@ -108,22 +115,22 @@ def aasist_front(sd, feats):
 
 def aasist_graph(sd, e_S, e_T, taps=None):
     """models/xlsr_aasist.py:111-177."""
-    out_S = graph_pool(sd, "pool_S.", graph_attention(sd, "GAT_layer_S.", e_S, 2.0), 0.5)
-    out_T = graph_pool(sd, "pool_T.", graph_attention(sd, "GAT_layer_T.", e_T, 2.0), 0.5)
+    out_S = graph_pool(sd, "pool_S.", graph_attention(sd, "GAT_layer_S.", e_S, 2.0), 0.5, taps)
+    out_T = graph_pool(sd, "pool_T.", graph_attention(sd, "GAT_layer_T.", e_T, 2.0), 0.5, taps)
     if taps is not None:
         taps["out_S"], taps["out_T"] = out_S, out_T
     # branch 1 (Q3: raw parameter as master)
     T1, S1, m1 = htrg_graph_attention(sd, "HtrgGAT_layer_ST11.", out_T, out_S, sd["master1"], 100.0)
-    S1 = graph_pool(sd, "pool_hS1.", S1, 0.5)
-    T1 = graph_pool(sd, "pool_hT1.", T1, 0.5)
+    S1 = graph_pool(sd, "pool_hS1.", S1, 0.5, taps)
+    T1 = graph_pool(sd, "pool_hT1.", T1, 0.5, taps)
     Ta, Sa, ma = htrg_graph_attention(sd, "HtrgGAT_layer_ST12.", T1, S1, m1, 100.0)
     T1 = T1 + Ta
     S1 = S1 + 1  # Q1
     m1 = m1 + ma
     # branch 2
     T2, S2, m2 = htrg_graph_attention(sd, "HtrgGAT_layer_ST21.", out_T, out_S, sd["master2"], 100.0)
-    S2 = graph_pool(sd, "pool_hS2.", S2, 0.5)
-    T2 = graph_pool(sd, "pool_hT2.", T2, 0.5)
+    S2 = graph_pool(sd, "pool_hS2.", S2, 0.5, taps)
+    T2 = graph_pool(sd, "pool_hT2.", T2, 0.5, taps)
     Ta, Sa, ma = htrg_graph_attention(sd, "HtrgGAT_layer_ST22.", T2, S2, m2, 100.0)
     T2 = T2 + Ta
     S2 = S2 + Sa

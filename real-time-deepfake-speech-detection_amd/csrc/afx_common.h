@@ -24,12 +24,6 @@ struct BF16 {
   static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
-  // 32x32x16: the full-rate form (measured 1.94 PFLOP/s on random operands against 1.32 for 16x16x32,
-  // tools/peak_probe.hip).  A: lane (r = l&31, h = l>>5) holds A[r][8h + j]; B likewise B[8h + j][r];
-  // D: col = l&31, row = (reg&3) + 8 (reg>>2) + 4 (l>>5).
-  static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
 };
 struct FP16 {
   typedef _Float16 T;
@@ -37,9 +31,6 @@ struct FP16 {
   typedef f16x4 V4;
   static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
 };
 

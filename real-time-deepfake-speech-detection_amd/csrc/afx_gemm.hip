@@ -23,6 +23,16 @@
 
 #include <type_traits>
 
+// Timing-only switches of the epilogue (GemmArgs::dbg_nodma: 8 no activation, 16 narrow stores, 32 no stores,
+// 64 no epilogue -- WRONG results) exist only in the attribution build (make attr -> lib/libafx_attr.so,
+// -DAFX_ATTR, loaded through AFX_LIB by tools/bench_convln_attr.py / bench_gemm_k.py); the product library
+// compiles them out, so no environment variable or debug key can switch results off.
+#ifdef AFX_ATTR
+#define AFX_DBG(p, bit) ((p).dbg_nodma & (bit))
+#else
+#define AFX_DBG(p, bit) 0
+#endif
+
 namespace afx {
 
 // ---------------------------------------------------------------------------------------
@@ -35,7 +45,7 @@ namespace afx {
 // fallback: ~300 KB of code around a 12-KB K-loop, refetched through the instruction cache after every tile.
 template <class HT, int BM, int BN, int WR, int WC, bool ROWLN, bool LEAN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / WR / 16][BN / WC / 16], char* smem,
-                                              int m0, int n0, int g) {
+                                              int m0, int n0, int g, long out_f_off = 0) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
   typedef typename HT::V4 V4;
@@ -124,7 +134,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           va[r] = fmaf(acc[i][2 * jp][r] * rstd[i], ga0[r], be0[r]);
           vb[r] = fmaf(acc[i][2 * jp + 1][r] * rstd[i], ga1[r], be1[r]);
         }
-        if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
+        if (p.act == ACT_GELU && !(AFX_DBG(p, 8))) {
           gelu_poly8(va, vb);
         } else if (!LEAN && p.act != ACT_NONE) {
 #pragma unroll
@@ -139,7 +149,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           va[r] = __uint_as_float(sw[0]);
           vb[r] = __uint_as_float(sw[1]);
         }
-        if (p.dbg_nodma & 32) {  // timing only: no stores
+        if (AFX_DBG(p, 32)) {  // timing only: no stores
           asm volatile("" :: "v"(va), "v"(vb));
           continue;
         }
@@ -168,7 +178,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
   const int gcol = g * p.g_n;
   const float alpha = p.alpha;
   const int kq = lane >> 4;
-  if (LEAN || ((p.N & 7) == 0 && !(p.dbg_nodma & 16))) {
+  if (LEAN || ((p.N & 7) == 0 && !(AFX_DBG(p, 16)))) {
     // Wide-store epilogue.  After the MFMAs a lane holds 4 consecutive columns of one row
     // (8 B of fp16); v_permlane16_swap exchanges 16-lane rows between the registers of two
     // adjacent 16-column tiles so that every lane ends up with 8 consecutive columns:
@@ -228,9 +238,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       row_of(i, orow, hrow, mok);
       const int nb = n0 + wc * WN + jp * 32;  // first column of the tile pair
       f32x4 va = acc[i][2 * jp] + bia[jp][0], vb = acc[i][2 * jp + 1] + bia[jp][1];
-      if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
+      if (p.act == ACT_GELU && !(AFX_DBG(p, 8))) {
         gelu_poly8(va, vb);
-      } else if (!LEAN && p.act != ACT_NONE && !(p.dbg_nodma & 8)) {
+      } else if (!LEAN && p.act != ACT_NONE && !(AFX_DBG(p, 8))) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           va[r] = apply_act(va[r], p.act);
@@ -248,7 +258,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         vb[r] = __uint_as_float(sw[1]);
       }
       const int n = nb + cb;  // this lane now owns columns n .. n+7 (va | vb)
-      if (p.dbg_nodma & 32) {  // timing only: no stores
+      if (AFX_DBG(p, 32)) {  // timing only: no stores
         asm volatile("" :: "v"(va), "v"(vb));
       } else if (mok && n < p.N) {
         if (HAS_R) {
@@ -256,7 +266,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           vb += rr[1];
         }
         if (p.out_f) {
-          float* op = p.out_f + orow * p.ldo_f + gcol + n;
+          float* op = p.out_f + out_f_off + orow * p.ldo_f + gcol + n;
           *(f32x4*)op = va;
           *(f32x4*)(op + 4) = vb;
         }
@@ -301,7 +311,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       if (n >= p.N) continue;
       f32x4 v = acc[i][j];
       if (p.bias) v += *(const f32x4*)(p.bias + gcol + n);
-      if (p.act != ACT_NONE && !(p.dbg_nodma & 8)) {
+      if (p.act != ACT_NONE && !(AFX_DBG(p, 8))) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
       }
@@ -314,232 +324,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         for (int r = 0; r < 4; ++r) h[r] = (T)v[r];
         *(V4*)((T*)p.out_h + hrow * p.ldo_h + gcol + n) = h;
       }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// Epilogue for accumulators of v_mfma_f32_32x32x16 (8-phase kernels, 2 x 4 waves).  With the operands
-// swapped (W fragment first) a lane holds, for tile (i, j) of the wave's block, output row
-// m = 32 i + (lane & 31) and columns 32 j + 8 q + 4 h + c in register 4 q + c (h = lane >> 5): four
-// quads of 4 consecutive columns.  v_permlane32_swap pairs quads 2p / 2p+1 across the two half-waves so
-// that every lane ends up with 8 consecutive columns starting at 16 p + 8 h (16-B fp16 / 32-B fp32
-// stores).  Same contract as gemm_epilogue: bias hoisted, residual rows prefetched one step ahead.
-// ---------------------------------------------------------------------------------------
-template <class HT, int BM, int BN, bool ROWLN, int WR = 2, int WC = 4>
-__device__ __forceinline__ void gemm_epilogue32(const GemmArgs& p, f32x16 (&acc)[BM / WR / 32][BN / WC / 32], char* smem,
-                                                int m0, int n0, int g) {
-  typedef typename HT::T T;
-  typedef typename HT::V8 V8;
-  constexpr int WM = BM / WR, WN = BN / WC, MT = WM / 32, NT = WN / 32;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave / WC, wc = wave % WC;
-  const int l31 = lane & 31, h = lane >> 5;
-  auto swap_pair = [&](f32x4& a, f32x4& b) {  // quads 2p (a) and 2p+1 (b) -> this lane's 8 consecutive columns (a | b)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[c]), __float_as_uint(b[c]), false, false);
-      a[c] = __uint_as_float(sw[0]);
-      b[c] = __uint_as_float(sw[1]);
-    }
-  };
-  auto quad = [&](const f32x16& t, int q) { return f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]}; };
-  auto gelu4 = [&](f32x4& v) { v = gelu_poly4(v); };
-  if constexpr (ROWLN) {
-    __syncthreads();  // every wave is done reading the last K-tile: this LDS region becomes scratch
-    float* red = (float*)smem;   // [WC][BM] partial row sums
-    float* vec = red + WC * BM;  // [3][BN]: bias, gamma, beta through LDS (one global round trip per workgroup)
-    for (int t = tid; t < BN; t += 64 * WR * WC) {
-      vec[t] = p.bias[n0 + t];
-      vec[BN + t] = p.ln_gamma[n0 + t];
-      vec[2 * BN + t] = p.ln_beta[n0 + t];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 b = *(const f32x4*)(vec + wc * WN + j * 32 + 8 * q + 4 * h);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] += b[c];
-      }
-    float mean[MT], rstd[MT];
-    const float invn = 1.0f / (float)BN;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      float sm = 0.f;
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sm += acc[i][j][r];
-      sm = pair_sum(sm);
-      if (h == 0) red[wc * BM + wr * WM + i * 32 + l31] = sm;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int row = wr * WM + i * 32 + l31;
-      float sm = 0.f;
-#pragma unroll
-      for (int c = 0; c < WC; ++c) sm += red[c * BM + row];
-      mean[i] = sm * invn;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      float sm = 0.f;
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc[i][j][r] -= mean[i];
-          sm = fmaf(acc[i][j][r], acc[i][j][r], sm);
-        }
-      sm = pair_sum(sm);
-      if (h == 0) red[wc * BM + wr * WM + i * 32 + l31] = sm;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int row = wr * WM + i * 32 + l31;
-      float sm = 0.f;
-#pragma unroll
-      for (int c = 0; c < WC; ++c) sm += red[c * BM + row];
-      rstd[i] = 1.0f / sqrtf(sm * invn + p.ln_eps);
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int pp = 0; pp < 2; ++pp) {
-        const int ca = wc * WN + j * 32 + 16 * pp + 4 * h, cb2 = ca + 8;  // columns of quads 2p and 2p+1 before the swap
-        const f32x4 ga0 = *(const f32x4*)(vec + BN + ca), be0 = *(const f32x4*)(vec + 2 * BN + ca);
-        const f32x4 ga1 = *(const f32x4*)(vec + BN + cb2), be1 = *(const f32x4*)(vec + 2 * BN + cb2);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int m = m0 + wr * WM + i * 32 + l31;
-          f32x4 va = quad(acc[i][j], 2 * pp), vb = quad(acc[i][j], 2 * pp + 1);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            va[c] = fmaf(va[c] * rstd[i], ga0[c], be0[c]);
-            vb[c] = fmaf(vb[c] * rstd[i], ga1[c], be1[c]);
-          }
-          if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
-            gelu4(va);
-            gelu4(vb);
-          }
-          swap_pair(va, vb);
-          if (p.dbg_nodma & 32) {  // timing only: no stores
-            asm volatile("" :: "v"(va), "v"(vb));
-            continue;
-          }
-          if (m >= p.M) continue;
-          const int n = n0 + wc * WN + j * 32 + 16 * pp + 8 * h;
-          const long orow = (long)(m / p.rpb) * p.o_batch_rows + (m % p.rpb) + p.o_row_off;
-          const long hrow = (long)(m / p.rpb) * p.oh_batch_rows + (m % p.rpb) + p.oh_row_off;
-          if (p.out_f) {
-            float* op = p.out_f + orow * p.ldo_f + n;
-            *(f32x4*)op = va;
-            *(f32x4*)(op + 4) = vb;
-          }
-          if (p.out_h) {
-            V8 hv;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              hv[c] = (T)va[c];
-              hv[4 + c] = (T)vb[c];
-            }
-            *(V8*)((T*)p.out_h + hrow * p.ldo_h + n) = hv;
-          }
-        }
-      }
-    return;
-  } else {
-    const int gcol = g * p.g_n;
-    const float alpha = p.alpha;
-    f32x4 bia[NT][4];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wc * WN + j * 32 + 8 * q + 4 * h;
-        bia[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) bia[j][q] = *(const f32x4*)(p.bias + gcol + n);
-      }
-    const bool one_batch = p.rpb >= p.M;
-    auto row_of = [&](int i, long& orow, long& hrow, bool& mok) {
-      const int m = m0 + wr * WM + i * 32 + l31;
-      mok = m < p.M;
-      const int mc = mok ? m : p.M - 1;
-      const int bq = one_batch ? 0 : mc / p.rpb, br = one_batch ? mc : mc - bq * p.rpb;
-      orow = (long)bq * p.o_batch_rows + br + p.o_row_off;
-      hrow = (long)bq * p.oh_batch_rows + br + p.oh_row_off;
-    };
-    constexpr int STEPS = MT * NT * 2;
-    auto col_of = [&](int step) { return n0 + wc * WN + ((step >> 1) % NT) * 32 + 16 * (step & 1) + 8 * h; };
-    auto load_resid = [&](int step, f32x4 (&r)[2]) {
-      long orow, hrow;
-      bool mok;
-      row_of(step / (2 * NT), orow, hrow, mok);
-      const int n = col_of(step);
-      r[0] = r[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (mok && n < p.N) {
-        const float* rp = p.resid + orow * p.ldr + gcol + n;
-        r[0] = *(const f32x4*)rp;
-        r[1] = *(const f32x4*)(rp + 4);
-      }
-    };
-    f32x4 rcur[2], rnxt[2];
-    if (p.resid) load_resid(0, rcur);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      long orow, hrow;
-      bool mok;
-      row_of(i, orow, hrow, mok);
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {  // (nested so that each level unrolls fully: one flat 2 MT NT loop does not at 4 x 4)
-      const int step = (i * NT + j) * 2 + pp;
-      if (p.resid && step + 1 < STEPS) load_resid(step + 1, rnxt);
-      f32x4 va = quad(acc[i][j], 2 * pp) + bia[j][2 * pp], vb = quad(acc[i][j], 2 * pp + 1) + bia[j][2 * pp + 1];
-      if (p.act == ACT_GELU && !(p.dbg_nodma & 8)) {
-        gelu4(va);
-        gelu4(vb);
-      }  // (other activations: the launcher keeps them on the 16x16x32 kernels)
-      if (alpha != 1.f) {
-        va *= alpha;
-        vb *= alpha;
-      }
-      swap_pair(va, vb);
-      const int n = col_of(step);
-      if (p.dbg_nodma & 32) {  // timing only: no stores
-        asm volatile("" :: "v"(va), "v"(vb));
-      } else if (mok && n < p.N) {
-        if (p.resid) {
-          va += rcur[0];
-          vb += rcur[1];
-        }
-        if (p.out_f) {
-          float* op = p.out_f + orow * p.ldo_f + gcol + n;
-          *(f32x4*)op = va;
-          *(f32x4*)(op + 4) = vb;
-        }
-        if (p.out_h) {
-          V8 hv;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            hv[c] = (T)va[c];
-            hv[4 + c] = (T)vb[c];
-          }
-          *(V8*)((T*)p.out_h + hrow * p.ldo_h + gcol + n) = hv;
-        }
-      }
-      rcur[0] = rnxt[0];
-      rcur[1] = rnxt[1];
-    }
     }
   }
 }
@@ -744,7 +528,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 //        were retired before the reading phase's first barrier (B0: ph1 reads are issued
 //        first and retired by lgkmcnt(8) there -> staged in ph2).
 // =======================================================================================
-template <class HT, int BM, int BN, bool ROWLN, bool X32>
+template <class HT, int BM, int BN, bool ROWLN>
 __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
@@ -757,9 +541,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   //     phase 4: --                stage R1(t+2)   MFMA (F1,R0)
   constexpr bool WIDE = BN > BM;              // A is the resident operand
   constexpr int RA = BM / 2, RB = BN / 2;     // rows of an A / B half-tile
-  // X32: v_mfma_f32_32x32x16 (32-row fragments, 4 k-steps of 16 per K-tile) -- the full-rate instruction;
-  // otherwise v_mfma_f32_16x16x32 (16-row fragments, 2 k-steps of 32), which issues at half that rate.
-  constexpr int FR = X32 ? 32 : 16, KSN = X32 ? 4 : 2;
+  // v_mfma_f32_16x16x32: 16-row fragments, 2 k-steps of 32 per K-tile (same FLOP per clock as 32x32x16 -- 16 against
+  // 32 cycles per instruction; its 16-MFMA segments of 256 cycles are what the two wave rows alternate on)
+  constexpr int FR = 16, KSN = 2;
   constexpr int MTH = RA / 2 / FR, NTH = RB / 4 / FR;  // fragments per half per wave
   constexpr int DA = RA / 64, DB = RB / 64;   // LDS-DMA instructions per thread per half-tile
   constexpr int OFF_A0 = 0, OFF_A1 = RA * 128, OFF_B0 = 2 * RA * 128, OFF_B1 = OFF_B0 + RB * 128;
@@ -775,7 +559,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   const T* Ag = (const T*)p.A + (long)g * p.g_a;
   const T* Wg = (const T*)p.W + (long)g * p.g_w;
   const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
-  const int nwg = nM * nN;
+  const int ntile = nM * nN;
+  const int nsl = p.split_k > 1 ? p.split_k : 1;  // split-K: work item = (K slice, tile), slice-major
+  const int nwg = ntile * nsl;
+  const int nk = (p.K >> 6) / nsl;                // K-tiles per work item
+  int slice = 0;
 
   // DMA source pointers.  Piece (i*8 + wave) of a half-tile is LDS rows 8(i*8+wave) .. +7,
   // lane l -> row l>>3, 16-B slot l&7 holding logical chunk (l&7) ^ ((row>>1)&7).
@@ -795,6 +583,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
       const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
       L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
     }
+    slice = L / ntile;  // an XCD's contiguous run of the order stays inside one K slice: shared A / W panels meet in its L2
+    L -= slice * ntile;
     if (p.map_mode == 2) {
       constexpr int GM = 8;
       const int width = GM * nN, grp = L / width, first = grp * GM;
@@ -807,6 +597,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     }
     m0 = pm * BM;
     n0 = pn * BN;
+    const int k0 = slice * nk * 64;  // first k of this work item
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -815,7 +606,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         int m = m0 + (r / (RA / 2)) * (BM / 2) + h * (RA / 2) + r % (RA / 2);
         m = m < p.M ? m : p.M - 1;
-        srcA[h][i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
+        srcA[h][i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8 + k0;
       }
 #pragma unroll
       for (int i = 0; i < DB; ++i) {
@@ -823,7 +614,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         int n = n0 + (r / (RB / 4)) * (BN / 4) + h * (RB / 4) + r % (RB / 4);
         n = n < p.N ? n : p.N - 1;
-        srcB[h][i] = Wg + (long)n * p.ldw + c * 8;
+        srcB[h][i] = Wg + (long)n * p.ldw + c * 8 + k0;
       }
     }
   };
@@ -852,7 +643,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   const char* aR = smem + (wr * (RA / 2) + frow) * 128;
   const char* bR = smem + (wc * (RB / 4) + frow) * 128;
 
-  typename std::conditional<X32, f32x16, f32x4>::type acc[2 * MTH][2 * NTH];
+  f32x4 acc[2 * MTH][2 * NTH];
   // the resident operand keeps both halves in registers, the flowing one a single half
   V8 af[WIDE ? 2 : 1][MTH][KSN], wf[WIDE ? 1 : 2][NTH][KSN];
 
@@ -878,12 +669,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
       for (int mi = 0; mi < MTH; ++mi)
 #pragma unroll
         for (int nj = 0; nj < NTH; ++nj) {
-          if constexpr (X32)
-            acc[ah * MTH + mi][bh * NTH + nj] =
-                HT::mfma32(wf[WIDE ? 0 : bh][nj][ks], af[WIDE ? ah : 0][mi][ks], acc[ah * MTH + mi][bh * NTH + nj]);
-          else
-            acc[ah * MTH + mi][bh * NTH + nj] =
-                HT::mfma(wf[WIDE ? 0 : bh][nj][ks], af[WIDE ? ah : 0][mi][ks], acc[ah * MTH + mi][bh * NTH + nj]);
+          acc[ah * MTH + mi][bh * NTH + nj] =
+              HT::mfma(wf[WIDE ? 0 : bh][nj][ks], af[WIDE ? ah : 0][mi][ks], acc[ah * MTH + mi][bh * NTH + nj]);
         }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -902,7 +689,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);     \
   } while (0)
 
-  const int nk = p.K >> 6;
   // prologue of an output tile: all of K-tile 0 and three half-tiles of K-tile 1 go out
   auto issue_prologue = [&] {
     stageR(0, 0, 0);
@@ -984,21 +770,21 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     // and the first K-tile's fill hide behind the bias / activation / store work.  (The row-
     // LayerNorm epilogue keeps its scratch in the one half-tile the prologue does not write.)
     const int m0c = m0, n0c = n0;
+    const long plane = (long)slice * p.part_stride;  // split-K: this work item's partial plane (0 otherwise)
     const int vn = v + gridDim.x;
     if (vn < nwg) {
       setup(vn);
       issue_prologue();
     }
-    if (p.dbg_nodma & 64) {  // timing only: no epilogue at all
+    if (AFX_DBG(p, 64)) {  // timing only: no epilogue at all
 #pragma unroll
       for (int i = 0; i < 2 * MTH; ++i)
 #pragma unroll
-        for (int j = 0; j < 2 * NTH; ++j)  // (element-wise: a 512-bit "v" operand is not a valid constraint in the host pass)
+        for (int j = 0; j < 2 * NTH; ++j)
 #pragma unroll
-          for (int r = 0; r < (X32 ? 16 : 4); ++r) asm volatile("" :: "v"(acc[i][j][r]));
+          for (int r = 0; r < 4; ++r) asm volatile("" :: "v"(acc[i][j][r]));
     } else {
-      if constexpr (X32) gemm_epilogue32<HT, BM, BN, ROWLN>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
-      else gemm_epilogue<HT, BM, BN, 2, 4, ROWLN, true>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
+      gemm_epilogue<HT, BM, BN, 2, 4, ROWLN, true>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g, plane);
     }
     if (vn >= nwg) break;
     v = vn;
@@ -1006,13 +792,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 #undef AFX_BAR
 }
 
-template <class HT, int BM, int BN, bool ROWLN, bool X32>
+template <class HT, int BM, int BN, bool ROWLN>
 static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static_assert(lds <= 160 * 1024, "two K-tile buffers must fit the 160 KB LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm8_kernel<HT, BM, BN, ROWLN, X32>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm8_kernel<HT, BM, BN, ROWLN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -1025,169 +811,9 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
     n_cu = prop.multiProcessorCount & ~7;  // a multiple of the 8 XCDs (the tile remap relies on it)
     if (n_cu < 8) n_cu = 8;
   }
-  const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+  const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * (p.split_k > 1 ? p.split_k : 1);
   dim3 grid(tiles < n_cu ? tiles : n_cu, 1, groups);  // persistent: at most one workgroup per CU
-  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN, X32>), grid, dim3(512), lds, s, p);
-  return hipGetLastError();
-}
-
-// =======================================================================================
-// Full-rate tile kernel: v_mfma_f32_32x32x16 with ONE wave per SIMD.
-// tools/peak_probe.hip: the 16x16x32 instruction issues at half the rate of 32x32x16 (1.32 against 1.94
-// PFLOP/s sustained on random operands), so every kernel above tops out near 1.3 PFLOP/s however well
-// it is scheduled; and the 8-phase schedule cannot simply switch instruction -- its MFMA segments halve
-// to 256 cycles and no longer cover the other wave row's LDS reads (measured slower, profiles/).
-// Here 4 waves (one per SIMD, up to 512 registers each) own 128 x 128 outputs apiece: 16 accumulator tiles
-// (256 registers), 8 fragment reads per 16 MFMAs, issued one k-step (16 wide) ahead into a second register
-// set so that a wave's own LDS reads ride in the shadow of its MFMAs.  Two 64-wide K-tiles in LDS; the
-// operand DMA of tile t+2 goes out, and the first fragments of tile t+1 are requested, just before the LAST
-// k-step of tile t (one barrier + one vmcnt(0) per K-tile, both already satisfied in steady state).
-// Instances: 256 x 256 (2 x 2 waves) and the row-complete 128 x 512 conv tile (1 x 4 waves).
-// MEASURED (profiles/r01_gemm32_ab.txt): correct and deterministic, but 1.10 PFLOP/s at 8192^3 against 1.30
-// for the 8-phase 16x16x32 kernel, and 15-25 % slower on the path's K = 1024 / 1536 shapes: with one wave
-// per SIMD nothing covers the wave's own barrier + 16 DMA issues per K-tile (~300 of 2048 cycles) or its
-// epilogue.  Kept behind the gemm_x32 = 2 knob as the A/B baseline for the next attempt (DMA and fragment
-// reads slotted between the MFMAs); the default dispatch does not use it.
-// =======================================================================================
-template <class HT, int BM, int BN, int WR, int WC, bool ROWLN>
-__global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs p) {
-  typedef typename HT::T T;
-  typedef typename HT::V8 V8;
-  constexpr int NW = WR * WC;
-  static_assert(NW == 4, "one wave per SIMD");
-  constexpr int WM = BM / WR, WN = BN / WC, MT = WM / 32, NT = WN / 32;
-  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
-  constexpr int AI = BM / (8 * NW), WI = BN / (8 * NW);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave / WC, wc = wave % WC;
-  const int g = blockIdx.z;
-  int pm, pn;
-  {
-    const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
-    const int nwg = nM * nN;
-    int L = blockIdx.x;
-    if (p.map_mode >= 1) {
-      const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
-      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-    }
-    if (p.map_mode == 2) {
-      constexpr int GM = 8;
-      const int width = GM * nN, grp = L / width, first = grp * GM;
-      const int gsz = nM - first < GM ? nM - first : GM;
-      pm = first + (L % width) % gsz;
-      pn = (L % width) / gsz;
-    } else {
-      pm = L / nN;
-      pn = L % nN;
-    }
-  }
-  const int m0 = pm * BM, n0 = pn * BN;
-  const T* Ag = (const T*)p.A + (long)g * p.g_a;
-  const T* Wg = (const T*)p.W + (long)g * p.g_w;
-  const T* a_src[AI];
-  const T* w_src[WI];
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int row = (i * NW + wave) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    int m = m0 + row;
-    m = m < p.M ? m : p.M - 1;
-    a_src[i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < WI; ++i) {
-    const int row = (i * NW + wave) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    int n = n0 + row;
-    n = n < p.N ? n : p.N - 1;
-    w_src[i] = Wg + (long)n * p.ldw + c * 8;
-  }
-  const unsigned lds_base = (unsigned)(size_t)smem;
-  auto dma16 = [&](const T* src, unsigned lds_off) {
-    unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + lds_off);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-  };
-  auto stage = [&](int buf, int kt) {
-    const unsigned base = (unsigned)(buf * STAGE);
-#pragma unroll
-    for (int i = 0; i < AI; ++i) dma16(a_src[i] + kt * 64, base + (i * NW + wave) * 1024);
-#pragma unroll
-    for (int i = 0; i < WI; ++i) dma16(w_src[i] + kt * 64, base + A_BYTES + (i * NW + wave) * 1024);
-  };
-  // fragment reads: lane (r = l & 31, h = l >> 5) takes row r of a 32-row tile, k = 16 ks + 8 h .. +7
-  const int l31 = lane & 31, hh = lane >> 5, fsw = (l31 >> 1) & 7;
-  const int a_off = (wr * WM + l31) * 128, w_off = A_BYTES + (wc * WN + l31) * 128;
-  int slot[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) slot[ks] = ((2 * ks + hh) ^ fsw) * 16;
-  V8 af[2][MT], wf[2][NT];
-  auto read_frags = [&](int buf, int ks, int set) {
-    const char* sb = smem + buf * STAGE;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) wf[set][j] = *(const V8*)(sb + w_off + j * 32 * 128 + slot[ks]);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) af[set][i] = *(const V8*)(sb + a_off + i * 32 * 128 + slot[ks]);
-  };
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = 0.f;
-  auto mfmas = [&](int set) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma32(wf[set][j], af[set][i], acc[i][j]);
-  };
-
-  const int nk = p.K >> 6;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (nk > 1) stage(1, 1);
-  read_frags(0, 0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-      read_frags(buf, ks + 1, (ks + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(ks & 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (kt + 1 < nk) {
-      // every wave has its last fragments of this tile; tile kt+1 has landed; its first fragments and the
-      // DMA of tile kt+2 (into this tile's buffer) are requested before the last k-step's MFMAs
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kt + 2 < nk) stage(buf, kt + 2);
-      read_frags(buf ^ 1, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    mfmas(1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  gemm_epilogue32<HT, BM, BN, ROWLN, WR, WC>(p, acc, smem, m0, n0, g);
-}
-
-template <class HT, int BM, int BN, int WR, int WC, bool ROWLN>
-static hipError_t launch_gemm32_t(const GemmArgs& p, int groups, hipStream_t s) {
-  constexpr int lds = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm32_kernel<HT, BM, BN, WR, WC, ROWLN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
-  hipLaunchKernelGGL((gemm32_kernel<HT, BM, BN, WR, WC, ROWLN>), grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN>), grid, dim3(512), lds, s, p);
   return hipGetLastError();
 }
 
@@ -1215,10 +841,13 @@ static int g_ant_override = -1;  // non-temporal A loads: -1 auto (row-complete 
 void gemm_set_a_nt(int v) { g_ant_override = v; }
 static int g_deep = -1;  // row-complete conv tile: 0 = 2-stage kernel, otherwise (default) the 8-phase kernel (A/B knob)
 void gemm_set_deep(int v) { g_deep = v; }
-static int g_x32 = 0;  // 8-phase kernels: 0 = v_mfma 16x16x32 (default: its 512-cycle segments balance the schedule), 1 = 32x32x16 (A/B knob)
-void gemm_set_x32(int v) { g_x32 = v; }  // 2 = the one-wave-per-SIMD 32x32x16 kernel (gemm32_kernel)
+#ifdef AFX_ATTR
 static int g_nodma = 0;  // timing-only epilogue knob bits (GemmArgs::dbg_nodma; WRONG results when set)
-void gemm_set_nodma(int v) { g_nodma = v; }
+bool gemm_set_nodma(int v) { g_nodma = v; return true; }
+#else
+static constexpr int g_nodma = 0;
+bool gemm_set_nodma(int v) { return v == 0; }  // the product build has no such switch
+#endif
 
 // Host-side shape contract; anything else is a programming error in the caller.
 static const char* check_gemm(const GemmArgs& p, int groups) {
@@ -1228,6 +857,12 @@ static const char* check_gemm(const GemmArgs& p, int groups) {
   if (p.kchunk <= 0 || p.kchunk % 64) return "gemm: kchunk must be a positive multiple of 64";
   if (p.rpb <= 0) return "gemm: rows-per-batch must be positive";
   if (!p.out_f && !p.out_h) return "gemm: no output";
+  if (p.split_k > 1) {
+    if (groups != 1 || p.kchunk != p.K || (p.K / 64) % p.split_k || p.ln_gamma) return "gemm: split-K needs a plain product with K / 64 divisible by the split";
+    if (p.bias || p.resid || p.out_h || p.act != ACT_NONE || p.alpha != 1.f || !p.out_f || (p.N & 7))
+      return "gemm: split-K stores raw fp32 partial planes only (bias / activation / residual belong to the consumer)";
+    if (p.part_stride < (long)p.M * p.ldo_f) return "gemm: split-K planes overlap";
+  }
   if (p.ln_gamma) {
     if (p.N != 512 || groups != 1) return "gemm: the fused LayerNorm epilogue needs N == 512 (row-complete tile)";
     if (!p.ln_beta || !p.bias || p.resid || p.alpha != 1.f) return "gemm: fused LayerNorm epilogue: bias + LN + act only";
@@ -1264,7 +899,20 @@ static int gemm_split_rows(const GemmArgs& p, int groups) {
   return (int)(nM1 * 256);
 }
 
+// Split-K factor for a plain product whose 256x256 tiles leave most of the 256 CUs idle (the teacher's N = 1024
+// products at M = 16 x 199: 52 tiles): the largest S <= 8 with tiles x S <= 256, S | K / 64 and at least 4 K-tiles per
+// work item (shorter K-loops are all prologue).  0 = leave the product whole.
+int gemm_pick_split_k(int M, int N, int K) {
+  const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+  if ((N & 7) || K % 64 || tiles < 16 || tiles > 128) return 0;
+  const int nk = K / 64;
+  for (int S = 8; S >= 2; --S)
+    if (tiles * S <= 256 && nk % S == 0 && nk / S >= 4) return S;
+  return 0;
+}
+
 int gemm_tile_of(const GemmArgs& p, int groups) {
+  if (p.split_k > 1) return 7;
   if (p.ln_gamma) return g_deep != 0 && p.kchunk == p.K ? 8 : 3;
   if (gemm_is_narrow(p.N)) return 1;
   if (groups != 1) return 0;
@@ -1287,22 +935,14 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
 template <class HT>
 static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t s) {
   // lean epilogue (no activation or erf-GELU, N % 8 == 0: every GEMM of the two models' fast paths) where it applies
-  const bool lean = (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0 && !(p.dbg_nodma & 16);
+  const bool lean = (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0 && !(AFX_DBG(p, 16));
   switch (tile) {
     case 1: return lean ? launch_gemm_t<HT, 128, 64, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 64, 2, 2>(p, groups, s);
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
     case 4: return launch_gemm_t<HT, 256, 128, 4, 2>(p, groups, s);
-    case 7: {
-      const int x = (p.act == ACT_NONE || p.act == ACT_GELU) ? g_x32 : 0;  // the 32x32 epilogue carries these two only
-      if (x == 2) return launch_gemm32_t<HT, 256, 256, 2, 2, false>(p, groups, s);
-      return x ? launch_gemm8_t<HT, 256, 256, false, true>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false, false>(p, groups, s);
-    }
-    case 8: {
-      const int x = (p.act == ACT_NONE || p.act == ACT_GELU) ? g_x32 : 0;
-      if (x == 2) return launch_gemm32_t<HT, 128, 512, 1, 4, true>(p, groups, s);
-      return x ? launch_gemm8_t<HT, 128, 512, true, true>(p, groups, s) : launch_gemm8_t<HT, 128, 512, true, false>(p, groups, s);
-    }
+    case 7: return launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
+    case 8: return launch_gemm8_t<HT, 128, 512, true>(p, groups, s);
     default: return lean ? launch_gemm_t<HT, 128, 128, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
   }
 }
@@ -1317,7 +957,7 @@ const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t
     tile = tile == 7 ? 0 : 3;  // the 8-phase kernels carry the lean epilogue: everything else stays on the 2-stage tiles
   p.a_nt = g_ant_override >= 0 ? g_ant_override : (tile == 3 ? 1 : 0);
   p.dbg_nodma = g_nodma;
-  const int m1 = tile == 7 && g_tile_override < 0 ? gemm_split_rows(p, groups) : 0;
+  const int m1 = tile == 7 && g_tile_override < 0 && p.split_k <= 1 ? gemm_split_rows(p, groups) : 0;
   if (m1 > 0) {  // rows [0, m1) on the 8-phase kernel, rows [m1, M) on the 128x128 kernel
     const size_t hs = 2;
     GemmArgs a = p, b = p;

@@ -46,7 +46,14 @@ struct GemmArgs {
   const float* ln_beta;
   float ln_eps;
   int a_nt;  // 1: non-temporal LDS-DMA for the A panel (set by launch_gemm)
-  int dbg_nodma;  // timing experiments only (wrong results): epilogue bits 8 no activation, 16 narrow stores, 32 no stores, 64 no epilogue
+  // Split-K (small-M products whose 256x256 tiles do not fill the chip: M = 16 x 199 rows, N = 1024 is 52 tiles on
+  // 256 CUs): split_k = S > 1 cuts K into S equal slices; work item (slice, tile) accumulates its slice and stores the
+  // raw fp32 partial tile into plane `slice` of out_f (planes part_stride floats apart, row stride ldo_f).  No bias,
+  // activation, residual or operand-type output here: the consumer (launch_rownorm with RowNormArgs::part) adds the
+  // planes in slice order, so the result does not depend on which workgroup finished when.  K / 64 % S == 0.
+  int split_k;
+  long part_stride;
+  int dbg_nodma;  // attribution build (-DAFX_ATTR) only, ignored otherwise: epilogue bits 8 no activation, 16 narrow stores, 32 no stores, 64 no epilogue
 };
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
 const char* launch_gemm_f32(const GemmArgs& p, int groups, hipStream_t s);  // afx_gemm_f32.hip (DT_FP32 operands)
@@ -59,9 +66,8 @@ void gemm_set_split(int v);     // A/B knob: 1 (default) = whole rounds on the 8
 void mhsa_set_force_long(int v);   // test knob: the blocked any-length trunk attention kernel at every length
 void conf_attn_mfma_set_force_long(int v);  // test knob: the blocked matrix-core Shaw attention at every length
 void conf_attn_set_block(int v);   // test knob: keys per LDS block of the fp32 attention (0 = automatic)
-void gemm_set_x32(int v);       // A/B knob: 0 (default) = 16x16x32, 1 = 8-phase kernels on v_mfma 32x32x16, 2 = gemm32_kernel
 void gemm_set_deep(int v);      // A/B knob, conv tile: 0 = 2-stage kernel, -1/2 = 8-phase kernel (default)
-void gemm_set_nodma(int v);     // timing-only knob: epilogue parts off (bits above; wrong results)
+bool gemm_set_nodma(int v);     // timing-only knob (attribution build, -DAFX_ATTR, only): epilogue parts off; false = not in this build
 
 // ---- frontend / row kernels (afx_frontend.hip) ---------------------------------
 // conv layer 0 (Cin=1,k=10,s=5) + LayerNorm(512) + erf-GELU; optional pre-emphasis.
@@ -89,7 +95,18 @@ struct RowNormArgs {
   void* out_h;
   long ldo_h;
   int rpb, o_batch_rows, o_row_off;
+  // Split-K consumer: x_row += add_bias + part[0][row] + ... + part[nsplit-1][row] (planes part_stride floats apart,
+  // row stride ldp, same row index as x), the sum is written back to x_out (may alias x: a wave owns its rows) and
+  // then normalised.  nsplit = 0: plain LayerNorm of x.
+  const float* part;
+  int nsplit;
+  long part_stride, ldp;
+  const float* add_bias;
+  float* x_out;
+  long ldx_out;
 };
+// S for a plain M x N x K product on the 8-phase 256x256 kernel: 0 = do not split
+int gemm_pick_split_k(int M, int N, int K);
 const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s);
 // zero the time padding rows of the positional-conv operand buffer (B, T+128, C)
 const char* launch_zero_pad_rows(void* buf_h, int B, int T, int C, int pad_front, int pad_back, int dtype,

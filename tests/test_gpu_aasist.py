@@ -90,35 +90,32 @@ def test_backend_vs_reference_forward(tag, T):
 
 
 def test_teacher_model_end_to_end():
-    """XLSR_AASIST end to end (2-layer trunk to keep the CPU oracle quick), B=8.
+    """XLSR_AASIST end to end (2-layer trunk to keep the CPU oracle quick), B=8, the seeded "lively" head.
 
-    Contract, in three parts (DESIGN.md "Numerics"):
-      1. the fp32 back-end is exact: fed the ORACLE's SSL features it reproduces the
-         oracle logits to 1e-5 (so every top-k decision agrees);
+    Contract (DESIGN.md "Numerics"):
+      1. the fp32 back-end is exact: fed the ORACLE's SSL features it reproduces the oracle logits to 1e-5;
       2. the fp16 trunk is within 2e-3 relative L2 of the fp32 trunk;
-      3. end to end the scores are within 1e-3 wherever no GraphPool decision flips.  The
-         reference's top-k is discontinuous and, with a random-init head, node scores sit
-         ~1e-5 apart, so the 8e-4 trunk rounding flips a decision on some utterances and
-         moves a logit by ~1e-2 there: bounded at 3e-2, and the median must hold 1e-3.
-    """
+      3. end to end EVERY utterance on which the reference model is well-conditioned (conftest.teacher_conditioning:
+         same GraphPool node sequences with and without the trunk's rounding, every deciding gap >= 3e-5) is within
+         the 1e-3 score tolerance.  Where a near-tie of the reference's own top-k flips, no tolerance applies -- the
+         oracle on the perturbed features moves by the same amount; those utterances are counted, not bounded."""
     from afx import engine, synth
+    from conftest import teacher_conditioning
     from oracle import models
-    sd = synth.model_state_dict("XLSR_AASIST", n_layers=2)
+    sd = synth.model_state_dict("XLSR_AASIST", n_layers=2, head_scale=1.5)
     wave = synth.waveforms(8, 64000, batch_idx=2)
-    taps = {}
-    ref = models.xlsr_aasist_forward(sd, wave, taps=taps)
     eng = engine.Engine("xlsr_aasist", n_layers=2, dtype="fp16")
     eng.load_state_dict(sd)
-    eng.enable_taps()
+    ref, got, rows = teacher_conditioning(sd, wave, eng)
+    taps = {}
+    assert torch.equal(models.xlsr_aasist_forward(sd, wave, taps=taps), ref)
     exact = eng.head(taps["ssl"].cuda()).cpu()
     assert (exact - ref).abs().max().item() <= 1e-5
-    got = eng.forward(wave.cuda()).cpu()
-    ssl = eng.tap("ssl").cpu().reshape(taps["ssl"].shape)
-    assert ((ssl - taps["ssl"]).norm() / taps["ssl"].norm()).item() < 2e-3
-    err = (got - ref).abs().max(dim=1)[0]
-    print("teacher per-utterance |dlogit|:", [f"{e:.1e}" for e in err.tolist()])
-    assert err.median().item() <= 1e-3
-    assert err.max().item() <= 3e-2
+    assert max(r["feat_rel_l2"] for r in rows) < 2e-3
+    print("teacher (2-layer trunk) per utterance:", [(r["ok"], f"{r['dlogit']:.1e}", f"{r['margin']:.1e}") for r in rows])
+    ok = [r for r in rows if r["ok"]]
+    assert len(ok) >= 4, "too few well-conditioned utterances to say anything"
+    assert all(r["dlogit"] <= 1e-3 for r in ok), [r for r in ok if r["dlogit"] > 1e-3]
 
 
 def test_dropin_models_package_teacher_and_student():

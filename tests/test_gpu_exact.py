@@ -130,7 +130,7 @@ def test_fp32_conformer_student_logits():
 
 def test_fp32_teacher_every_utterance_within_tolerance():
     """XLSR_AASIST end to end with no reduced precision: every utterance (not just the
-    median, cf. test_teacher_model_end_to_end) holds the score tolerance, and the graph
+    well-conditioned ones, cf. test_teacher_model_end_to_end) holds the score tolerance, and the graph
     pooling picks the oracle's nodes."""
     from afx import engine, synth
     from oracle import models
@@ -148,10 +148,9 @@ def test_fp32_teacher_every_utterance_within_tolerance():
     assert err.max().item() <= 1e-5
 
 
-def test_fp32_teacher_full_depth_and_fp16_deviation():
-    """BASELINE config 3 at its real depth (24 transformer layers, 4 s clips): exact mode
-    against the CPU oracle, and the default fp16 engine against exact mode on a larger batch
-    (GPU vs GPU, so the sample is not limited by the CPU oracle's speed)."""
+def test_fp32_teacher_full_depth():
+    """BASELINE config 3 at its real depth (24 transformer layers, 4 s clips) in exact mode against the CPU oracle.
+    (The fp16 engine at this depth is gated per utterance in tests/test_gpu_teacher.py.)"""
     from afx import engine, synth
     from oracle import models
     sd = synth.model_state_dict("XLSR_AASIST", n_layers=24)
@@ -162,11 +161,3 @@ def test_fp32_teacher_full_depth_and_fp16_deviation():
     err = (ex.forward(wave.cuda()).cpu() - ref).abs().max().item()
     print(f"teacher 24 layers, exact mode vs oracle: max|dlogit| {err:.2e}")
     assert err <= 1e-4
-    big = synth.waveforms(16, 64000, batch_idx=8).cuda()
-    want = ex.forward(big).cpu()
-    del ex
-    h = engine.Engine("xlsr_aasist", n_layers=24, dtype="fp16")
-    h.load_state_dict(sd)
-    d = (h.forward(big).cpu() - want).abs().max(dim=1)[0]
-    print("teacher 24 layers, fp16 vs exact mode per-utterance |dlogit|:", [f"{e:.1e}" for e in d.tolist()])
-    assert d.median().item() <= 1e-3 and d.max().item() <= 5e-2
