@@ -168,6 +168,15 @@ int afx_k_hgat(const float* x1, int n1, const float* x2, int n2, int B, int din,
 int afx_k_graph_pool(const float* h, int B, int N, int D, int keep, const float* w, const float* b, float* out,
                      void* stream);
 
+/* Residual_block alone (models/aasist_modules.py:340-397: conv1 (2,3) pad (1,1) ON x (Q2) -> bn2 -> SELU -> conv2 (2,3)
+ * pad (0,1), + conv_downsample (1,3) of x when the channel count changes).  x, y: device NCHW fp32 (B,cin,H,W) /
+ * (B,cout,H,W); conv weights in their checkpoint layout [cout][cin][kh][kw]; bn2 folded; down_w/down_b NULL exactly when
+ * cin == cout.  cin 1 or a multiple of 16, cout 32 / 64 / 128.  scratch: afx_k_resblock_scratch_floats() floats. */
+size_t afx_k_resblock_scratch_floats(int B, int cin, int cout, int H, int W);
+int afx_k_resblock(const float* x, int B, int cin, int cout, int H, int W, const float* conv1_w, const float* conv1_b,
+                   const float* bn2_scale, const float* bn2_shift, const float* conv2_w, const float* conv2_b,
+                   const float* down_w, const float* down_b, float* scratch, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

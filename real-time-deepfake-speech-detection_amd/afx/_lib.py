@@ -67,6 +67,8 @@ SIGNATURES = {
     "afx_aasist_error": (C.c_char_p, []),
     "afx_k_gat": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
     "afx_k_hgat": (_I, [_P, _I, _P, _I, _I, _I, _I, C.POINTER(_P), _F, _P, _L, _P, _P, _P, _P, _P]),
+    "afx_k_resblock_scratch_floats": (_Z, [_I, _I, _I, _I, _I]),
+    "afx_k_resblock": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "afx_k_graph_pool": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
 }
 
@@ -103,6 +105,7 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on ``device`` (default: the current device)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

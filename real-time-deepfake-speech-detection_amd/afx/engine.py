@@ -22,19 +22,36 @@ def torch_dtype(name):
     return {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[name]
 
 
+def _cuda_device(device):
+    """'cuda' / 'cuda:1' / torch.device / an int rank (main.py:48) / None -> a torch.device with an index."""
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    d = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+    if d.type != "cuda":
+        raise AfxError(f"the MI355X-native path runs on a GPU, not on {d}")
+    return d if d.index is not None else torch.device("cuda", torch.cuda.current_device())
+
+
 class Engine:
+    """One native engine = one GPU.  The handle's packed weights, the workspace and every launch live on
+    ``self.device`` (fixed at construction: the given device, else the current one) whatever torch's current
+    device is when a method is called -- the reference passes ``device=rank`` and never calls
+    ``torch.cuda.set_device`` (main.py:48,78-82).  Inputs on another GPU are refused, not dereferenced."""
+
     def __init__(self, arch, n_layers=24, dtype=None, conf_emb=144, conf_heads=4, conf_kernel=31,
-                 conf_blocks=4, pre_emphasis=False, pre_emphasis_coef=0.97):
+                 conf_blocks=4, pre_emphasis=False, pre_emphasis_coef=0.97, device=None):
         dtype = dtype or DEFAULT_DTYPE
         if dtype not in DTYPES:
             raise ValueError(f"dtype must be one of {sorted(DTYPES)}, got {dtype!r}")
         if not torch.cuda.is_available():
             raise AfxError("no HIP device: the MI355X-native path has no CPU fallback")
         self.arch, self.dtype, self.n_layers = arch, dtype, n_layers
+        self.device = _cuda_device(device)
         cfg = Config(ARCHS[arch], DTYPES[dtype], n_layers, conf_emb, conf_heads, conf_kernel, conf_blocks,
                      1 if pre_emphasis else 0, pre_emphasis_coef)
         self._h = C.c_void_p()
-        check(lib().afx_create(C.byref(cfg), C.byref(self._h)))
+        with torch.cuda.device(self.device):  # afx_create allocates on the current device
+            check(lib().afx_create(C.byref(cfg), C.byref(self._h)))
         self._ws = None
         self._taps = False
 
@@ -47,45 +64,54 @@ class Engine:
                 pass
             self._h = None
 
+    def _stream(self):
+        return stream_ptr(self.device)
+
     # ---- weights -------------------------------------------------------------------
     def load_state_dict(self, sd):
         """sd: name -> tensor (reference checkpoint names).  Tensors are moved to
         the device as contiguous fp32 and copied / repacked by the library."""
-        l, s = lib(), stream_ptr()
-        dev = torch.device("cuda", torch.cuda.current_device())
-        for name, t in sd.items():
-            if not torch.is_tensor(t) or not t.dtype.is_floating_point:
-                continue
-            t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
-            shape = (C.c_int64 * max(t.ndim, 1))(*t.shape)
-            check(l.afx_load_weight(self._h, name.encode(), ptr(t), shape, t.ndim, s))
-        torch.cuda.current_stream().synchronize()  # sources may be freed by the caller
-        check(l.afx_finalize(self._h, s))
+        l, dev = lib(), self.device
+        with torch.cuda.device(dev):
+            s = self._stream()
+            for name, t in sd.items():
+                if not torch.is_tensor(t) or not t.dtype.is_floating_point:
+                    continue
+                t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+                shape = (C.c_int64 * max(t.ndim, 1))(*t.shape)
+                check(l.afx_load_weight(self._h, name.encode(), ptr(t), shape, t.ndim, s))
+            torch.cuda.current_stream(dev).synchronize()  # sources may be freed by the caller
+            check(l.afx_finalize(self._h, s))
 
     # ---- forward -------------------------------------------------------------------
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    @staticmethod
-    def _wave(x):
+    def _on_device(self, x, what):
+        if not x.is_cuda:
+            raise AfxError(f"{what} must live on the GPU (the caller does batch_x.to(device), main.py:209)")
+        if x.device != self.device:
+            raise AfxError(f"{what} is on {x.device} but this engine (weights, workspace, launches) lives on {self.device}")
+
+    def _wave(self, x):
         if x.ndim == 3:  # (B,L,1): models/fe.py:18 uses channel 0
             x = x[:, :, 0]
         if x.ndim != 2:
             raise ValueError(f"expected a (B,L) or (B,L,1) waveform batch, got shape {tuple(x.shape)}")
-        if not x.is_cuda:
-            raise AfxError("input must live on the GPU (the caller does batch_x.to(device), main.py:209)")
+        self._on_device(x, "input")
         return x.to(torch.float32).contiguous()
 
     def forward(self, wave):
         x = self._wave(wave)
         B, L = x.shape
         l = lib()
-        ws = self._workspace(l.afx_workspace_bytes(self._h, B, L))
-        out = torch.empty(B, 2, dtype=torch.float32, device=x.device)
-        check(l.afx_forward(self._h, ptr(x), B, L, ptr(out), ptr(ws), ws.numel(), stream_ptr()))
+        with torch.cuda.device(self.device):
+            ws = self._workspace(l.afx_workspace_bytes(self._h, B, L))
+            out = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+            check(l.afx_forward(self._h, ptr(x), B, L, ptr(out), ptr(ws), ws.numel(), self._stream()))
         return out
 
     def ssl(self, wave):
@@ -93,20 +119,23 @@ class Engine:
         B, L = x.shape
         l = lib()
         T = l.afx_num_frames(L)
-        ws = self._workspace(l.afx_workspace_bytes(self._h, B, L))
-        buf = torch.empty(B, max(T, 1), 1024, dtype=torch.float32, device=x.device)
-        check(l.afx_ssl_forward(self._h, ptr(x), B, L, ptr(buf), ptr(ws), ws.numel(), stream_ptr()))
+        with torch.cuda.device(self.device):
+            ws = self._workspace(l.afx_workspace_bytes(self._h, B, L))
+            buf = torch.empty(B, max(T, 1), 1024, dtype=torch.float32, device=self.device)
+            check(l.afx_ssl_forward(self._h, ptr(x), B, L, ptr(buf), ptr(ws), ws.numel(), self._stream()))
         return buf[:, :max(T, 0)]
 
     def head(self, feats):
+        self._on_device(feats, "SSL features")
         f = feats.to(torch.float32).contiguous()
         B, T, D = f.shape
         if D != 1024:
             raise ValueError("SSL features must have 1024 channels")
         l = lib()
-        ws = self._workspace(l.afx_head_workspace_bytes(self._h, B, T))
-        out = torch.empty(B, 2, dtype=torch.float32, device=f.device)
-        check(l.afx_head_forward(self._h, ptr(f), B, T, ptr(out), ptr(ws), ws.numel(), stream_ptr()))
+        with torch.cuda.device(self.device):
+            ws = self._workspace(l.afx_head_workspace_bytes(self._h, B, T))
+            out = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+            check(l.afx_head_forward(self._h, ptr(f), B, T, ptr(out), ptr(ws), ws.numel(), self._stream()))
         return out
 
     # ---- hipGraph replay: the ~130 launches of a forward as ONE graph launch ----------
@@ -116,16 +145,17 @@ class Engine:
         Returns ``run(wave) -> logits``: copies the batch into the graph's static input and
         replays.  Worth it for small, latency-bound batches (B = 1 streaming-style calls),
         where host launch overhead is comparable to the GPU time."""
-        static_in = torch.zeros(B, L, dtype=torch.float32, device="cuda")
-        self._workspace(lib().afx_workspace_bytes(self._h, B, L))
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):  # warm-up outside the capture (one-off attribute calls, allocations)
-            self.forward(static_in)
-        torch.cuda.current_stream().wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_out = self.forward(static_in)
+        with torch.cuda.device(self.device):
+            static_in = torch.zeros(B, L, dtype=torch.float32, device=self.device)
+            self._workspace(lib().afx_workspace_bytes(self._h, B, L))
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):  # warm-up outside the capture (one-off attribute calls, allocations)
+                self.forward(static_in)
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self.forward(static_in)
 
         def run(wave):
             static_in.copy_(self._wave(wave), non_blocking=True)
@@ -152,7 +182,8 @@ class Engine:
 
     def tap(self, name):
         n = C.c_size_t(0)
-        check(lib().afx_tap(self._h, name.encode(), None, 0, C.byref(n), stream_ptr()))
-        out = torch.empty(n.value, dtype=torch.float32, device="cuda")
-        check(lib().afx_tap(self._h, name.encode(), ptr(out), n.value, C.byref(n), stream_ptr()))
+        with torch.cuda.device(self.device):
+            check(lib().afx_tap(self._h, name.encode(), None, 0, C.byref(n), self._stream()))
+            out = torch.empty(n.value, dtype=torch.float32, device=self.device)
+            check(lib().afx_tap(self._h, name.encode(), ptr(out), n.value, C.byref(n), self._stream()))
         return out

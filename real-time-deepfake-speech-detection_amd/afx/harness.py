@@ -179,6 +179,9 @@ def evaluate(model, loader, device, loss_fn=None, preprocessor=None):
 
 
 class _Shard(torch.utils.data.Dataset):
+    """This rank's utterances; every item keeps its dataset index AND its utterance id, so that nobody ever has to
+    call ``dataset[i]`` again (the reference datasets decode the audio file in ``__getitem__``)."""
+
     def __init__(self, base, idx):
         self.base, self.idx = base, [int(i) for i in idx if i >= 0]
 
@@ -187,27 +190,37 @@ class _Shard(torch.utils.data.Dataset):
 
     def __getitem__(self, i):
         utt, x, label = self.base[self.idx[i]]
-        return self.idx[i], x, label
+        return self.idx[i], utt, x, label
 
 
 def produce_evaluation_file_distributed(dataset, model, device, save_path, batch_size, num_workers=4, group=None):
     """Multi-GPU scoring: rank r scores utterances r, r+W, ...; ONE all-gather of
     (index, score) pairs (RCCL when the group's backend is nccl); rank 0 writes the file
-    in dataset order.  Returns (indices, scores) on every rank."""
+    in dataset order.  Returns (indices, scores) on every rank.
+
+    The utterance ids are collected in the scoring loop (each clip is decoded exactly once, by the loader's workers)
+    and gathered as Python objects after the scores -- rank 0 never re-reads the dataset for a name."""
     import torch.distributed as tdist
     rank, world = tdist.get_rank(group), tdist.get_world_size(group)
     idx = adist.shard_indices(len(dataset), rank, world)
     model.eval()
     scores = torch.zeros(idx.numel(), dtype=torch.float32, device=device)
+    names = {}
     pos = 0
     with torch.no_grad():
-        for _i, batch_x, _label in _loader(_Shard(dataset, idx.tolist()), batch_size, num_workers):
-            out = model(batch_x.to(device, non_blocking=True))
+        loader = (((i, utt), x) for i, utt, x, _label in _loader(_Shard(dataset, idx.tolist()), batch_size, num_workers))
+        for (i, utt), x in prefetch_to_device(loader, device):
+            out = model(x)
             scores[pos:pos + out.shape[0]] = out[:, 1]
             pos += out.shape[0]
+            names.update(zip((int(v) for v in (i.tolist() if torch.is_tensor(i) else i)), utt))
     gi, gs = adist.all_gather_scores(idx.to(device=device, dtype=torch.int32), scores, world, group)
     mi, ms = adist.merge_scores(gi, gs)
+    all_names = [None] * world
+    tdist.all_gather_object(all_names, names, group=group)
     if rank == 0:
-        names = [dataset[int(i)][0] for i in mi.tolist()] if hasattr(dataset, "__getitem__") else mi.tolist()
-        write_score_file(save_path, names, ms.cpu().numpy().ravel().tolist())
+        lut = {}
+        for d in all_names:
+            lut.update(d)
+        write_score_file(save_path, [lut[int(i)] for i in mi.tolist()], ms.cpu().numpy().ravel().tolist())
     return mi, ms

@@ -79,26 +79,42 @@ class Wav2Vec2Trunk(nn.Module):
 
 
 class _StubPickle:
-    """``pickle_module`` for torch.load that tolerates classes of packages that are not installed
-    (fairseq / omegaconf / argparse-style config objects inside ``xlsr2_300m.pt``): an unknown
-    global becomes an inert stand-in, tensors and plain containers load as usual.  Nothing from the
-    stand-ins is executed -- only the ``model`` state_dict is read afterwards."""
+    """``pickle_module`` for torch.load of a fairseq checkpoint (``xlsr2_300m.pt`` carries argparse / omegaconf /
+    fairseq config objects beside the tensors).  ALLOW-LIST: only what rebuilding tensors and plain containers needs is
+    resolved to the real object (torch's own rebuild helpers and storage / dtype types, ``collections.OrderedDict``,
+    ``argparse.Namespace``, numpy's array / scalar reconstructors); EVERY other global -- installed or not, ``os.system``
+    and ``builtins.eval`` included -- becomes an inert stand-in class whose construction and ``__setstate__`` only store
+    what they are given.  So a crafted file cannot run code through this loader; only the ``model`` state_dict is read
+    afterwards."""
     import pickle as _pickle
 
     __name__ = "afx_stub_pickle"
+    _ALLOWED_MODULES = ("torch._utils", "torch.storage", "torch._tensor", "torch.serialization")
+    _ALLOWED = {("collections", "OrderedDict"), ("argparse", "Namespace"), ("torch", "Size"), ("torch", "device"),
+                ("torch", "dtype"), ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy", "ndarray"),
+                ("numpy", "dtype"), ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "slice"),
+                ("builtins", "complex"), ("builtins", "bytearray")}
 
     class Unpickler(_pickle.Unpickler):
         def find_class(self, module, name):
-            try:
-                return super().find_class(module, name)
-            except (ImportError, AttributeError):
-                def __init__(self, *a, **k):
+            ok = (module, name) in _StubPickle._ALLOWED or \
+                (module in _StubPickle._ALLOWED_MODULES and name != "_load_from_bytes") or \
+                (module == "torch" and (name.endswith("Storage") or name.endswith("Tensor") or name in torch.__dict__
+                                        and isinstance(torch.__dict__[name], torch.dtype)))
+            if ok:
+                try:
+                    return super().find_class(module, name)
+                except (ImportError, AttributeError):
                     pass
 
-                def __setstate__(self, state):
-                    self.__dict__.update(state if isinstance(state, dict) else {"state": state})
-                return type(name, (), {"__module__": module, "__init__": __init__, "__setstate__": __setstate__,
-                                       "__reduce__": None})
+            def __init__(self, *a, **k):
+                pass
+
+            def __setstate__(self, state):
+                self.__dict__.update(state if isinstance(state, dict) else {"state": state})
+            return type(name, (), {"__module__": module, "__init__": __init__, "__setstate__": __setstate__,
+                                   "__call__": lambda self, *a, **k: None})
 
     @staticmethod
     def load(f, **kw):
@@ -162,9 +178,12 @@ class AfxModule(nn.Module):
         eng = self.__dict__.get("_afx_eng")
         n_layers = len(self._afx_trunk().encoder.layers)
         dtype = self.__dict__.get("afx_dtype", None) or DEFAULT_DTYPE
-        key = (n_layers, dtype, tuple(sorted(self._afx_cfg().items())))
+        dev = next(self.parameters()).device  # the engine lives where the module's parameters live (device=rank, main.py:48)
+        if dev.type != "cuda":
+            raise RuntimeError("the model is on the CPU: move it to a GPU first (the native path has no CPU fallback)")
+        key = (n_layers, dtype, str(dev), tuple(sorted(self._afx_cfg().items())))
         if eng is None or self.__dict__.get("_afx_key") != key:
-            eng = Engine(self.afx_arch, n_layers=n_layers, dtype=dtype, **self._afx_cfg())
+            eng = Engine(self.afx_arch, n_layers=n_layers, dtype=dtype, device=dev, **self._afx_cfg())
             self.__dict__["_afx_eng"], self.__dict__["_afx_key"], self.__dict__["_afx_sig"] = eng, key, None
         sig = self._afx_signature()
         if self.__dict__.get("_afx_sig") != sig:

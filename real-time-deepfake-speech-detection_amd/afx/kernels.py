@@ -153,6 +153,18 @@ def gat(x, p, temp):
     return y
 
 
+def resblock(x, conv1_w, conv1_b, bn2_scale, bn2_shift, conv2_w, conv2_b, down_w=None, down_b=None):
+    """Residual_block (models/aasist_modules.py:340-397) on an NCHW fp32 image; conv weights in checkpoint layout."""
+    B, cin, H, W = x.shape
+    cout = conv1_w.shape[0]
+    scratch = torch.empty(lib().afx_k_resblock_scratch_floats(B, cin, cout, H, W), dtype=torch.float32, device=x.device)
+    y = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
+    _check_aasist(lib().afx_k_resblock(ptr(x), B, cin, cout, H, W, ptr(conv1_w), ptr(conv1_b), ptr(bn2_scale),
+                                       ptr(bn2_shift), ptr(conv2_w), ptr(conv2_b), ptr(down_w), ptr(down_b),
+                                       ptr(scratch), ptr(y), stream_ptr()))
+    return y
+
+
 HGAT_ORDER = ["t1w", "t1b", "t2w", "t2b", "att_w", "att_b", "attM_w", "attM_b", "v11", "v22", "v12", "vM",
               "w1", "b1", "w2", "b2", "w1M", "b1M", "w2M", "b2M", "bn_scale", "bn_shift"]
 

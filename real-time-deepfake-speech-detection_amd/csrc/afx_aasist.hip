@@ -150,21 +150,21 @@ __global__ void pool_bn_selu_kernel(const float* __restrict__ ll, int T, int wd,
 __global__ void first_block_kernel(const float* __restrict__ x, int M, int img, int wp, int wd, const float* __restrict__ w1,
                                    const float* __restrict__ b1, const float* __restrict__ sc, const float* __restrict__ sh,
                                    const float* __restrict__ wd_, const float* __restrict__ bd, float* __restrict__ Y,
-                                   float* __restrict__ D, int cout) {
+                                   float* __restrict__ D, int cout, int hin) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)M * cout) return;
   const long m = idx / cout;
   const int n = (int)(idx % cout);
   const int pix = (int)(m % img), h = pix / wp, w = pix % wp;
   float y = 0.f, d = 0.f;
-  if (w < wd && h < 43) {
+  if (w < wd && h < hin + 1) {
     float a = b1[n];
 #pragma unroll
     for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
       for (int dw = 0; dw < 3; ++dw) a = fmaf(x[m + dh * wp + dw], w1[n * 6 + dh * 3 + dw], a);
     y = selu(fmaf(a, sc[n], sh[n]));
-    if (h < 42) {
+    if (h < hin) {
       float e = bd[n];
 #pragma unroll
       for (int dw = 0; dw < 3; ++dw) e = fmaf(x[m + wp + dw], wd_[n * 3 + dw], e);
@@ -362,13 +362,10 @@ static const char* launch_gat(const GatArgs& a, int B, int din, int dout, hipStr
   if (a.N < 1 || lds > 160 * 1024) return "aasist: graph has too many nodes for the LDS slab (clip longer than ~37 s)";
   dim3 grid(a.N + (a.master ? 1 : 0), B);
   hipError_t e = hipSuccess;
-  static int lds_set[3] = {0, 0, 0};
+  static LdsLimit lim[3];
 #define AFX_GAT(IDX, DI, DO)                                                                                          \
   do {                                                                                                                \
-    if (lds > 48 * 1024 && lds > lds_set[IDX]) {                                                                      \
-      e = hipFuncSetAttribute((const void*)gat_kernel<DI, DO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      \
-      if (e == hipSuccess) lds_set[IDX] = lds;                                                                        \
-    }                                                                                                                 \
+    if (lds > 48 * 1024) e = lim[IDX].ensure((const void*)gat_kernel<DI, DO>, lds);                                   \
     if (e == hipSuccess) hipLaunchKernelGGL((gat_kernel<DI, DO>), grid, dim3(256), lds, s, a);                        \
   } while (0)
   if (din == 64 && dout == 64)
@@ -624,7 +621,7 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
     const AasistWeights::Block& K = w.blk[0];
     const long n = (long)M * K.cout;
     hipLaunchKernelGGL(first_block_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x1, M, img, wp, wd, K.w1,
-                       K.b1, K.bn2_scale, K.bn2_shift, K.wd, K.bd, Y, D, K.cout);
+                       K.b1, K.bn2_scale, K.bn2_shift, K.wd, K.bd, Y, D, K.cout, AAS_F);
     F32GemmArgs g;
     memset(&g, 0, sizeof g);
     g.A = Y + (long)wp * K.cout; g.lda = K.cout; g.nch = 2; g.kc = 3 * K.cout; g.chunk_stride = (long)wp * K.cout;
@@ -819,6 +816,95 @@ extern "C" int afx_k_hgat(const float* x1, int n1, const float* x2, int n2, int 
   a.bn_scale = wts[20]; a.bn_shift = wts[21]; a.temp = temp; a.y1 = y1; a.y2 = y2;
   a.master = master; a.master_bstride = master_bstride; a.master_out = mout;
   aasist_last = launch_gat(a, B, din, dout, s);
+  return aasist_last ? 1 : 0;
+}
+
+// ---- Residual_block alone (models/aasist_modules.py:340-397) on an NCHW image of any size: the same kernels as
+// the fused front (zero-padded channel-last image, convs as chunked-K products on the fp32 matrix cores) between
+// two layout passes.  conv1 sees x itself (Q2: the bn1 + SELU result is discarded by the reference).
+namespace afx {
+__global__ void nchw_to_img_kernel(const float* __restrict__ x, int C, int H, int W, int hp, int wp, float* __restrict__ img,
+                                   long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W), h = (int)(i / W % H), c = (int)(i / ((long)W * H) % C);
+    const long b = i / ((long)W * H * C);
+    img[((b * hp + h + 1) * wp + w + 1) * C + c] = x[i];
+  }
+}
+__global__ void img_to_nchw_kernel(const float* __restrict__ img, int C, int H, int W, int hp, int wp, float* __restrict__ y,
+                                   long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W), h = (int)(i / W % H), c = (int)(i / ((long)W * H) % C);
+    const long b = i / ((long)W * H * C);
+    y[i] = img[((b * hp + h + 1) * wp + w + 1) * C + c];
+  }
+}
+}  // namespace afx
+
+extern "C" size_t afx_k_resblock_scratch_floats(int B, int cin, int cout, int H, int W) {
+  const size_t pix = (size_t)B * (H + 4) * (W + 2) + 3 * (size_t)(W + 2) + 16;
+  return pix * ((size_t)cin + 3 * (size_t)cout) + (size_t)cout * cin * 6 + (size_t)cout * cout * 6 + (size_t)cout * cin * 3 + 256;
+}
+
+extern "C" int afx_k_resblock(const float* x, int B, int cin, int cout, int H, int W, const float* conv1_w,
+                              const float* conv1_b, const float* bn2_scale, const float* bn2_shift, const float* conv2_w,
+                              const float* conv2_b, const float* down_w, const float* down_b, float* scratch, float* y,
+                              void* stream) {
+  using namespace afx;
+  hipStream_t s = (hipStream_t)stream;
+  auto bad = [&](const char* m) { aasist_last = m; return 1; };
+  if (!x || !conv1_w || !conv1_b || !bn2_scale || !bn2_shift || !conv2_w || !conv2_b || !scratch || !y) return bad("resblock: null argument");
+  if (B < 1 || H < 1 || W < 1) return bad("resblock: empty image");
+  if (cout != 32 && cout != 64 && cout != 128) return bad("resblock: output channels must be 32, 64 or 128");
+  if (cin != 1 && cin % 16) return bad("resblock: input channels must be 1 or a multiple of 16");
+  if ((cin != cout) != (down_w != nullptr)) return bad("resblock: conv_downsample exactly when the channel count changes");
+  const int hp = H + 4, wp = W + 2, img = hp * wp;
+  const long M = (long)B * img;
+  const size_t pix = (size_t)M + 3 * (size_t)wp + 16;
+  float* X = scratch;
+  float* Y = X + pix * cin;
+  float* D = Y + pix * cout;
+  float* O = D + pix * cout;
+  float* w1p = O + pix * cout;
+  float* w2p = w1p + (size_t)cout * cin * 6;
+  float* wdp = w2p + (size_t)cout * cout * 6;
+  if (hipMemsetAsync(scratch, 0, pix * ((size_t)cin + 3 * (size_t)cout) * 4, s) != hipSuccess) return bad("resblock: memset failed");
+  hipLaunchKernelGGL(pack_conv2d_kernel, dim3(64), dim3(256), 0, s, conv1_w, cout, cin, 2, 3, w1p);
+  hipLaunchKernelGGL(pack_conv2d_kernel, dim3(64), dim3(256), 0, s, conv2_w, cout, cout, 2, 3, w2p);
+  if (down_w) hipLaunchKernelGGL(pack_conv2d_kernel, dim3(64), dim3(256), 0, s, down_w, cout, cin, 1, 3, wdp);
+  const long nin = (long)B * cin * H * W, nout = (long)B * cout * H * W;
+  hipLaunchKernelGGL(nchw_to_img_kernel, dim3((unsigned)((nin + 255) / 256 < 4096 ? (nin + 255) / 256 : 4096)), dim3(256), 0, s, x,
+                     cin, H, W, hp, wp, X, nin);
+  F32GemmArgs g;
+  const float* resid = X;
+  if (cin == 1) {  // conv1 + bn2 + SELU -> Y and the (1,3) downsample -> D in one VALU kernel (K = 6 / 3: no matrix shape)
+    const long n = M * cout;
+    hipLaunchKernelGGL(first_block_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, (int)M, img, wp, W, w1p, conv1_b,
+                       bn2_scale, bn2_shift, wdp, down_b, Y, D, cout, H);
+    resid = D;
+  } else {
+    memset(&g, 0, sizeof g);  // conv1 (pad (1,1)) on x -> bn2 -> SELU -> Y, H + 1 rows
+    g.A = X; g.lda = cin; g.nch = 2; g.kc = 3 * cin; g.chunk_stride = (long)wp * cin;
+    g.W = w1p; g.M = (int)M; g.N = cout; g.bias = conv1_b; g.bn_scale = bn2_scale; g.bn_shift = bn2_shift; g.post = 1;
+    g.img = img; g.wp = wp; g.hout = H + 1; g.wd = W; g.out = Y; g.ldo = cout; g.o_off = wp + 1;
+    if ((aasist_last = launch_f32_gemm(g, s))) return 1;
+    if (down_w) {
+      memset(&g, 0, sizeof g);
+      g.A = X + (long)wp * cin; g.lda = cin; g.nch = 1; g.kc = 3 * cin; g.W = wdp; g.M = (int)M; g.N = cout;
+      g.bias = down_b; g.img = img; g.wp = wp; g.hout = H; g.wd = W; g.out = D; g.ldo = cout; g.o_off = wp + 1;
+      if ((aasist_last = launch_f32_gemm(g, s))) return 1;
+      resid = D;
+    }
+  }
+  memset(&g, 0, sizeof g);  // conv2 (pad (0,1)) on Y + identity
+  g.A = Y + (long)wp * cout; g.lda = cout; g.nch = 2; g.kc = 3 * cout; g.chunk_stride = (long)wp * cout;
+  g.W = w2p; g.M = (int)M; g.N = cout; g.bias = conv2_b; g.resid = resid;
+  g.img = img; g.wp = wp; g.hout = H; g.wd = W; g.out = O; g.ldo = cout; g.o_off = wp + 1;
+  if ((aasist_last = launch_f32_gemm(g, s))) return 1;
+  hipLaunchKernelGGL(img_to_nchw_kernel, dim3((unsigned)((nout + 255) / 256 < 4096 ? (nout + 255) / 256 : 4096)), dim3(256), 0, s, O,
+                     cout, H, W, hp, wp, y, nout);
+  hipError_t e = hipGetLastError();
+  aasist_last = e == hipSuccess ? nullptr : hipGetErrorString(e);
   return aasist_last ? 1 : 0;
 }
 

@@ -4,7 +4,28 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 namespace afx {
+
+// Raising a kernel's dynamic-LDS limit (hipFuncSetAttribute) acts on the CURRENT device's copy of the kernel and is
+// sticky there, so the "already raised to N bytes" memo is kept per device (one process may drive several GPUs: the
+// reference passes `device=rank`, main.py:48) and under a lock (engines may be driven from several host threads).
+// ensure() raises the limit only when a larger request arrives (graph-capture friendly: no call in steady state).
+constexpr int kMaxDevices = 16;
+struct LdsLimit {
+  int have[kMaxDevices] = {0};
+  std::mutex mu;
+  hipError_t ensure(const void* fn, int bytes) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> g(mu);
+    if (bytes <= have[d]) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) have[d] = bytes;
+    return e;
+  }
+};
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;

@@ -159,13 +159,8 @@ static hipError_t launch_conf_attn_t(const float* q, long ldq, const float* kv, 
   if (g_conf_attn_block && g_conf_attn_block < N) KB = g_conf_attn_block;
   else if (N > 256 || lds_of(N) > 160 * 1024) KB = 64;
   const int lds = lds_of(KB);
-  static int lds_set = 0;  // the attribute is sticky: raise it only when a larger request arrives (graph-capture friendly)
-  if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conf_attn_kernel<DH, HT, REL>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    lds_set = lds;
-  }
+  static LdsLimit lim;  // sticky per device: raised only when a larger request arrives (graph-capture friendly)
+  if (hipError_t e = lim.ensure((const void*)conf_attn_kernel<DH, HT, REL>, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((conf_attn_kernel<DH, HT, REL>), dim3(H, B, (N + 255) / 256), dim3(256), lds, s, q, ldq, kv, ldkv, rel,
                      max_pos, N, H, KB, (typename HT::T*)out, ldo);
   return hipGetLastError();
@@ -595,17 +590,15 @@ const char* launch_conf_attn_mfma(const float* q, long ldq, const float* kv, lon
   if (N + 15 > CA_KEYS || g_conf_attn_force_long) {  // beyond 209 tokens: keys in blocks of 128
     const int ldsl = CAL_KB * 128 + 16 * DT * CAL_VT_STRIDE * 2 + 4 * 16 * CAL_RS * 4;
     hipError_t el = hipSuccess;
-    static int setl[2] = {0, 0};
+    static LdsLimit liml[2];
     dim3 grid(H, B, (N + 63) / 64);
     if (dtype == DT_BF16) {
-      if (!setl[0]) el = hipFuncSetAttribute((const void*)conf_attn_mfma_long_kernel<BF16, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsl);
-      setl[0] = 1;
+      el = liml[0].ensure((const void*)conf_attn_mfma_long_kernel<BF16, 36>, ldsl);
       if (el == hipSuccess)
         hipLaunchKernelGGL((conf_attn_mfma_long_kernel<BF16, 36>), grid, dim3(256), ldsl, s, q, ldq, kv, ldkv, (const __bf16*)rel_h,
                            max_pos, N, H, (__bf16*)out_h, ldo);
     } else {
-      if (!setl[1]) el = hipFuncSetAttribute((const void*)conf_attn_mfma_long_kernel<FP16, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsl);
-      setl[1] = 1;
+      el = liml[1].ensure((const void*)conf_attn_mfma_long_kernel<FP16, 36>, ldsl);
       if (el == hipSuccess)
         hipLaunchKernelGGL((conf_attn_mfma_long_kernel<FP16, 36>), grid, dim3(256), ldsl, s, q, ldq, kv, ldkv, (const _Float16*)rel_h,
                            max_pos, N, H, (_Float16*)out_h, ldo);
@@ -615,16 +608,14 @@ const char* launch_conf_attn_mfma(const float* q, long ldq, const float* kv, lon
   }
   const int lds = CA_KEYS * 128 + 16 * DT * CA_VT_STRIDE * 2 + 4 * 16 * CA_RS * 4;
   hipError_t e = hipSuccess;
-  static int set[2] = {0, 0};
+  static LdsLimit lim[2];
   if (dtype == DT_BF16) {
-    if (!set[0]) e = hipFuncSetAttribute((const void*)conf_attn_mfma_kernel<BF16, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    set[0] = 1;
+    e = lim[0].ensure((const void*)conf_attn_mfma_kernel<BF16, 36>, lds);
     if (e == hipSuccess)
       hipLaunchKernelGGL((conf_attn_mfma_kernel<BF16, 36>), dim3(H, B), dim3(256), lds, s, q, ldq, kv, ldkv, (const __bf16*)rel_h,
                          max_pos, N, H, (__bf16*)out_h, ldo);
   } else {
-    if (!set[1]) e = hipFuncSetAttribute((const void*)conf_attn_mfma_kernel<FP16, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    set[1] = 1;
+    e = lim[1].ensure((const void*)conf_attn_mfma_kernel<FP16, 36>, lds);
     if (e == hipSuccess)
       hipLaunchKernelGGL((conf_attn_mfma_kernel<FP16, 36>), dim3(H, B), dim3(256), lds, s, q, ldq, kv, ldkv, (const _Float16*)rel_h,
                          max_pos, N, H, (_Float16*)out_h, ldo);
@@ -710,13 +701,10 @@ const char* launch_conf_dwconv(const float* x, long ldx, const float* w, const f
   const int lds = (NC + 31 - 1 + 8) * 32 * (int)sizeof(float);
   dim3 grid((C + 31) / 32, B, (N + NC - 1) / NC);
   hipError_t e = hipSuccess;
-  static int lds_set[3] = {0, 0, 0};
+  static LdsLimit lim[3];
   if (dtype < 0 || dtype > 2) return "conf_dwconv: unknown dtype";
   AFX_DISPATCH_HT(dtype, {
-    if (lds > lds_set[dtype]) {
-      e = hipFuncSetAttribute((const void*)conf_dwconv_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e == hipSuccess) lds_set[dtype] = lds;
-    }
+    e = lim[dtype].ensure((const void*)conf_dwconv_kernel<HT>, lds);
     if (e == hipSuccess)
       hipLaunchKernelGGL(conf_dwconv_kernel<HT>, grid, dim3(256), lds, s, x, ldx, w, bias, bn_scale, bn_shift, N, NC, C, k,
                          (HT::T*)out_h, ldo);

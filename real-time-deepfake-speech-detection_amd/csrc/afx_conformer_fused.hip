@@ -391,12 +391,8 @@ __global__ __launch_bounds__(64 * NWAVE) void conf_chain_kernel(ConfChainArgs p)
 template <class HT, int STAGE>
 static hipError_t launch_conf_chain_t(const ConfChainArgs& p, hipStream_t s) {
   constexpr int lds = PARAMS + kChainParamFloats * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conf_chain_kernel<HT, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static LdsLimit lim;
+  if (hipError_t e = lim.ensure((const void*)conf_chain_kernel<HT, STAGE>, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((conf_chain_kernel<HT, STAGE>), dim3((unsigned)((p.M + 16 * NWAVE - 1) / (16 * NWAVE))), dim3(64 * NWAVE), lds, s, p);
   return hipGetLastError();
 }

@@ -96,8 +96,11 @@ struct ConfBlock {
   float* chain_prm[3];  // per fused chain: the per-column vectors packed into one 8-KB block (ConfChainArgs::params)
 };
 
+struct Profiler;  // per-engine launch timing (below)
+
 struct afx_engine {
   afx_config cfg;
+  Profiler* prof = nullptr;  // owned; no process-wide map: two engines on two host threads share nothing
   int dt;
   size_t hsz;  // bytes per operand element
   std::vector<void*> allocs;
@@ -255,6 +258,11 @@ static int store_raw(afx_engine* e, const std::string& key, const float* src, co
   FT& t = e->f[key];
   const size_t n = numel(shape, ndim);
   if (!t.p || t.n != n) {
+    if (t.p) {  // reloaded with another size: release the old buffer now, not at destroy
+      for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it)
+        if (*it == t.p) { e->allocs.erase(it); break; }
+      (void)hipFree(t.p);
+    }
     t.p = (float*)e->dalloc(n * 4);
     if (!t.p) return fail("afx_load_weight: device allocation failed for %s", key.c_str());
     t.n = n;
@@ -641,17 +649,16 @@ struct Profiler {
     return pool[used++];
   }
 };
-static std::unordered_map<afx_engine*, Profiler> g_prof;
-static thread_local Profiler* t_prof = nullptr;
+static thread_local Profiler* t_prof = nullptr;  // the profiler of the engine whose forward runs on this thread
 static int g_posconv_sliding = 1;  // positional conv: sliding-window kernel (0: chunked-K GEMM)
 static int g_conf_attn_mfma = 1;   // Conformer attention on the matrix cores (0: the fp32 VALU kernel)
 static int g_fuse_conformer = 1;  // Conformer block: row-local chains fused (afx_conformer_fused.hip); 0 = per-op path
 static int g_fuse_conv_ln = 1;  // conv layers 1-6: LayerNorm+GELU in the GEMM epilogue (A/B knob)
 static void prof_forget(afx_engine* e) {
-  auto it = g_prof.find(e);
-  if (it == g_prof.end()) return;
-  for (hipEvent_t ev : it->second.pool) (void)hipEventDestroy(ev);
-  g_prof.erase(it);
+  if (!e->prof) return;
+  for (hipEvent_t ev : e->prof->pool) (void)hipEventDestroy(ev);
+  delete e->prof;
+  e->prof = nullptr;
 }
 
 template <class F>
@@ -677,7 +684,8 @@ static const char* P_rownorm(const RowNormArgs& a, int dt, hipStream_t s) {
 
 extern "C" int afx_profile_begin(afx_handle h) {
   if (!h) return fail("afx_profile_begin: null handle");
-  Profiler& p = g_prof[h];
+  if (!h->prof) h->prof = new Profiler();
+  Profiler& p = *h->prof;
   p.on = true;
   p.recs.clear();
   p.used = 0;
@@ -685,7 +693,8 @@ extern "C" int afx_profile_begin(afx_handle h) {
 }
 extern "C" int afx_profile_end(afx_handle h, int n, double* ms, double* flops, long long* launches) {
   if (!h || n < PC_COUNT || !ms || !flops || !launches) return fail("afx_profile_end: need %d slots", (int)PC_COUNT);
-  Profiler& p = g_prof[h];
+  if (!h->prof) return fail("afx_profile_end: afx_profile_begin was not called on this handle");
+  Profiler& p = *h->prof;
   for (int i = 0; i < n; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
   for (const ProfRec& r : p.recs) {
     HIP_OK(hipEventSynchronize(r.b));
@@ -1047,7 +1056,7 @@ extern "C" int afx_forward(afx_handle h, const float* wave, int B, int L, float*
   const size_t needb = carve(h, B, L, 0, ws, &w);
   if (ws_bytes < needb) return fail("afx_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   hipStream_t s = (hipStream_t)stream;
-  t_prof = g_prof.count(h) ? &g_prof[h] : nullptr;
+  t_prof = h->prof;
   if (run_trunk(h, wave, B, L, w, s)) return 1;
   return run_head(h, B, w.T[6], w, logits, s);
 }
@@ -1059,7 +1068,7 @@ extern "C" int afx_ssl_forward(afx_handle h, const float* wave, int B, int L, fl
   const size_t needb = carve(h, B, L, 0, ws, &w);
   if (ws_bytes < needb) return fail("afx_ssl_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   hipStream_t s = (hipStream_t)stream;
-  t_prof = g_prof.count(h) ? &g_prof[h] : nullptr;
+  t_prof = h->prof;
   if (run_trunk(h, wave, B, L, w, s)) return 1;
   HIP_OK(hipMemcpyAsync(feats, w.ssl_f, (size_t)B * w.T[6] * kD * 4, hipMemcpyDeviceToDevice, s));
   return 0;
@@ -1095,7 +1104,7 @@ extern "C" int afx_head_forward(afx_handle h, const float* feats, int B, int T, 
                        h->dt == AFX_DT_BF16 ? 1 : 0);
     HIP_OK(hipGetLastError());
   }
-  t_prof = g_prof.count(h) ? &g_prof[h] : nullptr;
+  t_prof = h->prof;
   return run_head(h, B, T, w, logits, s);
 }
 

@@ -796,21 +796,18 @@ template <class HT, int BM, int BN, bool ROWLN>
 static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static_assert(lds <= 160 * 1024, "two K-tile buffers must fit the 160 KB LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm8_kernel<HT, BM, BN, ROWLN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
+  static LdsLimit lim;
+  if (hipError_t e = lim.ensure((const void*)gemm8_kernel<HT, BM, BN, ROWLN>, lds); e != hipSuccess) return e;
+  static int n_cu_of[kMaxDevices] = {0};  // (benign if two threads fill the same slot: same value)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+  if (!n_cu_of[dev]) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorUnknown;
+    cus &= ~7;  // a multiple of the 8 XCDs (the tile remap relies on it)
+    n_cu_of[dev] = cus < 8 ? 8 : cus;
   }
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-    n_cu = prop.multiProcessorCount & ~7;  // a multiple of the 8 XCDs (the tile remap relies on it)
-    if (n_cu < 8) n_cu = 8;
-  }
+  const int n_cu = n_cu_of[dev];
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * (p.split_k > 1 ? p.split_k : 1);
   dim3 grid(tiles < n_cu ? tiles : n_cu, 1, groups);  // persistent: at most one workgroup per CU
   hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN>), grid, dim3(512), lds, s, p);
@@ -820,13 +817,8 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
 template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false, bool LEAN = false>
 static hipError_t launch_gemm_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<HT, BM, BN, WR, WC, ROWLN, LEAN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static LdsLimit lim;
+  if (hipError_t e = lim.ensure((const void*)gemm_kernel<HT, BM, BN, WR, WC, ROWLN, LEAN>, lds); e != hipSuccess) return e;
   dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
   hipLaunchKernelGGL((gemm_kernel<HT, BM, BN, WR, WC, ROWLN, LEAN>), grid, dim3(64 * WR * WC), lds, s, p);
   return hipGetLastError();
@@ -917,6 +909,9 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
   if (gemm_is_narrow(p.N)) return 1;
   if (groups != 1) return 0;
   if (g_tile_override == 2) return 4;  // 256x128 / 8 waves (A/B only: slower everywhere measured)
+  if (g_tile_override == 4) return 5;  // 128x128 / 8 waves, 2-stage (A/B)
+  if (g_tile_override == 5) return 1;  // 128x64 / 4 waves (A/B: forced)
+  if (g_tile_override == 6) return 6;  // 128x256 / 8 waves, 2-stage (A/B)
   if (g_tile_override == 3) return p.kchunk == p.K ? 7 : 0;  // 8-phase 256x256
   if (g_tile_override >= 0) return g_tile_override == 1 ? 2 : 0;
   // Wave-quantisation model fitted to tools/bench_gemm.py (profiles/r01_gemm_tile_ab*.txt):
@@ -941,6 +936,8 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
     case 4: return launch_gemm_t<HT, 256, 128, 4, 2>(p, groups, s);
+    case 5: return lean ? launch_gemm_t<HT, 128, 128, 2, 4, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 128, 2, 4>(p, groups, s);
+    case 6: return lean ? launch_gemm_t<HT, 128, 256, 2, 4, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 256, 2, 4>(p, groups, s);
     case 7: return launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
     case 8: return launch_gemm8_t<HT, 128, 512, true>(p, groups, s);
     default: return lean ? launch_gemm_t<HT, 128, 128, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);

@@ -154,21 +154,15 @@ const char* launch_posconv(const PosConvArgs& p_in, int dtype, hipStream_t s) {
   p.slab_rows = (p.T + PC_TAPS - 1 + 7) & ~7;
   const int lds = 2 * p.slab_rows * 128 + PC_RING * 8192;
   if (lds > 160 * 1024) return "posconv: slab does not fit the LDS";
-  static int lds_set[2] = {0, 0};
+  static LdsLimit lim[2];
   hipError_t e = hipSuccess;
   const int npair = (p.B + 1) / 2;
   dim3 grid(16 * npair);
   if (dtype == DT_BF16) {
-    if (lds > lds_set[0]) {
-      e = hipFuncSetAttribute((const void*)posconv_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e == hipSuccess) lds_set[0] = lds;
-    }
+    e = lim[0].ensure((const void*)posconv_kernel<BF16>, lds);
     if (e == hipSuccess) hipLaunchKernelGGL(posconv_kernel<BF16>, grid, dim3(64 * PC_NW), lds, s, p);
   } else {
-    if (lds > lds_set[1]) {
-      e = hipFuncSetAttribute((const void*)posconv_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e == hipSuccess) lds_set[1] = lds;
-    }
+    e = lim[1].ensure((const void*)posconv_kernel<FP16>, lds);
     if (e == hipSuccess) hipLaunchKernelGGL(posconv_kernel<FP16>, grid, dim3(64 * PC_NW), lds, s, p);
   }
   if (e == hipSuccess) e = hipGetLastError();

@@ -107,9 +107,10 @@ class GraphPool(nn.Module):
 
 
 class Residual_block(nn.Module):
-    """Parameter container of models/aasist_modules.py:340-397 (bn1 is present in
-    checkpoints but never reaches the output -- Q2).  The block only runs fused inside
-    XLSR_AASIST's native back-end; there is no standalone native entry point."""
+    """models/aasist_modules.py:340-397.  bn1 is present in checkpoints but never reaches the
+    output (Q2: the reference overwrites the bn1 + SELU result with conv1(x)).  Inside
+    XLSR_AASIST the six blocks run fused in the native back-end; stand-alone, ``forward``
+    runs the same kernels on one NCHW image (afx_k_resblock)."""
 
     def __init__(self, nb_filts, first=False):
         super().__init__()
@@ -129,4 +130,10 @@ class Residual_block(nn.Module):
             self.downsample = False
 
     def forward(self, x):
-        raise NotImplementedError("Residual_block runs only as part of XLSR_AASIST's fused native back-end")
+        _eval_only(self, x)
+        d = lambda t: t.detach().float().contiguous()
+        sc, sh = _bn(self.bn2)
+        dw = d(self.conv_downsample.weight) if self.downsample else None
+        db = d(self.conv_downsample.bias) if self.downsample else None
+        return _K.resblock(x.float().contiguous(), d(self.conv1.weight), d(self.conv1.bias), sc, sh,
+                           d(self.conv2.weight), d(self.conv2.bias), dw, db)

@@ -215,3 +215,68 @@ def test_fairseq_style_checkpoint_loads_without_fairseq(tmp_path):
     torch.save({"model": {k: v for k, v in sd.items() if "fc2" not in k}}, path)
     with pytest.raises(KeyError, match="lacks"):
         host.load_ssl_checkpoint(trunk, str(path))
+
+
+DIST_SCORE_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from afx import harness
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+calls = []
+
+class Toy(torch.utils.data.Dataset):
+    def __len__(self):
+        return 9
+    def __getitem__(self, i):
+        calls.append(i)  # the reference datasets decode an audio file here (data/test_set.py)
+        return f"clip_{i:03d}", torch.full((8,), float(i)), 0
+
+class Model(torch.nn.Module):
+    def forward(self, x):
+        return torch.stack([-x[:, 0], x[:, 0] * 0.5], dim=1)
+
+out = sys.argv[2]
+mi, ms = harness.produce_evaluation_file_distributed(Toy(), Model(), "cpu", out, batch_size=2, num_workers=0)
+assert mi.tolist() == list(range(9)) and ms.tolist() == [i * 0.5 for i in range(9)]
+assert sorted(calls) == list(range(rank, 9, world)), calls  # every clip decoded once, by its own rank only
+dist.barrier()
+if rank == 0:
+    lines = open(out).read().split("\n")
+    assert lines[:9] == [f"clip_{i:03d} {i * 0.5}" for i in range(9)], lines
+    print("DIST_SCORE_OK")
+dist.destroy_process_group()
+"""
+
+
+def test_distributed_scoring_world_size_2_never_rereads_the_dataset(tmp_path):
+    """produce_evaluation_file_distributed on two gloo ranks: utterances sharded r, r+W, ..., the ids travel with the
+    shards (all_gather_object) -- rank 0 writes the file in dataset order without ever calling dataset[i] for a name."""
+    script = tmp_path / "worker.py"
+    script.write_text(DIST_SCORE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29733", str(script), PKG, str(tmp_path / "scores.txt")],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "DIST_SCORE_OK" in r.stdout
+
+
+def test_checkpoint_loader_does_not_execute_pickled_callables(tmp_path):
+    """The fairseq-free checkpoint reader resolves only an allow-list of globals; anything else in the pickle --
+    here os.system via __reduce__ -- becomes an inert stand-in instead of running."""
+    import os as _os
+    from afx import host, synth
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __reduce__(self):
+            return (_os.system, (f"touch {marker}",))
+    sd = synth.ssl_state_dict(1, prefix="")
+    path = tmp_path / "evil.pt"
+    torch.save({"cfg": Evil(), "model": sd}, path)
+    trunk = host.Wav2Vec2Trunk(n_layers=1)
+    host.load_ssl_checkpoint(trunk, str(path))
+    assert not marker.exists()
+    own = trunk.state_dict()
+    assert all(torch.equal(own[k], sd[k]) for k in own)

@@ -70,6 +70,24 @@ def test_graph_pool_vs_reference_module_descending_order(K):
     np.testing.assert_allclose(y.cpu().numpy(), z["pool.y"], **TOL)
 
 
+@pytest.mark.parametrize("tag,filts,first", [("rb_first", [1, 32], True), ("rb_down", [32, 64], False), ("rb_same", [64, 64], False)])
+def test_residual_block_vs_reference_module(tag, filts, first):
+    """Residual_block.forward stand-alone (afx_k_resblock) against the reference's own module outputs
+    (models/aasist_modules.py:340-397, incl. Q2: conv1 sees x, bn1 is dead)."""
+    from models.aasist_modules import Residual_block
+    z = load_golden("aasist_modules.npz")
+    rb = Residual_block(nb_filts=filts, first=first).eval()
+    missing, unexpected = rb.load_state_dict(sub_sd(z, tag + "."), strict=True)
+    assert not missing and not unexpected
+    rb = rb.cuda()
+    with torch.no_grad():
+        y = rb(_c(z[tag + ".x"]))
+    assert y.shape == z[tag + ".y"].shape
+    np.testing.assert_allclose(y.cpu().numpy(), z[tag + ".y"], **TOL)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        rb.train()(_c(z[tag + ".x"]))
+
+
 @pytest.mark.parametrize("tag,T", [("t199", 199), ("t49", 49), ("t201", 201)])
 def test_backend_vs_reference_forward(tag, T):
     """feats -> logits through afx_head_forward against XLSR_AASIST.forward itself."""
@@ -90,32 +108,30 @@ def test_backend_vs_reference_forward(tag, T):
 
 
 def test_teacher_model_end_to_end():
-    """XLSR_AASIST end to end (2-layer trunk to keep the CPU oracle quick), B=8, the seeded "lively" head.
+    """XLSR_AASIST end to end (2-layer trunk to keep the CPU oracle quick), 16 clips of 4 s, the seeded "lively" head
+    (matrices x 1.5: node scores spread instead of sitting within 1e-6 of each other).
 
-    Contract (DESIGN.md "Numerics"):
-      1. the fp32 back-end is exact: fed the ORACLE's SSL features it reproduces the oracle logits to 1e-5;
+    Contract (DESIGN.md "Numerics"), every part for EVERY utterance:
+      1. the fp32 back-end is exact: on the engine's own SSL features it equals the oracle back-end to 1e-5;
       2. the fp16 trunk is within 2e-3 relative L2 of the fp32 trunk;
-      3. end to end EVERY utterance on which the reference model is well-conditioned (conftest.teacher_conditioning:
-         same GraphPool node sequences with and without the trunk's rounding, every deciding gap >= 3e-5) is within
-         the 1e-3 score tolerance.  Where a near-tie of the reference's own top-k flips, no tolerance applies -- the
-         oracle on the perturbed features moves by the same amount; those utterances are counted, not bounded."""
+      3. wherever the reference model keeps its GraphPool decisions under that trunk rounding
+         (conftest.teacher_conditioning: same node sequences), the logits are within the 1e-3 score tolerance.
+    Where a near-tie of the reference's own top-k flips, (1) still holds -- the deviation IS the oracle's response to
+    the perturbed features -- and no tolerance is claimed; the count is printed."""
     from afx import engine, synth
     from conftest import teacher_conditioning
-    from oracle import models
     sd = synth.model_state_dict("XLSR_AASIST", n_layers=2, head_scale=1.5)
-    wave = synth.waveforms(8, 64000, batch_idx=2)
+    wave = torch.cat([synth.waveforms(8, 64000, batch_idx=2), synth.waveforms(8, 64000, batch_idx=3)])
     eng = engine.Engine("xlsr_aasist", n_layers=2, dtype="fp16")
     eng.load_state_dict(sd)
-    ref, got, rows = teacher_conditioning(sd, wave, eng)
-    taps = {}
-    assert torch.equal(models.xlsr_aasist_forward(sd, wave, taps=taps), ref)
-    exact = eng.head(taps["ssl"].cuda()).cpu()
-    assert (exact - ref).abs().max().item() <= 1e-5
+    _ref, _got, rows = teacher_conditioning(sd, wave, eng)
+    print("teacher (2-layer trunk) per utterance (same top-k, |dlogit|, back-end alone):",
+          [(r["same_topk"], f"{r['dlogit']:.1e}", f"{r['backend']:.1e}") for r in rows])
+    assert max(r["backend"] for r in rows) <= 1e-5
     assert max(r["feat_rel_l2"] for r in rows) < 2e-3
-    print("teacher (2-layer trunk) per utterance:", [(r["ok"], f"{r['dlogit']:.1e}", f"{r['margin']:.1e}") for r in rows])
-    ok = [r for r in rows if r["ok"]]
-    assert len(ok) >= 4, "too few well-conditioned utterances to say anything"
-    assert all(r["dlogit"] <= 1e-3 for r in ok), [r for r in ok if r["dlogit"] > 1e-3]
+    kept = [r for r in rows if r["same_topk"]]
+    assert kept, "no utterance kept its top-k decisions: nothing to compare"
+    assert all(r["dlogit"] <= 1e-3 for r in kept), [r for r in kept if r["dlogit"] > 1e-3]
 
 
 def test_dropin_models_package_teacher_and_student():

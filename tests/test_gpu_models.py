@@ -281,3 +281,58 @@ def test_distributed_scoring_over_rccl_with_one_rank(afx_mod, tmp_path):
     assert idx.tolist() == list(range(7))
     assert (tmp_path / "a.txt").read_text() == (tmp_path / "b.txt").read_text()
     assert [f"utt{i}" for i in range(7)] == ref_names and len(ref_scores) == 7
+
+
+@pytest.mark.parametrize("pre_emphasis", [False, True])
+def test_eval_loop_loss_and_accuracy_like_trainer_test(afx_mod, pre_emphasis):
+    """afx.harness.evaluate == Trainer._test (trainer.py:85-132): pre-emphasis when configured (:104, Q7), model,
+    weighted cross-entropy summed as loss x batch size, arg-max accuracy in percent, ragged last batch -- on a toy
+    loader, against the same loop over the CPU oracle (scores within 1e-3 -> loss within 1e-3, accuracy identical
+    because no toy sample sits on the decision boundary)."""
+    engine, synth = afx_mod
+    from afx import harness
+    from oracle import models as omodels, pre
+    sd = synth.model_state_dict("ConformerModel", n_layers=1, n_encoders=1)
+    eng = engine.Engine("conformer", n_layers=1, dtype="fp16", conf_blocks=1)
+    eng.load_state_dict(sd)
+
+    class Wrap(torch.nn.Module):
+        def forward(self, x):
+            return eng.forward(x)
+
+    n = 11
+    waves = torch.cat([synth.waveforms(1, 16000, batch_idx=700 + i) for i in range(n)])
+    ref_in = pre.pre_emphasis(waves) if pre_emphasis else waves
+    ref_logits = omodels.conformer_forward(sd, ref_in)
+    labels = (ref_logits[:, 1] > ref_logits[:, 0]).long()
+    labels[::3] = 1 - labels[::3]  # a third of the labels wrong on purpose: accuracy is neither 0 nor 100
+    assert (ref_logits[:, 1] - ref_logits[:, 0]).abs().min().item() > 5e-3  # nobody on the boundary
+    loader = [([f"u{i}" for i in range(s, min(s + 4, n))], waves[s:s + 4], labels[s:s + 4].float().view(-1, 1))
+              for s in range(0, n, 4)]  # batches of 4, 4, 3; labels arrive as float columns like the reference's
+    loss_fn = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1]).cuda())  # main.py:106,122
+    prep = harness.PreEmphasis(enabled=pre_emphasis)
+    loss, acc = harness.evaluate(Wrap(), loader, "cuda", loss_fn=loss_fn, preprocessor=prep)
+    # trainer.py:85-132 over the oracle's logits
+    ce = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1]))
+    want_loss = sum(ce(ref_logits[s:s + 4], labels[s:s + 4]).item() * len(labels[s:s + 4]) for s in range(0, n, 4)) / n
+    want_acc = (ref_logits.max(dim=1)[1] == labels).sum().item() / n * 100
+    assert abs(loss - want_loss) <= 1e-3 and acc == want_acc and 0 < acc < 100
+
+
+def test_engine_is_bound_to_its_device_not_to_the_current_one(afx_mod):
+    """The reference passes device=rank and never calls torch.cuda.set_device (main.py:48,78-82): an engine must keep
+    weights, workspace and launches on ITS device and refuse tensors of another one instead of dereferencing them."""
+    engine, synth = afx_mod
+    from afx._lib import AfxError
+    eng = engine.Engine("ssl", n_layers=1, dtype="fp16", device="cuda:0")
+    assert eng.device == torch.device("cuda", 0)
+    with pytest.raises(AfxError, match="lives on"):
+        eng._on_device(_FakeOtherDevice(), "input")
+    with pytest.raises(AfxError, match="GPU"):
+        engine.Engine("ssl", n_layers=1, device="cpu")
+
+
+class _FakeOtherDevice:
+    """Stands for a tensor on another GPU (this box has one): only what Engine._on_device looks at."""
+    is_cuda = True
+    device = torch.device("cuda", 1)

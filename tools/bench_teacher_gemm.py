@@ -1,0 +1,66 @@
+"""A/B of GEMM variants on the teacher's (B = 16, M = 3184) products, interleaved rounds in one process:
+tile instances (gemm_tile override) and split-K (planes + the LayerNorm consumer's extra read, timed as a pair)."""
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "real-time-deepfake-speech-detection_amd")]
+from afx import kernels as K  # noqa: E402
+from afx._lib import check, lib  # noqa: E402
+
+M = int(os.environ.get("BENCH_M", 3184))
+SHAPES = [("qkv", 3072, 1024, False), ("out", 1024, 1024, True), ("fc1", 4096, 1024, False), ("fc2", 1024, 4096, True)]
+TILES = [("auto", -1), ("128x128/4w", 0), ("128x64/4w", 5), ("128x128/8w", 4), ("128x256/8w", 6), ("256x128/8w", 2), ("8ph 256x256", 3)]
+
+
+def timeit(fn, reps=20):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def main():
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for name, N, Kk, resid in SHAPES:
+        a = torch.randn(M, Kk, generator=g, device="cuda").half()
+        w = (torch.randn(N, Kk, generator=g, device="cuda") * 0.03).half()
+        bias = torch.randn(N, generator=g, device="cuda")
+        x = torch.randn(M, N, generator=g, device="cuda") if resid else None
+        ga = torch.ones(N, device="cuda")
+        flops = 2.0 * M * N * Kk
+        variants = {}
+        for tn, tv in TILES:
+            def f(tv=tv):
+                check(lib().afx_debug_set(b"gemm_tile", tv))
+                if resid:
+                    K.gemm("fp16", a, w, bias=bias, resid=x, out_f=True, out_h=False)
+                else:
+                    K.gemm("fp16", a, w, bias=bias, act="gelu" if name == "fc1" else None, out_f=False, out_h=True)
+            variants[tn] = f
+        if resid:
+            variants["LN alone"] = lambda: K.rownorm("fp16", x, ga, bias, out_f=False, out_h=True)
+            for S in (2, 4, 8):
+                if (Kk // 64) % S == 0:
+                    part = K.gemm_splitk("fp16", a, w, S)
+                    variants[f"splitK{S}"] = lambda S=S: K.gemm_splitk("fp16", a, w, S)
+                    variants[f"LN+{S}planes"] = lambda part=part: K.rownorm_splitk("fp16", x, part, bias, ga, bias)
+        times = {k: [] for k in variants}
+        for _ in range(5):
+            for k, f in variants.items():
+                times[k].append(timeit(f))
+        check(lib().afx_debug_set(b"gemm_tile", -1))
+        print(f"{name} M={M} N={N} K={Kk}: " + "  ".join(
+            f"{k}: {statistics.median(t):6.1f} us" + (f" ({flops / statistics.median(t) / 1e6:5.0f} TF)" if "LN" not in k else "")
+            for k, t in times.items()), flush=True)
+
+
+if __name__ == "__main__":
+    main()
