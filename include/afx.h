@@ -76,6 +76,14 @@ int afx_forward(afx_handle h, const float* wave, int B, int L, float* logits, vo
 /* SSL features only: feats device (B,T,1024) fp32 == extract_feat() of models/fe.py:17-21 */
 int afx_ssl_forward(afx_handle h, const float* wave, int B, int L, float* feats, void* ws, size_t ws_bytes,
                     void* stream);
+/* The path from the OUTPUT OF CONV LAYER 5 on: conv5_h device (B,T5,512) in the operand type (fp16 / bf16; fp32 in exact
+ * mode) -> conv layer 6, feature LayerNorm, projection, positional conv, transformer layers, head -> logits (B,2).
+ * Same kernels in the same order as afx_forward from that point, so a caller that keeps conv layers 0-5 incrementally
+ * (they are causal-local: a new 250-ms chunk adds 800/400/200/100/50/25 frames, the rest of the 4-s window is unchanged)
+ * reproduces afx_forward(window) bit for bit at a sixteenth of the conv cost (afx/streaming.py, BASELINE config 5). */
+size_t afx_tail_workspace_bytes(afx_handle h, int B, int T5);
+int afx_tail_forward(afx_handle h, const void* conv5_h, int B, int T5, float* logits, void* ws, size_t ws_bytes,
+                     void* stream);
 /* back-end alone from given SSL features (B,T,1024) fp32 -> logits (B,2) */
 int afx_head_forward(afx_handle h, const float* feats, int B, int T, float* logits, void* ws, size_t ws_bytes,
                      void* stream);

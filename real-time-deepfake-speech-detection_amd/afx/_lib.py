@@ -41,6 +41,8 @@ SIGNATURES = {
     "afx_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
     "afx_ssl_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
     "afx_head_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
+    "afx_tail_workspace_bytes": (_Z, [_P, _I, _I]),
+    "afx_tail_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
     "afx_enable_taps": (_I, [_P, _I]),
     "afx_tap": (_I, [_P, C.c_char_p, _P, _Z, C.POINTER(_Z), _P]),
     "afx_profile_begin": (_I, [_P]),

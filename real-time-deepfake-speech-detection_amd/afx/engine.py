@@ -46,6 +46,7 @@ class Engine:
         if not torch.cuda.is_available():
             raise AfxError("no HIP device: the MI355X-native path has no CPU fallback")
         self.arch, self.dtype, self.n_layers = arch, dtype, n_layers
+        self.pre_emphasis = bool(pre_emphasis)
         self.device = _cuda_device(device)
         cfg = Config(ARCHS[arch], DTYPES[dtype], n_layers, conf_emb, conf_heads, conf_kernel, conf_blocks,
                      1 if pre_emphasis else 0, pre_emphasis_coef)
@@ -136,6 +137,20 @@ class Engine:
             ws = self._workspace(l.afx_head_workspace_bytes(self._h, B, T))
             out = torch.empty(B, 2, dtype=torch.float32, device=self.device)
             check(l.afx_head_forward(self._h, ptr(f), B, T, ptr(out), ptr(ws), ws.numel(), self._stream()))
+        return out
+
+    def tail(self, conv5):
+        """conv5: (B,T5,512) output of conv layer 5 in the operand type -> logits (B,2) (afx_tail_forward)."""
+        self._on_device(conv5, "conv-layer-5 activations")
+        if conv5.dtype != torch_dtype(self.dtype) or conv5.ndim != 3 or conv5.shape[2] != 512:
+            raise ValueError(f"expected a (B,T5,512) {self.dtype} tensor, got {tuple(conv5.shape)} {conv5.dtype}")
+        c = conv5.contiguous()
+        B, T5 = c.shape[0], c.shape[1]
+        l = lib()
+        with torch.cuda.device(self.device):
+            ws = self._workspace(l.afx_tail_workspace_bytes(self._h, B, T5))
+            out = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+            check(l.afx_tail_forward(self._h, ptr(c), B, T5, ptr(out), ptr(ws), ws.numel(), self._stream()))
         return out
 
     # ---- hipGraph replay: the ~130 launches of a forward as ONE graph launch ----------

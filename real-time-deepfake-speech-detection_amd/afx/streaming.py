@@ -1,22 +1,40 @@
 """Streaming front of the path (BASELINE config 5) with reference-exact semantics.
 
-The reference has no streaming mode: its models are bidirectional over the whole clip (full
-self-attention, a centred k=128 positional conv), so a cached-state incremental forward would be a
-different model.  What a "250 ms" real-time detector built on it can do without changing a single
-number is re-score, every hop, the window the reference itself would be given: the last `window`
-samples of the stream (while fewer have arrived: that history repeated, the reference's own
-pad-by-tiling policy, data/test_set.py:139-146,201-227).  Each emitted score therefore equals
-``model(window)[:, 1]`` of the reference on that window, and the parity tests say so.
+The reference has no streaming mode: its models are bidirectional over the whole clip (full self-attention, a centred
+k=128 positional conv), so an encoder with cached keys/values would be a different model with nothing to be identical
+to.  What a "250 ms" real-time detector built on it can do without changing a single number is re-score, every hop, the
+window the reference itself would be given: the last `window` samples of the stream (while fewer have arrived: that
+history repeated, the reference's own pad-by-tiling policy, data/test_set.py:139-146,201-227).  Each emitted score
+equals ``model(window)[:, 1]`` of the reference on that window, and the parity tests say so at every hop.
 
-Per stream the state is a ring of `window` fp32 samples in HBM (256 KB at 4 s); a hop costs one
-ring write, one batched ring read (`afx_k_tile_crop`: out[i] = ring[(oldest + i) mod window]) and one
-forward of the whole batch of streams.  Streams are pinned to a GPU; nothing is exchanged between
-GPUs.  Real-time factor = time per hop / hop duration.
+Two scorers with that contract:
+
+``SlidingWindowScorer``  recomputes the whole model on the window every hop (round 1).
+
+``IncrementalScorer``    caches what is exactly reusable.  The conv feature extractor (7 strided Conv1d + per-frame
+    LayerNorm + GELU, 35 % of the student's FLOPs) is causal-local: frame j of conv layer i depends on a fixed span of
+    samples, the layers' cumulative strides 5, 10, ..., 160 all divide the 4000-sample hop and the window start is a
+    multiple of the hop, so the frames of layers 0-5 that a window needs are the SAME absolute frames the previous
+    window needed, shifted by 800 / 400 / 200 / 100 / 50 / 25.  Per hop only those new frames are computed (each layer
+    keeps its k - s unconsumed input frames: 5 samples, then 1, 1, 1, 1, 0 frames), the newest 25 join a ring of the
+    window's 399 layer-5 frames, and `afx_tail_forward` runs the rest -- conv layer 6 (its stride makes 12.5 frames per
+    hop, so it is recomputed over the ring: 1 % of the conv work), projection, positional conv, transformer, head --
+    with the same kernels in the same order as the full forward: the scores are bit-identical to
+    ``SlidingWindowScorer``'s, at a sixteenth of the conv-stack cost.  Everything behind the conv stack is bidirectional
+    over the window in the reference and is recomputed, as it must be.
+
+Per stream the state is a sample ring (256 KB, used while the window fills and by the sliding scorer), the carries
+(< 5 KB) and the layer-5 ring (399 x 512 halfs = 408 KB).  Streams are pinned to a GPU; nothing is exchanged between
+GPUs (tools/stream_bench.py --gpus N runs one process per GPU over its own streams).  Real-time factor = time per hop /
+hop duration.
 """
 import torch
 
 from . import harness
+from . import kernels as K
 from ._lib import check, lib, ptr, stream_ptr
+
+CONV_KS = [(10, 5), (3, 2), (3, 2), (3, 2), (3, 2), (2, 2), (2, 2)]
 
 
 class SlidingWindowScorer:
@@ -32,9 +50,7 @@ class SlidingWindowScorer:
         self._starts = torch.zeros(n_streams, dtype=torch.int64, device=device)
         self._batch = torch.empty(n_streams, window, dtype=torch.float32, device=device)
 
-    def push(self, chunk):
-        """chunk: (S, hop) fp32 on the GPU, the newest `hop` samples of every stream.
-        Returns the (S,) bonafide scores of the current windows."""
+    def _store(self, chunk):
         if chunk.shape != (self.S, self.hop) or not chunk.is_cuda:
             raise ValueError(f"expected a CUDA tensor of shape {(self.S, self.hop)}")
         pos = self.total % self.window
@@ -43,12 +59,85 @@ class SlidingWindowScorer:
         if first < self.hop:
             self.ring[:, : self.hop - first] = chunk[:, first:]
         self.total += self.hop
+
+    def _window_batch(self):
         if self.total < self.window:  # warm-up: the history so far, repeated (reference pad policy)
-            batch = harness.batch_adjust_duration([self.ring[s, : self.total] for s in range(self.S)], self.window)
-        else:  # steady state: one batched ring read, oldest sample first
-            self._starts.fill_(self.total % self.window)
-            check(lib().afx_k_tile_crop(ptr(self.ring), ptr(self._offs), ptr(self._starts), self.S, self.window,
-                                        ptr(self._batch), stream_ptr()))
-            batch = self._batch
+            return harness.batch_adjust_duration([self.ring[s, : self.total] for s in range(self.S)], self.window)
+        self._starts.fill_(self.total % self.window)  # steady state: one batched ring read, oldest sample first
+        check(lib().afx_k_tile_crop(ptr(self.ring), ptr(self._offs), ptr(self._starts), self.S, self.window,
+                                    ptr(self._batch), stream_ptr()))
+        return self._batch
+
+    def push(self, chunk):
+        """chunk: (S, hop) fp32 on the GPU, the newest `hop` samples of every stream.
+        Returns the (S,) bonafide scores of the current windows."""
+        self._store(chunk)
+        batch = self._window_batch()
         out = self.model.forward(batch) if hasattr(self.model, "forward") else self.model(batch)
+        return out[:, 1]
+
+
+class IncrementalScorer(SlidingWindowScorer):
+    """Same scores as SlidingWindowScorer, bit for bit, with conv layers 0-5 computed once per frame (see the module
+    docstring).  ``engine``: an afx Engine (Conformer student or XLSR_AASIST) whose weights came from ``state_dict``
+    (reference key names; the conv feature extractor's tensors are read from it).  Requires hop % 160 == 0 and
+    window % hop == 0, and an engine built without fused pre-emphasis (the reference's scoring loop applies none,
+    main.py:208-214; its reflect pad at the window's first sample would make frame 0 window-dependent)."""
+
+    def __init__(self, engine, state_dict, n_streams, window=64000, hop=4000):
+        super().__init__(engine, n_streams, window, hop, device=engine.device)
+        if hop % 160 or window % hop:
+            raise ValueError("exact reuse needs hop % 160 == 0 (the stride of conv layer 5) and window % hop == 0")
+        if engine.dtype == "fp32":
+            raise ValueError("the incremental scorer runs the half-precision conv kernels (fp16 / bf16 engines)")
+        if getattr(engine, "pre_emphasis", False):
+            raise ValueError("engine-side pre-emphasis makes the window's first frame position-dependent: not reusable")
+        self.eng, self.dt = engine, engine.dtype
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        pre = "ssl_model.model.feature_extractor.conv_layers."
+        dev = engine.device
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        self.w0 = f32(sd[pre + "0.0.weight"])
+        self.cw = [None] + [K.pack_conv(self.dt, f32(sd[f"{pre}{i}.0.weight"])) for i in range(1, 6)]
+        self.cb = [f32(sd[f"{pre}{i}.0.bias"]) for i in range(6)]
+        self.lg = [f32(sd[f"{pre}{i}.2.1.weight"]) for i in range(6)]
+        self.lb = [f32(sd[f"{pre}{i}.2.1.bias"]) for i in range(6)]
+        n = window
+        for k, s in CONV_KS[:6]:
+            n = (n - k) // s + 1
+        self.T5 = n  # layer-5 frames of one window (399 at 4 s)
+        if self.T5 < 2:
+            raise ValueError("window too short")
+        self.carry = [torch.empty(n_streams, 0, dtype=torch.float32, device=dev)] + \
+                     [torch.empty(n_streams, 0, 512, dtype=K.torch_dtype(self.dt), device=dev) for _ in range(5)]
+        self.l5 = torch.empty(n_streams, 0, 512, dtype=K.torch_dtype(self.dt), device=dev)  # newest T5 layer-5 frames
+
+    def _advance(self, chunk):
+        """Feed `hop` new samples through conv layers 0-5; only frames that became computable are produced."""
+        x = torch.cat([self.carry[0], chunk], dim=1)
+        for i, (k, s) in enumerate(CONV_KS[:6]):
+            n_in = x.shape[1]
+            n_out = (n_in - k) // s + 1 if n_in >= k else 0
+            self.carry[i] = x[:, n_out * s:].contiguous()  # the unconsumed tail: k - s frames in steady state
+            if n_out == 0:
+                return None
+            xin = x[:, : (n_out - 1) * s + k].contiguous()
+            if i == 0:
+                y = K.conv0(self.dt, xin, self.w0, self.cb[0], self.lg[0], self.lb[0])
+            else:
+                _, y = K.conv_ln_act(self.dt, xin, self.cw[i], k, s, self.cb[i], self.lg[i], self.lb[i], out_f=False, out_h=True)
+            if i < 5:
+                x = torch.cat([self.carry[i + 1], y], dim=1)
+        return y
+
+    def push(self, chunk):
+        self._store(chunk)
+        new5 = self._advance(chunk)
+        if new5 is not None:
+            self.l5 = torch.cat([self.l5, new5], dim=1)[:, -self.T5:]
+        if self.total < self.window:  # the window is still filling: the reference would be given the tiled history
+            out = self.eng.forward(self._window_batch())
+        else:
+            assert self.l5.shape[1] == self.T5
+            out = self.eng.tail(self.l5)
         return out[:, 1]

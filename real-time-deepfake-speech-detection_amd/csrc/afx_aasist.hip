@@ -43,12 +43,17 @@ struct F32GemmArgs {
   long o_off;          // output row = m + o_off
 };
 
+// One wave = 32 rows x 16 NT columns; blockIdx.y walks column blocks of 16 NT (the launcher picks NT so that the grid
+// gives every SIMD of the chip at least one wave: the LL product, M = 16 x 199 rows, was 25 workgroups before).
+// Operand fragments come straight from L2 (a lane's 16 B of a row per k-step of 16: 6 loads per 32-64 MFMAs) and are
+// requested one k-step AHEAD into a second register set, so the loads' latency sits under the previous step's MFMAs.
 template <int NT>
 __global__ __launch_bounds__(256) void f32_gemm_kernel(F32GemmArgs p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, kq = lane >> 4;
   const long m0 = ((long)blockIdx.x * 4 + wave) * 32;
   if (m0 >= p.M) return;
+  const int n0 = blockIdx.y * NT * 16;
   const long ldw = (long)p.nch * p.kc;
   const float* arow[2];
 #pragma unroll
@@ -57,31 +62,41 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(F32GemmArgs p) {
     m = m < p.M ? m : p.M - 1;
     arow[mt] = p.A + m * p.lda + kq * 4;
   }
-  const float* wrow = p.W + (long)r * ldw + kq * 4;
+  const float* wrow = p.W + (long)(n0 + r) * ldw + kq * 4;
   f32x4 acc[2][NT];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int ch = 0; ch < p.nch; ++ch) {
-    const long ao = (long)ch * p.chunk_stride;
-    const long wo = (long)ch * p.kc;
-    for (int k0 = 0; k0 < p.kc; k0 += 16) {
-      f32x4 a[2], b[NT];
+  const int spc = p.kc >> 4, nsteps = p.nch * spc;  // k-steps of 16 per chunk, in all
+  auto load = [&](int st, f32x4 (&a)[2], f32x4 (&b)[NT]) {
+    const int ch = st / spc, k0 = (st - ch * spc) << 4;
+    const long ao = (long)ch * p.chunk_stride + k0, wo = (long)ch * p.kc + k0;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) a[mt] = *(const f32x4*)(arow[mt] + ao + k0);
+    for (int mt = 0; mt < 2; ++mt) a[mt] = *(const f32x4*)(arow[mt] + ao);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)(wrow + (long)nt * 16 * ldw + wo + k0);
+    for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)(wrow + (long)nt * 16 * ldw + wo);
+  };
+  auto mfmas = [&](const f32x4 (&a)[2], const f32x4 (&b)[NT]) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][s], a[mt][s], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][s], a[mt][s], acc[mt][nt], 0, 0, 0);
+  };
+  f32x4 a0[2], b0[NT], a1[2], b1[NT];
+  load(0, a0, b0);
+  for (int st = 0; st < nsteps; st += 2) {
+    if (st + 1 < nsteps) load(st + 1, a1, b1);
+    mfmas(a0, b0);
+    if (st + 1 < nsteps) {
+      if (st + 2 < nsteps) load(st + 2, a0, b0);
+      mfmas(a1, b1);
     }
   }
-  // operands swapped: lane holds out[m = .. + (lane&15)][n = 16nt + 4*(lane>>4) + 0..3]
+  // operands swapped: lane holds out[m = .. + (lane&15)][n = n0 + 16nt + 4*(lane>>4) + 0..3]
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const long m = m0 + mt * 16 + r;
@@ -94,7 +109,7 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(F32GemmArgs p) {
     const long orow = (m + p.o_off) * p.ldo;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + kq * 4;
+      const int n = n0 + nt * 16 + kq * 4;
       f32x4 v = acc[mt][nt];
       if (p.bias) v += *(const f32x4*)(p.bias + n);
       if (p.resid) v += *(const f32x4*)(p.resid + orow + n);
@@ -115,12 +130,18 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(F32GemmArgs p) {
 
 static const char* launch_f32_gemm(const F32GemmArgs& p, hipStream_t s) {
   if (p.kc % 16 || p.M <= 0) return "aasist gemm: chunk length must be a multiple of 16";
-  dim3 grid((unsigned)((p.M + 127) / 128));
-  switch (p.N) {
-    case 32: hipLaunchKernelGGL(f32_gemm_kernel<2>, grid, dim3(256), 0, s, p); break;
-    case 64: hipLaunchKernelGGL(f32_gemm_kernel<4>, grid, dim3(256), 0, s, p); break;
-    case 128: hipLaunchKernelGGL(f32_gemm_kernel<8>, grid, dim3(256), 0, s, p); break;
-    default: return "aasist gemm: N must be 32, 64 or 128";
+  if (p.N != 32 && p.N != 64 && p.N != 128) return "aasist gemm: N must be 32, 64 or 128";
+  // columns per wave: as wide as possible (A rows are re-read once per column block) while the grid still gives
+  // each of the chip's 1024 SIMDs a wave
+  const long row_waves = (p.M + 31) / 32;
+  int nt = p.N / 16;
+  while (nt > 1 && row_waves * (p.N / (16 * nt)) < 1024) nt >>= 1;
+  dim3 grid((unsigned)((p.M + 127) / 128), p.N / (16 * nt));
+  switch (nt) {
+    case 1: hipLaunchKernelGGL(f32_gemm_kernel<1>, grid, dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL(f32_gemm_kernel<2>, grid, dim3(256), 0, s, p); break;
+    case 4: hipLaunchKernelGGL(f32_gemm_kernel<4>, grid, dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL(f32_gemm_kernel<8>, grid, dim3(256), 0, s, p); break;
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);

@@ -523,17 +523,27 @@ struct Ws {
   AasistWs aa;
 };
 
-static size_t carve(const afx_engine* e, int B, int L, int Tfeat, void* base, Ws* w) {
+// Three entry shapes share one walk: the whole path (L > 0 samples), the path from the output of conv layer 5
+// (T5 > 0 frames: afx_tail_forward, the streaming mode's per-hop call), the head alone (Tfeat SSL frames).
+static size_t carve(const afx_engine* e, int B, int L, int Tfeat, void* base, Ws* w, int T5 = 0) {
   Carver c(base);
   const size_t hs = dtype_size(e->dt);
   int T = Tfeat;
-  if (L > 0) {
-    conv_lengths(L, w->T);
+  if (L > 0 || T5 > 0) {
+    if (L > 0) {
+      conv_lengths(L, w->T);
+      const size_t n0 = (size_t)B * w->T[0] * kC, n1 = (size_t)B * w->T[1] * kC;
+      w->bufA = c.take(n0 * hs);
+      w->bufB = c.take(n1 * hs);
+      w->tmp32 = (float*)c.take(n1 * 4);
+    } else {
+      for (int i = 0; i < 5; ++i) w->T[i] = 0;
+      w->T[5] = T5;
+      w->T[6] = T5 >= kConvK[6] ? (T5 - kConvK[6]) / kConvS[6] + 1 : 0;
+      w->bufA = w->bufB = nullptr;
+      w->tmp32 = (float*)c.take((size_t)B * (w->T[6] > 0 ? w->T[6] : 1) * kC * 4);
+    }
     T = w->T[6];
-    const size_t n0 = (size_t)B * w->T[0] * kC, n1 = (size_t)B * w->T[1] * kC;
-    w->bufA = c.take(n0 * hs);
-    w->bufB = c.take(n1 * hs);
-    w->tmp32 = (float*)c.take(n1 * 4);
     w->feats_h = c.take((size_t)B * T * kC * hs);
     w->x = (float*)c.take((size_t)B * T * kD * 4);
     w->xpad = c.take((size_t)B * (T + kPosK) * kD * hs);
@@ -737,7 +747,8 @@ static RowNormArgs plain_norm(const float* x, long ldx, int rows, int C, const f
 #define launch_gemm P_gemm
 #define launch_rownorm P_rownorm
 
-static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipStream_t s) {
+// l5: null = start from the waveform; else the output of conv layer 5, (B, T[5], 512) operand type (tail mode)
+static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipStream_t s, const void* l5 = nullptr) {
   const int dt = e->dt;
   const int* T = w.T;
   if (T[6] < 1) return fail("afx_forward: %d samples are too few for one output frame (need >= 400)", L);
@@ -745,15 +756,16 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     return e->F("ssl.feature_extractor.conv_layers." + std::to_string(i) + leaf);
   };
   // layer 0: waveform -> (B,T0,512) operand type, LN + GELU fused
-  KOK(timed(PC_CONV0, 2.0 * B * T[0] * kC * kConvK[0], s, [&] {
-    return launch_conv0(wave, B, L, T[0], cf(0, ".0.weight"), cf(0, ".0.bias"), cf(0, ".2.1.weight"),
-                        cf(0, ".2.1.bias"), e->cfg.pre_emphasis, e->cfg.pre_emphasis_coef, w.bufA, dt, s);
-  }));
+  if (!l5)
+    KOK(timed(PC_CONV0, 2.0 * B * T[0] * kC * kConvK[0], s, [&] {
+      return launch_conv0(wave, B, L, T[0], cf(0, ".0.weight"), cf(0, ".0.bias"), cf(0, ".2.1.weight"),
+                          cf(0, ".2.1.bias"), e->cfg.pre_emphasis, e->cfg.pre_emphasis_coef, w.bufA, dt, s);
+    }));
   // layers 1..6: conv-as-GEMM on a row-complete tile, LayerNorm(512) + GELU fused into the
   // epilogue (the pre-norm fp32 activations never leave the registers)
-  void* in = w.bufA;
+  void* in = l5 ? const_cast<void*>(l5) : w.bufA;
   void* out = w.bufB;
-  for (int i = 1; i < 7; ++i) {
+  for (int i = l5 ? 6 : 1; i < 7; ++i) {
     const int M = B * T[i], K = kConvK[i] * kC;
     GemmArgs g = plain_gemm(in, 0, e->convw[i], K, M, kC, K);
     g.rpb = T[i]; g.a_batch = (long)T[i - 1] * kC; g.a_row = (long)kConvS[i] * kC;
@@ -1058,6 +1070,28 @@ extern "C" int afx_forward(afx_handle h, const float* wave, int B, int L, float*
   hipStream_t s = (hipStream_t)stream;
   t_prof = h->prof;
   if (run_trunk(h, wave, B, L, w, s)) return 1;
+  return run_head(h, B, w.T[6], w, logits, s);
+}
+
+// The path from the output of conv layer 5 on (conv layer 6, feature LayerNorm, projection, positional conv,
+// transformer layers, head): what a streaming caller runs every hop after it has produced only the NEW frames of
+// conv layers 0-5 (afx/streaming.py).  Same kernels, same order as afx_forward from that point on.
+extern "C" size_t afx_tail_workspace_bytes(afx_handle h, int B, int T5) {
+  if (!h || B <= 0 || T5 <= 0) return 0;
+  Ws w;
+  return carve(h, B, 0, 0, nullptr, &w, T5);
+}
+extern "C" int afx_tail_forward(afx_handle h, const void* conv5_h, int B, int T5, float* logits, void* ws, size_t ws_bytes,
+                                void* stream) {
+  if (check_call(h, conv5_h, B, T5, logits, ws)) return 1;
+  if (h->cfg.arch == AFX_ARCH_SSL) return fail("afx_tail_forward: this handle has no back-end");
+  Ws w;
+  const size_t needb = carve(h, B, 0, 0, ws, &w, T5);
+  if (ws_bytes < needb) return fail("afx_tail_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
+  if (w.T[6] < 1) return fail("afx_tail_forward: %d conv-layer-5 frames are too few for one output frame", T5);
+  hipStream_t s = (hipStream_t)stream;
+  t_prof = h->prof;
+  if (run_trunk(h, nullptr, B, 0, w, s, conv5_h)) return 1;
   return run_head(h, B, w.T[6], w, logits, s);
 }
 

@@ -249,6 +249,39 @@ def test_streaming_scores_equal_the_reference_on_every_window(afx_mod):
         sc.push(torch.zeros(S, H))
 
 
+@pytest.mark.parametrize("arch", ["conformer", "xlsr_aasist"])
+def test_incremental_streaming_is_bit_identical_to_rescoring_the_window(afx_mod, arch):
+    """BASELINE config 5 with exact reuse (afx/streaming.py IncrementalScorer): conv layers 0-5 are computed once per
+    frame and cached, conv layer 6 and everything bidirectional is recomputed -- every hop's scores must EQUAL, bit for
+    bit, the scores of the full forward on the same window (SlidingWindowScorer, itself checked against the oracle at
+    every hop above), through the warm-up, the first full window and many hops of ring wrap-around."""
+    engine, synth = afx_mod
+    from afx.streaming import IncrementalScorer, SlidingWindowScorer
+    from oracle import models
+    if arch == "conformer":
+        sd = synth.model_state_dict("ConformerModel", n_layers=1, n_encoders=1)
+        eng = engine.Engine("conformer", n_layers=1, dtype="fp16", conf_blocks=1)
+        ofwd = models.conformer_forward
+    else:
+        sd = synth.model_state_dict("XLSR_AASIST", n_layers=1)
+        eng = engine.Engine("xlsr_aasist", n_layers=1, dtype="fp16")
+        ofwd = models.xlsr_aasist_forward
+    eng.load_state_dict(sd)
+    S, W, H = 3, 16000, 4000
+    inc = IncrementalScorer(eng, sd, S, window=W, hop=H)
+    ref = SlidingWindowScorer(eng, S, window=W, hop=H)
+    stream = synth.waveforms(S, 13 * H, batch_idx=91)
+    for step in range(13):
+        chunk = stream[:, step * H:(step + 1) * H].cuda()
+        a = inc.push(chunk).clone()
+        b = ref.push(chunk).clone()
+        assert torch.equal(a, b), f"hop {step}: {(a - b).abs().max().item():.2e}"
+    win = stream[:, -W:]
+    assert (a.cpu() - ofwd(sd, win)[:, 1]).abs().max().item() <= SCORE_TOL
+    with pytest.raises(ValueError, match="hop % 160"):
+        IncrementalScorer(eng, sd, S, window=16000, hop=1000)
+
+
 def test_distributed_scoring_over_rccl_with_one_rank(afx_mod, tmp_path):
     """afx.harness.produce_evaluation_file_distributed through the real RCCL backend (world size 1 on the
     one GPU of this box: same code path as N ranks -- shard, score, all-gather of (index, score) pairs,

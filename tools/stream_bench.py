@@ -1,5 +1,15 @@
-"""Real-time factor of the sliding-window streaming mode (BASELINE config 5) on one GPU:
-S concurrent streams, 250 ms hops, every hop re-scores each stream's last 4 s with the student."""
+"""Real-time factor of the streaming mode (BASELINE config 5): S concurrent streams per GPU, 250 ms hops, every hop
+emits each stream's score of its last 4 s.  Two scorers with bit-identical outputs (afx/streaming.py):
+  sliding      the whole model on the window every hop (round 1);
+  incremental  conv layers 0-5 cached per absolute frame, only the new 800/400/.../25 frames computed per hop.
+
+    python tools/stream_bench.py [--workload conformer_student|xlsr_aasist] [--streams 1 64 512 2048]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/stream_bench.py --gpus N ...
+
+With --gpus N every rank pins its own S streams to its GPU (state lives there; nothing is exchanged on the data path);
+the hop time reported is the max over ranks (one RCCL all-reduce of a scalar, outside the timed hops), the stream
+count the sum."""
+import argparse
 import os
 import sys
 import time
@@ -9,23 +19,56 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "real-time-deepfake-speech-detection_amd")]
 from afx import engine, synth  # noqa: E402
-from afx.streaming import SlidingWindowScorer  # noqa: E402
+from afx.streaming import IncrementalScorer, SlidingWindowScorer  # noqa: E402
 
-sd = synth.model_state_dict("ConformerModel", n_layers=6)
-eng = engine.Engine("conformer", n_layers=6, dtype="fp16")
-eng.load_state_dict(sd)
-W, H = 64000, 4000
-for S in [int(a) for a in (sys.argv[1:] or ["1", "64", "512", "2048"])]:
-    sc = SlidingWindowScorer(eng, S, window=W, hop=H)
-    chunk = (0.1 * torch.randn(S, H)).cuda()
-    for _ in range(W // H + 2):  # fill the rings, reach the steady state
-        sc.push(chunk)
-    torch.cuda.synchronize()
-    n = 10
-    t0 = time.perf_counter()
-    for _ in range(n):
-        scores = sc.push(chunk)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
-    print(f"streams {S:5d}: {dt * 1e3:8.2f} ms per 250-ms hop  RTF {dt / 0.25:6.3f}  ({S / dt:8.0f} window scores/s)", flush=True)
-    del sc
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workload", default="conformer_student", choices=["conformer_student", "xlsr_aasist"])
+    ap.add_argument("--streams", type=int, nargs="*", default=[1, 64, 512, 2048])
+    ap.add_argument("--hops", type=int, default=10)
+    args = ap.parse_args()
+    rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    arch, oname, nl = ("conformer", "ConformerModel", 6) if args.workload == "conformer_student" else ("xlsr_aasist", "XLSR_AASIST", 24)
+    sd = synth.model_state_dict(oname, n_layers=nl)
+    eng = engine.Engine(arch, n_layers=nl, dtype="fp16")
+    eng.load_state_dict(sd)
+    W, H = 64000, 4000
+    for S in args.streams:
+        line = f"{args.workload}, {world} GPU(s) x {S} streams:"
+        for name in ("sliding", "incremental"):
+            sc = SlidingWindowScorer(eng, S, window=W, hop=H) if name == "sliding" else IncrementalScorer(eng, sd, S, window=W, hop=H)
+            chunk = (0.1 * torch.randn(S, H, generator=torch.Generator().manual_seed(rank))).cuda()
+            for _ in range(W // H + 2):  # fill the window, reach the steady state
+                sc.push(chunk)
+            torch.cuda.synchronize()
+            if dist:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.hops):
+                sc.push(chunk)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.hops
+            if dist:
+                t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = t.item()
+            line += f"  {name} {dt * 1e3:8.2f} ms/hop RTF {dt / 0.25:6.3f} ({world * S / dt:8.0f} scores/s)"
+            del sc
+        if rank == 0:
+            print(line, flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
