@@ -108,7 +108,6 @@ const char* afx_profile_class_name(int cls);
  * "gemm_map": workgroup->tile order of the MFMA GEMM, -1 default, 0 linear, 1 XCD-
  * contiguous, 2 XCD-contiguous + grouped.  "gemm_tile": -1 auto, 0 128x128, 1 256x256.
  * "fuse_conv_ln": 1 (default) conv layers 1-6 use the fused LayerNorm epilogue, 0 two kernels.
- * "split_k": 1 (default) small-M out-proj / FC2 run split-K and the next LayerNorm folds the planes in, 0 whole products.
  * None of these changes WHAT is computed; the timing-only switches that do ("gemm_nodma") exist only in the
  * attribution build (make attr), the product library refuses them. */
 int afx_debug_set(const char* key, int value);
@@ -118,17 +117,6 @@ int afx_debug_set(const char* key, int value);
 int afx_k_gemm(int dtype, const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
                int act, float alpha, const float* resid, long ldr, float* out_f, long ldo_f, void* out_h, long ldo_h,
                void* stream);
-/* Split-K pair (small-M products that leave most CUs idle as 256x256 tiles: the teacher's out-proj / FC2 at batch 16).
- * afx_k_gemm_splitk: K cut into S equal slices, `part` receives S raw fp32 partial planes (M x N each, no bias);
- * afx_k_rownorm_splitk, the consumer the engine uses: x_out = x + add_bias + plane 0 + ... + plane S-1 in that fixed
- * order (x_out may alias x), then LayerNorm(x_out) -> out_f / out_h.  afx_pick_split_k: the engine's choice of S for a
- * product (0 = not split). */
-int afx_k_gemm_splitk(int dtype, const void* A, long lda, const void* W, long ldw, int M, int N, int K, int S, float* part,
-                      void* stream);
-int afx_pick_split_k(int M, int N, int K);
-int afx_k_rownorm_splitk(int dtype, const float* x, int rows, int C, const float* gamma, const float* beta, float eps,
-                         const float* part, int S, const float* add_bias, float* x_out, float* out_f, void* out_h,
-                         void* stream);
 /* Conv1d(Cin->N, k, stride s) on channel-last input (B,Tin,Cin) as one GEMM; Wp is
  * the tap-major packed weight [N][k*Cin]; out_f (B,Tout,N) fp32 */
 int afx_k_conv_gemm(int dtype, const void* in_h, const void* Wp, int B, int Tin, int Tout, int Cin, int k, int s,

@@ -51,9 +51,6 @@ SIGNATURES = {
     "afx_profile_class_name": (C.c_char_p, [_I]),
     "afx_debug_set": (_I, [C.c_char_p, _I]),
     "afx_k_gemm": (_I, [_I, _P, _L, _P, _L, _I, _I, _I, _P, _I, _F, _P, _L, _P, _L, _P, _L, _P]),
-    "afx_k_gemm_splitk": (_I, [_I, _P, _L, _P, _L, _I, _I, _I, _I, _P, _P]),
-    "afx_pick_split_k": (_I, [_I, _I, _I]),
-    "afx_k_rownorm_splitk": (_I, [_I, _P, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P, _P, _P]),
     "afx_k_conv_gemm": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "afx_k_conv_ln_act": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _P, _P]),
     "afx_k_pack_linear": (_I, [_I, _P, _I, _I, _I, _P, _P]),

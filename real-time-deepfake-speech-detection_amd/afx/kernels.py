@@ -20,27 +20,6 @@ def gemm(dtype, A, W, bias=None, act=None, alpha=1.0, resid=None, out_f=True, ou
     return of, oh
 
 
-def gemm_splitk(dtype, A, W, S):
-    """A (M,K) half, W (N,K) half -> S raw fp32 partial planes (S,M,N): plane s = A[:, slice s] @ W[:, slice s]^T."""
-    M, K = A.shape
-    N = W.shape[0]
-    part = torch.empty(S, M, N, dtype=torch.float32, device=A.device)
-    check(lib().afx_k_gemm_splitk(DTYPES[dtype], ptr(A), A.stride(0), ptr(W), W.stride(0), M, N, K, S, ptr(part),
-                                  stream_ptr()))
-    return part
-
-
-def rownorm_splitk(dtype, x, part, add_bias, gamma, beta, eps=1e-5):
-    """x (rows,C) fp32 residual rows, part (S,rows,C): -> (x + bias + sum of planes, LayerNorm of it fp32, half)."""
-    rows, Cc = x.shape
-    xo = torch.empty_like(x)
-    of = torch.empty(rows, Cc, dtype=torch.float32, device=x.device)
-    oh = torch.empty(rows, Cc, dtype=torch_dtype(dtype), device=x.device)
-    check(lib().afx_k_rownorm_splitk(DTYPES[dtype], ptr(x), rows, Cc, ptr(gamma), ptr(beta), eps, ptr(part),
-                                     part.shape[0], ptr(add_bias), ptr(xo), ptr(of), ptr(oh), stream_ptr()))
-    return xo, of, oh
-
-
 def pack_linear(dtype, w, kpad=None):
     N, K = w.shape
     kpad = kpad or K

@@ -497,7 +497,6 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
 // ---------------------------------------------------------------------------------
 // workspace carving (identical walk for sizing and for the real call)
 // ---------------------------------------------------------------------------------
-static int g_split_k = 1;  // small-M N = 1024 products as split-K partial planes folded into the next LayerNorm (A/B knob)
 struct Carver {
   char* base;
   size_t off = 0;
@@ -514,8 +513,6 @@ struct Ws {
   int T[7];
   void *bufA, *bufB, *feats_h, *xpad, *hbuf, *qkv, *att, *ff, *ssl_h;
   float *tmp32, *x, *ssl_f;
-  float* part;      // split-K partial planes of the N = 1024 products (out-proj, FC2), consumed by the next LayerNorm
-  int s_out, s_fc2; // their split factors at this batch size (0: product left whole)
   // Conformer
   float *ll32, *xc, *qkv32, *glu32;
   void *hc, *hid, *ao, *u;
@@ -551,14 +548,6 @@ static size_t carve(const afx_engine* e, int B, int L, int Tfeat, void* base, Ws
     w->qkv = c.take((size_t)B * T * 3 * kD * hs);
     w->att = c.take((size_t)B * T * kD * hs);
     w->ff = c.take((size_t)B * T * kF * hs);
-    w->s_out = w->s_fc2 = 0;
-    w->part = nullptr;
-    if (e->dt != AFX_DT_FP32 && g_split_k) {
-      w->s_out = gemm_pick_split_k(B * T, kD, kD);
-      w->s_fc2 = gemm_pick_split_k(B * T, kD, kF);
-    }
-    const int smax = w->s_out > w->s_fc2 ? w->s_out : w->s_fc2;
-    if (smax > 0) w->part = (float*)c.take((size_t)smax * B * T * kD * 4);
   }
   w->ssl_f = (float*)c.take((size_t)B * T * kD * 4);
   w->ssl_h = c.take((size_t)B * T * kD * hs);
@@ -834,63 +823,41 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     KOK(launch_gemm(g, dt, kPosG, s));
   }
   if (tap(e, "pos", w.x, (size_t)M * kD, false, s)) return 1;
-  // transformer layers (pre-LN).  At small M the two N = 1024 products (out-proj, FC2) are 52 256x256 tiles for 256
-  // CUs: they run split-K (raw fp32 partial planes, afx_gemm.hip) and the LayerNorm that follows each of them
-  // anyway adds bias + planes to the residual stream x on its way through (fixed order: deterministic).
-  int pend_s = 0;               // planes waiting in w.part for the next LayerNorm
-  const float* pend_bias = nullptr;
-  auto consume = [&](RowNormArgs& n) {
-    if (!pend_s) return;
-    n.part = w.part; n.nsplit = pend_s; n.part_stride = (long)M * kD; n.ldp = kD;
-    n.add_bias = pend_bias; n.x_out = w.x; n.ldx_out = kD;
-    pend_s = 0;
-  };
-  auto resid_product = [&](const void* A, long lda, const void* W, int K, const float* bias, int S) -> const char* {
+  // transformer layers (pre-LN)
+  auto resid_product = [&](const void* A, long lda, const void* W, int K, const float* bias) -> const char* {
     GemmArgs o = plain_gemm(A, lda, W, K, M, kD, K);
-    if (S > 1) {
-      o.split_k = S; o.part_stride = (long)M * kD; o.out_f = w.part; o.ldo_f = kD;
-      pend_s = S; pend_bias = bias;
-    } else {
-      o.bias = bias; o.resid = w.x; o.ldr = kD; o.out_f = w.x; o.ldo_f = kD;
-    }
+    o.bias = bias; o.resid = w.x; o.ldr = kD; o.out_f = w.x; o.ldo_f = kD;
     return launch_gemm(o, dt, 1, s);
   };
   for (int l = 0; l < e->cfg.n_layers; ++l) {
     const std::string P = "ssl.encoder.layers." + std::to_string(l) + ".";
     RowNormArgs n1 = plain_norm(w.x, kD, M, kD, e->F(P + "self_attn_layer_norm.weight"), e->F(P + "self_attn_layer_norm.bias"));
     n1.out_h = w.hbuf; n1.ldo_h = kD;
-    consume(n1);
     KOK(launch_rownorm(n1, dt, s));
-    if (e->taps_on && l > 0) {  // x is complete only behind the LayerNorm that folded the previous layer's FC2 planes in
-      const std::string nm = "layer" + std::to_string(l - 1);
-      if (tap(e, nm.c_str(), w.x, (size_t)M * kD, false, s)) return 1;
-    }
     GemmArgs q = plain_gemm(w.hbuf, kD, e->wqkv[l], kD, M, 3 * kD, kD);
     q.bias = e->bqkv[l];
     q.out_h = w.qkv; q.ldo_h = 3 * kD;
     KOK(launch_gemm(q, dt, 1, s));
     KOK(timed(PC_MHSA, 4.0 * B * kH * (double)Tt * Tt * 64, s, [&] { return launch_mhsa(w.qkv, w.att, B, Tt, kH, dt, s); }));
-    KOK(resid_product(w.att, kD, e->wo[l], kD, e->F(P + "self_attn.out_proj.bias"), w.s_out));
+    KOK(resid_product(w.att, kD, e->wo[l], kD, e->F(P + "self_attn.out_proj.bias")));
     RowNormArgs n2 = plain_norm(w.x, kD, M, kD, e->F(P + "final_layer_norm.weight"), e->F(P + "final_layer_norm.bias"));
     n2.out_h = w.hbuf; n2.ldo_h = kD;
-    consume(n2);
     KOK(launch_rownorm(n2, dt, s));
     GemmArgs f1 = plain_gemm(w.hbuf, kD, e->w1[l], kD, M, kF, kD);
     f1.bias = e->F(P + "fc1.bias"); f1.act = ACT_GELU;
     f1.out_h = w.ff; f1.ldo_h = kF;
     KOK(launch_gemm(f1, dt, 1, s));
-    KOK(resid_product(w.ff, kF, e->w2[l], kF, e->F(P + "fc2.bias"), w.s_fc2));
+    KOK(resid_product(w.ff, kF, e->w2[l], kF, e->F(P + "fc2.bias")));
+    if (e->taps_on) {
+      const std::string nm = "layer" + std::to_string(l);
+      if (tap(e, nm.c_str(), w.x, (size_t)M * kD, false, s)) return 1;
+    }
   }
   // final encoder LayerNorm -> fp32 features (API output / AASIST input) + operand copy (LL GEMM)
   RowNormArgs nf = plain_norm(w.x, kD, M, kD, e->F("ssl.encoder.layer_norm.weight"), e->F("ssl.encoder.layer_norm.bias"));
   nf.out_f = w.ssl_f; nf.ldo_f = kD;
   nf.out_h = w.ssl_h; nf.ldo_h = kD;
-  consume(nf);
   KOK(launch_rownorm(nf, dt, s));
-  if (e->taps_on) {
-    const std::string nm = "layer" + std::to_string(e->cfg.n_layers - 1);
-    if (tap(e, nm.c_str(), w.x, (size_t)M * kD, false, s)) return 1;
-  }
   if (tap(e, "ssl", w.ssl_f, (size_t)M * kD, false, s)) return 1;
   return 0;
 }
@@ -1166,24 +1133,6 @@ extern "C" int afx_k_gemm(int dtype, const void* A, long lda, const void* W, lon
   g.out_f = out_f; g.ldo_f = ldo_f; g.out_h = out_h; g.ldo_h = ldo_h;
   KRET(launch_gemm(g, dtype, 1, (hipStream_t)stream));
 }
-// split-K form of a plain product on the 8-phase kernel: S raw fp32 partial planes (M x N each, plane s = K slice s)
-extern "C" int afx_k_gemm_splitk(int dtype, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
-                                 int S, float* part, void* stream) {
-  GemmArgs g = plain_gemm(A, lda, W, ldw, M, N, K);
-  g.split_k = S; g.part_stride = (long)M * N; g.out_f = part; g.ldo_f = N;
-  KRET(launch_gemm(g, dtype, 1, (hipStream_t)stream));
-}
-extern "C" int afx_pick_split_k(int M, int N, int K) { return gemm_pick_split_k(M, N, K); }
-// its consumer: x_out = x + add_bias + plane 0 + ... + plane S-1 (fixed order), then LayerNorm of that row
-extern "C" int afx_k_rownorm_splitk(int dtype, const float* x, int rows, int C, const float* gamma, const float* beta,
-                                    float eps, const float* part, int S, const float* add_bias, float* x_out,
-                                    float* out_f, void* out_h, void* stream) {
-  RowNormArgs a = plain_norm(x, C, rows, C, gamma, beta);
-  a.eps = eps; a.out_f = out_f; a.ldo_f = C; a.out_h = out_h; a.ldo_h = C;
-  a.part = part; a.nsplit = S; a.part_stride = (long)rows * C; a.ldp = C; a.add_bias = add_bias;
-  a.x_out = x_out; a.ldx_out = C;
-  KRET(launch_rownorm(a, dtype, (hipStream_t)stream));
-}
 extern "C" int afx_k_conv_gemm(int dtype, const void* in_h, const void* Wp, int B, int Tin, int Tout, int Cin, int k,
                                int s_, int N, const float* bias, float* out_f, void* stream) {
   GemmArgs g = plain_gemm(in_h, 0, Wp, (long)k * Cin, B * Tout, N, k * Cin);
@@ -1272,10 +1221,7 @@ extern "C" int afx_debug_set(const char* key, int value) {
     g_fuse_conv_ln = value != 0;
     return 0;
   }
-  if (!strcmp(key, "split_k")) {
-    g_split_k = value != 0;
-    return 0;
-  }
+
   return fail("afx_debug_set: unknown key '%s'", key);
 }
 extern "C" int afx_k_pre_emphasis(const float* x, int B, int L, float coef, float* y, void* stream) {

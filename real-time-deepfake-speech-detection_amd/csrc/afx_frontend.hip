@@ -271,7 +271,7 @@ const char* launch_tile_crop(const float* x, const long long* offs, const long l
 // fp32 like torch.  Used for the conv-stack LayerNorm+GELU, every transformer /
 // Conformer LayerNorm and the final encoder LayerNorm.  HBM-bound.
 // ---------------------------------------------------------------------------------
-template <class HT, bool REDUCE>
+template <class HT>
 __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
   typedef typename HT::T T;
   typedef typename HT::V4 V4;
@@ -292,38 +292,6 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
       if (c < a.C) v[u][it] = *(const f32x4*)(x + c);
     }
   }
-  if constexpr (REDUCE) {
-    // split-K consumer (GemmArgs::split_k): row = x + bias + plane 0 + plane 1 + ..., always in that order, so the
-    // sum is the same whichever workgroup of the producer finished first; the new residual row goes back to x_out
-    f32x4 ab[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int c = (it * 64 + lane) * 4;
-      ab[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a.add_bias && c < a.C) ab[it] = *(const f32x4*)(a.add_bias + c);
-    }
-#pragma unroll
-    for (int u = 0; u < RPW; ++u)
-#pragma unroll
-      for (int it = 0; it < 4; ++it) v[u][it] += ab[it];
-    for (int sp = 0; sp < a.nsplit; ++sp) {
-      f32x4 pv[RPW][4];
-#pragma unroll
-      for (int u = 0; u < RPW; ++u) {
-        const float* pr = a.part + (long)sp * a.part_stride + (live[u] ? r0 + u : r0) * a.ldp;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int c = (it * 64 + lane) * 4;
-          pv[u][it] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (c < a.C) pv[u][it] = *(const f32x4*)(pr + c);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < RPW; ++u)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) v[u][it] += pv[u][it];
-    }
-  }
   // gamma / beta once per wave, requested before any store: on gfx9 a wait for a load that was issued after a
   // store is a wait for the store as well (one shared, out-of-order vmcnt)
   f32x4 gm[4], bt[4];
@@ -334,19 +302,6 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
     if (c < a.C) {
       gm[it] = *(const f32x4*)(a.gamma + c);
       bt[it] = *(const f32x4*)(a.beta + c);
-    }
-  }
-  if constexpr (REDUCE) {
-    if (a.x_out) {
-#pragma unroll
-      for (int u = 0; u < RPW; ++u) {
-        if (!live[u]) continue;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int c = (it * 64 + lane) * 4;
-          if (c < a.C) *(f32x4*)(a.x_out + (r0 + u) * a.ldx_out + c) = v[u][it];
-        }
-      }
     }
   }
   const float inv = 1.0f / (float)a.C;
@@ -405,12 +360,7 @@ const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
   if (a.rows <= 0 || a.C <= 0 || a.C > 1024 || a.C % 4) return "rownorm: need 0 < C <= 1024, C % 4 == 0";
   if (!a.out_f && !a.out_h) return "rownorm: no output";
   dim3 grid((a.rows + 7) / 8);  // 4 waves x 2 rows
-  if (a.nsplit > 0) {
-    if (!a.part || a.nsplit > 16 || a.rpb < a.rows) return "rownorm: split-K consumer needs planes, nsplit <= 16, one batch";
-    AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL((rownorm_kernel<HT, true>), grid, dim3(256), 0, s, a));
-  } else {
-    AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL((rownorm_kernel<HT, false>), grid, dim3(256), 0, s, a));
-  }
+  AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL(rownorm_kernel<HT>, grid, dim3(256), 0, s, a));
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -45,7 +45,7 @@ namespace afx {
 // fallback: ~300 KB of code around a 12-KB K-loop, refetched through the instruction cache after every tile.
 template <class HT, int BM, int BN, int WR, int WC, bool ROWLN, bool LEAN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / WR / 16][BN / WC / 16], char* smem,
-                                              int m0, int n0, int g, long out_f_off = 0) {
+                                              int m0, int n0, int g) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
   typedef typename HT::V4 V4;
@@ -266,7 +266,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           vb += rr[1];
         }
         if (p.out_f) {
-          float* op = p.out_f + out_f_off + orow * p.ldo_f + gcol + n;
+          float* op = p.out_f + orow * p.ldo_f + gcol + n;
           *(f32x4*)op = va;
           *(f32x4*)(op + 4) = vb;
         }
@@ -559,11 +559,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   const T* Ag = (const T*)p.A + (long)g * p.g_a;
   const T* Wg = (const T*)p.W + (long)g * p.g_w;
   const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
-  const int ntile = nM * nN;
-  const int nsl = p.split_k > 1 ? p.split_k : 1;  // split-K: work item = (K slice, tile), slice-major
-  const int nwg = ntile * nsl;
-  const int nk = (p.K >> 6) / nsl;                // K-tiles per work item
-  int slice = 0;
+  const int nwg = nM * nN;
+  const int nk = p.K >> 6;
 
   // DMA source pointers.  Piece (i*8 + wave) of a half-tile is LDS rows 8(i*8+wave) .. +7,
   // lane l -> row l>>3, 16-B slot l&7 holding logical chunk (l&7) ^ ((row>>1)&7).
@@ -583,8 +580,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
       const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
       L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
     }
-    slice = L / ntile;  // an XCD's contiguous run of the order stays inside one K slice: shared A / W panels meet in its L2
-    L -= slice * ntile;
     if (p.map_mode == 2) {
       constexpr int GM = 8;
       const int width = GM * nN, grp = L / width, first = grp * GM;
@@ -597,7 +592,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     }
     m0 = pm * BM;
     n0 = pn * BN;
-    const int k0 = slice * nk * 64;  // first k of this work item
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -606,7 +600,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         int m = m0 + (r / (RA / 2)) * (BM / 2) + h * (RA / 2) + r % (RA / 2);
         m = m < p.M ? m : p.M - 1;
-        srcA[h][i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8 + k0;
+        srcA[h][i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
       }
 #pragma unroll
       for (int i = 0; i < DB; ++i) {
@@ -614,7 +608,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         int n = n0 + (r / (RB / 4)) * (BN / 4) + h * (RB / 4) + r % (RB / 4);
         n = n < p.N ? n : p.N - 1;
-        srcB[h][i] = Wg + (long)n * p.ldw + c * 8 + k0;
+        srcB[h][i] = Wg + (long)n * p.ldw + c * 8;
       }
     }
   };
@@ -770,7 +764,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     // and the first K-tile's fill hide behind the bias / activation / store work.  (The row-
     // LayerNorm epilogue keeps its scratch in the one half-tile the prologue does not write.)
     const int m0c = m0, n0c = n0;
-    const long plane = (long)slice * p.part_stride;  // split-K: this work item's partial plane (0 otherwise)
     const int vn = v + gridDim.x;
     if (vn < nwg) {
       setup(vn);
@@ -784,7 +777,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) asm volatile("" :: "v"(acc[i][j][r]));
     } else {
-      gemm_epilogue<HT, BM, BN, 2, 4, ROWLN, true>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g, plane);
+      gemm_epilogue<HT, BM, BN, 2, 4, ROWLN, true>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
     }
     if (vn >= nwg) break;
     v = vn;
@@ -808,7 +801,7 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
     n_cu_of[dev] = cus < 8 ? 8 : cus;
   }
   const int n_cu = n_cu_of[dev];
-  const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * (p.split_k > 1 ? p.split_k : 1);
+  const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
   dim3 grid(tiles < n_cu ? tiles : n_cu, 1, groups);  // persistent: at most one workgroup per CU
   hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN>), grid, dim3(512), lds, s, p);
   return hipGetLastError();
@@ -849,12 +842,6 @@ static const char* check_gemm(const GemmArgs& p, int groups) {
   if (p.kchunk <= 0 || p.kchunk % 64) return "gemm: kchunk must be a positive multiple of 64";
   if (p.rpb <= 0) return "gemm: rows-per-batch must be positive";
   if (!p.out_f && !p.out_h) return "gemm: no output";
-  if (p.split_k > 1) {
-    if (groups != 1 || p.kchunk != p.K || (p.K / 64) % p.split_k || p.ln_gamma) return "gemm: split-K needs a plain product with K / 64 divisible by the split";
-    if (p.bias || p.resid || p.out_h || p.act != ACT_NONE || p.alpha != 1.f || !p.out_f || (p.N & 7))
-      return "gemm: split-K stores raw fp32 partial planes only (bias / activation / residual belong to the consumer)";
-    if (p.part_stride < (long)p.M * p.ldo_f) return "gemm: split-K planes overlap";
-  }
   if (p.ln_gamma) {
     if (p.N != 512 || groups != 1) return "gemm: the fused LayerNorm epilogue needs N == 512 (row-complete tile)";
     if (!p.ln_beta || !p.bias || p.resid || p.alpha != 1.f) return "gemm: fused LayerNorm epilogue: bias + LN + act only";
@@ -865,7 +852,7 @@ static const char* check_gemm(const GemmArgs& p, int groups) {
 bool gemm_is_narrow(int N) { return N <= 64 || (N > 128 && N < 256 && N % 128 != 0); }
 
 // Which tile instance serves a problem: 0 = 128x128, 1 = 128x64, 2 = 256x256 (2-stage),
-// 3 = the row-complete 128x512 tile with the fused LayerNorm epilogue (2-stage), 4 = 256x128,
+// 3 = the row-complete 128x512 tile with the fused LayerNorm epilogue (2-stage),
 // 7 = 8-phase 256x256, 8 = 8-phase row-complete 128x512.
 // 256x256 tiles halve the operand bytes per FLOP (the per-CU L2->LDS rate is what bounds
 // this kernel) but quantise badly at M = B*199: measured faster only for the conv layers
@@ -891,27 +878,11 @@ static int gemm_split_rows(const GemmArgs& p, int groups) {
   return (int)(nM1 * 256);
 }
 
-// Split-K factor for a plain product whose 256x256 tiles leave most of the 256 CUs idle (the teacher's N = 1024
-// products at M = 16 x 199: 52 tiles): the largest S <= 8 with tiles x S <= 256, S | K / 64 and at least 4 K-tiles per
-// work item (shorter K-loops are all prologue).  0 = leave the product whole.
-int gemm_pick_split_k(int M, int N, int K) {
-  const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
-  if ((N & 7) || K % 64 || tiles < 16 || tiles > 128) return 0;
-  const int nk = K / 64;
-  for (int S = 8; S >= 2; --S)
-    if (tiles * S <= 256 && nk % S == 0 && nk / S >= 4) return S;
-  return 0;
-}
-
 int gemm_tile_of(const GemmArgs& p, int groups) {
-  if (p.split_k > 1) return 7;
   if (p.ln_gamma) return g_deep != 0 && p.kchunk == p.K ? 8 : 3;
   if (gemm_is_narrow(p.N)) return 1;
   if (groups != 1) return 0;
-  if (g_tile_override == 2) return 4;  // 256x128 / 8 waves (A/B only: slower everywhere measured)
-  if (g_tile_override == 4) return 5;  // 128x128 / 8 waves, 2-stage (A/B)
-  if (g_tile_override == 5) return 1;  // 128x64 / 4 waves (A/B: forced)
-  if (g_tile_override == 6) return 6;  // 128x256 / 8 waves, 2-stage (A/B)
+  if (g_tile_override == 5) return 1;  // 128x64 / 4 waves (forced)
   if (g_tile_override == 3) return p.kchunk == p.K ? 7 : 0;  // 8-phase 256x256
   if (g_tile_override >= 0) return g_tile_override == 1 ? 2 : 0;
   // Wave-quantisation model fitted to tools/bench_gemm.py (profiles/r01_gemm_tile_ab*.txt):
@@ -935,9 +906,6 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 1: return lean ? launch_gemm_t<HT, 128, 64, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 64, 2, 2>(p, groups, s);
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
-    case 4: return launch_gemm_t<HT, 256, 128, 4, 2>(p, groups, s);
-    case 5: return lean ? launch_gemm_t<HT, 128, 128, 2, 4, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 128, 2, 4>(p, groups, s);
-    case 6: return lean ? launch_gemm_t<HT, 128, 256, 2, 4, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 256, 2, 4>(p, groups, s);
     case 7: return launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
     case 8: return launch_gemm8_t<HT, 128, 512, true>(p, groups, s);
     default: return lean ? launch_gemm_t<HT, 128, 128, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
@@ -954,7 +922,7 @@ const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t
     tile = tile == 7 ? 0 : 3;  // the 8-phase kernels carry the lean epilogue: everything else stays on the 2-stage tiles
   p.a_nt = g_ant_override >= 0 ? g_ant_override : (tile == 3 ? 1 : 0);
   p.dbg_nodma = g_nodma;
-  const int m1 = tile == 7 && g_tile_override < 0 && p.split_k <= 1 ? gemm_split_rows(p, groups) : 0;
+  const int m1 = tile == 7 && g_tile_override < 0 ? gemm_split_rows(p, groups) : 0;
   if (m1 > 0) {  // rows [0, m1) on the 8-phase kernel, rows [m1, M) on the 128x128 kernel
     const size_t hs = 2;
     GemmArgs a = p, b = p;

@@ -46,13 +46,6 @@ struct GemmArgs {
   const float* ln_beta;
   float ln_eps;
   int a_nt;  // 1: non-temporal LDS-DMA for the A panel (set by launch_gemm)
-  // Split-K (small-M products whose 256x256 tiles do not fill the chip: M = 16 x 199 rows, N = 1024 is 52 tiles on
-  // 256 CUs): split_k = S > 1 cuts K into S equal slices; work item (slice, tile) accumulates its slice and stores the
-  // raw fp32 partial tile into plane `slice` of out_f (planes part_stride floats apart, row stride ldo_f).  No bias,
-  // activation, residual or operand-type output here: the consumer (launch_rownorm with RowNormArgs::part) adds the
-  // planes in slice order, so the result does not depend on which workgroup finished when.  K / 64 % S == 0.
-  int split_k;
-  long part_stride;
   int dbg_nodma;  // attribution build (-DAFX_ATTR) only, ignored otherwise: epilogue bits 8 no activation, 16 narrow stores, 32 no stores, 64 no epilogue
 };
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
@@ -95,18 +88,7 @@ struct RowNormArgs {
   void* out_h;
   long ldo_h;
   int rpb, o_batch_rows, o_row_off;
-  // Split-K consumer: x_row += add_bias + part[0][row] + ... + part[nsplit-1][row] (planes part_stride floats apart,
-  // row stride ldp, same row index as x), the sum is written back to x_out (may alias x: a wave owns its rows) and
-  // then normalised.  nsplit = 0: plain LayerNorm of x.
-  const float* part;
-  int nsplit;
-  long part_stride, ldp;
-  const float* add_bias;
-  float* x_out;
-  long ldx_out;
 };
-// S for a plain M x N x K product on the 8-phase 256x256 kernel: 0 = do not split
-int gemm_pick_split_k(int M, int N, int K);
 const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s);
 // zero the time padding rows of the positional-conv operand buffer (B, T+128, C)
 const char* launch_zero_pad_rows(void* buf_h, int B, int T, int C, int pad_front, int pad_back, int dtype,

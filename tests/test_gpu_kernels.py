@@ -420,47 +420,3 @@ def test_conformer_glu_depthwise_bn_swish(K, k, N):
     y = y * sc[None, :, None] + sh[None, :, None]
     ref = (y * torch.sigmoid(y)).transpose(1, 2).reshape(B * N, C)
     _close(got, ref, 2e-3, 2e-3)
-
-
-@pytest.mark.parametrize("M,N,K_,S", [(3184, 1024, 1024, 4), (3184, 1024, 4096, 4), (1000, 512, 512, 2), (199, 1024, 4096, 8)])
-def test_gemm_split_k_planes_and_layernorm_consumer(K, M, N, K_, S):
-    """Split-K of the small-M N = 1024 products (teacher out-proj / FC2 at batch 16: 52 tiles for 256 CUs).  Each
-    plane must equal the product over its own K slice (bit for bit the whole-K 8-phase kernel on that slice: same k
-    order), the planes are identical launch after launch, and the consumer's x + bias + planes (fixed order) and its
-    LayerNorm match an fp32 reference."""
-    from afx._lib import check, lib
-    g = torch.Generator().manual_seed(M + K_)
-    A = torch.randn(M, K_, generator=g).half().cuda()
-    W = (torch.randn(N, K_, generator=g) / math.sqrt(K_)).half().cuda()
-    part = K.gemm_splitk("fp16", A, W, S)
-    ks = K_ // S
-    try:
-        check(lib().afx_debug_set(b"gemm_tile", 3))  # the whole-K 8-phase kernel on each slice
-        for s_ in range(S):
-            want, _ = K.gemm("fp16", A[:, s_ * ks:(s_ + 1) * ks], W[:, s_ * ks:(s_ + 1) * ks])
-            assert torch.equal(part[s_], want)
-    finally:
-        check(lib().afx_debug_set(b"gemm_tile", -1))
-    for _ in range(6):
-        assert torch.equal(K.gemm_splitk("fp16", A, W, S), part)
-    x = torch.randn(M, N, generator=g).cuda()
-    bias = torch.randn(N, generator=g).cuda()
-    ga = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
-    be = (0.1 * torch.randn(N, generator=g)).cuda()
-    xo, of, oh = K.rownorm_splitk("fp16", x, part, bias, ga, be)
-    want_x = x + bias
-    for s_ in range(S):
-        want_x = want_x + part[s_]
-    assert torch.equal(xo, want_x)  # the documented order, exactly
-    _close(xo, (x + bias + A.float() @ W.float().t()).cpu(), 2e-4, 2e-4)
-    ref = F.layer_norm(want_x.cpu(), (N,), ga.cpu(), be.cpu(), 1e-5)
-    _close(of, ref, 2e-5, 2e-5)
-    _close(oh, ref, 2e-3, 1e-3)
-
-
-def test_split_k_choice_fills_the_chip_and_leaves_large_batches_whole():
-    from afx._lib import lib
-    pick = lib().afx_pick_split_k
-    assert pick(16 * 199, 1024, 1024) == 4 and pick(16 * 199, 1024, 4096) == 4   # 52 tiles x 4 = 208 work items
-    assert pick(64 * 199, 1024, 1024) == 0 and pick(64 * 199, 1024, 4096) == 0   # 200 tiles: left whole
-    assert pick(199, 1024, 4096) == 0                                           # 4 tiles: the small-tile kernel's case

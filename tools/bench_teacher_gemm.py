@@ -1,5 +1,6 @@
-"""A/B of GEMM variants on the teacher's (B = 16, M = 3184) products, interleaved rounds in one process:
-tile instances (gemm_tile override) and split-K (planes + the LayerNorm consumer's extra read, timed as a pair)."""
+"""A/B of GEMM tile instances (gemm_tile override) on the teacher's (B = 16, M = 3184) products, interleaved rounds in
+one process.  (Round 2 also measured here, and rejected: split-K with fp32 partial planes folded into the next LayerNorm,
+and 8-wave 128x128 / 128x256 / 256x128 2-stage tiles -- profiles/r02_teacher_gemm_tile_splitk_ab.txt.)"""
 import os
 import statistics
 import sys
@@ -13,7 +14,7 @@ from afx._lib import check, lib  # noqa: E402
 
 M = int(os.environ.get("BENCH_M", 3184))
 SHAPES = [("qkv", 3072, 1024, False), ("out", 1024, 1024, True), ("fc1", 4096, 1024, False), ("fc2", 1024, 4096, True)]
-TILES = [("auto", -1), ("128x128/4w", 0), ("128x64/4w", 5), ("128x128/8w", 4), ("128x256/8w", 6), ("256x128/8w", 2), ("8ph 256x256", 3)]
+TILES = [("auto", -1), ("128x128/4w", 0), ("128x64/4w", 5), ("8ph 256x256", 3)]
 
 
 def timeit(fn, reps=20):
@@ -47,11 +48,6 @@ def main():
             variants[tn] = f
         if resid:
             variants["LN alone"] = lambda: K.rownorm("fp16", x, ga, bias, out_f=False, out_h=True)
-            for S in (2, 4, 8):
-                if (Kk // 64) % S == 0:
-                    part = K.gemm_splitk("fp16", a, w, S)
-                    variants[f"splitK{S}"] = lambda S=S: K.gemm_splitk("fp16", a, w, S)
-                    variants[f"LN+{S}planes"] = lambda part=part: K.rownorm_splitk("fp16", x, part, bias, ga, bias)
         times = {k: [] for k in variants}
         for _ in range(5):
             for k, f in variants.items():
