@@ -32,20 +32,17 @@ SHAPES = [
     ("square 8192^3", "lin", (8192, 8192, 8192)),
 ]
 SETS = {
-    "tile": [("128x128", ("gemm_tile", 0)), ("256x128", ("gemm_tile", 2)), ("256x256", ("gemm_tile", 1))],
+    "tile": [("128x128", ("gemm_tile", 0)), ("256x256", ("gemm_tile", 1))],
     "8ph": [("128x128", ("gemm_tile", 0)), ("256x256 2-stage", ("gemm_tile", 1)), ("256x256 8-phase", ("gemm_tile", 3))],
-    "x32": [("8-phase 16x16x32", [("gemm_tile", 3), ("gemm_x32", 0)]), ("8-phase 32x32x16", [("gemm_tile", 3), ("gemm_x32", 1)]),
-            ("1 wave/SIMD 32x32x16", [("gemm_tile", 3), ("gemm_x32", 2)])],
-    "x32ln": [("16x16x32", ("gemm_x32", 0)), ("32x32x16", ("gemm_x32", 1)), ("1 wave/SIMD 32x32x16", ("gemm_x32", 2))],
-    "small": [("default", ("gemm_tile", -1)), ("128x128", ("gemm_tile", 0)), ("256x128", ("gemm_tile", 2)), ("8-phase 256x256", ("gemm_tile", 3))],
+    "small": [("default", ("gemm_tile", -1)), ("128x128", ("gemm_tile", 0)), ("128x64", ("gemm_tile", 5)), ("8-phase 256x256", ("gemm_tile", 3))],
     "split": [("single kernel", ("gemm_split", 0)), ("rounds + remainder", ("gemm_split", 1))],
     "map": [("map0", ("gemm_map", 0)), ("map1", ("gemm_map", 1)), ("map2", ("gemm_map", 2))],
     "nt": [("A default", ("gemm_a_nt", 0)), ("A nt", ("gemm_a_nt", 1))],
     "deep": [("2-stage", ("gemm_deep", 0)), ("8-phase", ("gemm_deep", 2))],
-    "epi": [("narrow stores", ("gemm_nodma", 16)), ("wide stores", ("gemm_nodma", 0))],
+    "epi": [("narrow stores", ("gemm_nodma", 16)), ("wide stores", ("gemm_nodma", 0))],  # attribution build only (AFX_LIB=.../libafx_attr.so)
 }
 VARIANTS = SETS[os.environ.get("BENCH_SET", "tile")]
-if os.environ.get("BENCH_SET") in ("nt", "deep", "x32ln"):  # the fused conv + LayerNorm kernel (row-complete tile)
+if os.environ.get("BENCH_SET") in ("nt", "deep"):  # the fused conv + LayerNorm kernel (row-complete tile)
     SHAPES = [("convln1 M=409536 K=1536", "convln", (B, 12799, 3, 2)), ("convln2 M=204736 K=1536", "convln", (B, 6399, 3, 2)),
               ("convln3 M=102336 K=1536", "convln", (B, 3199, 3, 2)), ("convln5 M=25536 K=1024", "convln", (B, 799, 2, 2))] + SHAPES[3:]
 
@@ -99,10 +96,9 @@ def main():
         print(f"{name:36s} {row}", flush=True)
     for key in ("gemm_tile", "gemm_map", "gemm_a_nt"):
         check(lib().afx_debug_set(key.encode(), -1))
-    check(lib().afx_debug_set(b"gemm_nodma", 0))
+    lib().afx_debug_set(b"gemm_nodma", 0)  # (refused by the product build: it has no such switch)
     check(lib().afx_debug_set(b"gemm_deep", -1))
     check(lib().afx_debug_set(b"gemm_split", 1))
-    check(lib().afx_debug_set(b"gemm_x32", 0))
 
 
 if __name__ == "__main__":
