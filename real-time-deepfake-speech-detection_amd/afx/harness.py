@@ -160,6 +160,56 @@ def produce_evaluation_file(dataset, model, device, save_path, batch_size, num_w
     return names, scores
 
 
+def checkpoint_comment(ckpt_path):
+    """main.py:265-266: the score-file suffix of a swept checkpoint = the last three '_'-separated fields of its path."""
+    parts = ckpt_path.split("_")
+    return parts[-3] + "_" + parts[-2] + "_" + parts[-1]
+
+
+def score_tracks(model, tracks, datasets, save_paths, device, batch_size, comment=None, num_workers=4, log=print):
+    """The track loop of main.py:406-451 (dup :296-371): for every requested track, in order -- skip it when its score
+    file already exists (":File existed, skip"), else build its dataset and call produce_evaluation_file.
+    ``datasets``: track -> zero-argument callable returning the Dataset (the reference constructs
+    ASVspoof2019LA_eval / ASVspoof2021DF_eval / ... there; datasets are the caller's, SURVEY 8 out of scope);
+    ``save_paths``: track -> score file ('.txt' gets ``_<comment>`` inserted as at main.py:398-404).  An 'InTheWild'
+    track without its own path uses the DF21 path with the track name substituted (main.py:440-441).  Returns
+    {track: path} of the files written."""
+    paths = dict(save_paths)
+    if comment is not None:
+        paths = {t: p.replace(".txt", f"_{comment}.txt") for t, p in paths.items()}
+    done = {}
+    for track in tracks:
+        if track not in paths and "DF21" in paths:
+            paths[track] = paths["DF21"].replace("DF21", track)
+        if track not in datasets or track not in paths:
+            raise ValueError(f"Track {track} not found.")
+        log(f"Evaluating {track}")
+        if os.path.exists(paths[track]):
+            log("File existed, skip")
+            continue
+        produce_evaluation_file(datasets[track](), model, device, paths[track], batch_size, num_workers=num_workers)
+        done[track] = paths[track]
+    return done
+
+
+def score_all_checkpoints(folder, build_model, tracks, datasets, save_paths, device, batch_size, num_workers=4, log=print):
+    """``--score_all_folder_path`` (main.py:258-371): every '*.pt*' file of ``folder`` is loaded into a fresh model the way
+    the reference does -- through a DataParallel-style 'module.' prefix (main.py:288-291, utils.py:13-43) -- and scored
+    on every track, the score files suffixed with the checkpoint's comment.  ``build_model()`` returns the model on
+    ``device``.  Returns {checkpoint: {track: path}}."""
+    out = {}
+    for name in sorted(n for n in os.listdir(folder) if ".pt" in n):
+        ckpt = os.path.join(folder, name)
+        model = build_model()
+        sd = torch.load(ckpt, map_location=device)
+        wrapped = f_state_dict_wrapper(sd, data_parallel=True)            # what DataParallel(model).load_state_dict sees
+        model.load_state_dict(f_state_dict_wrapper(wrapped, data_parallel=False))  # ... and model = model.module
+        log(f"Load checkpoint from {ckpt}")
+        out[ckpt] = score_tracks(model, tracks, datasets, save_paths, device, batch_size, comment=checkpoint_comment(ckpt),
+                                 num_workers=num_workers, log=log)
+    return out
+
+
 def evaluate(model, loader, device, loss_fn=None, preprocessor=None):
     """trainer.py:85-132: (mean loss, accuracy %) over a loader."""
     model.eval()

@@ -280,3 +280,49 @@ def test_checkpoint_loader_does_not_execute_pickled_callables(tmp_path):
     assert not marker.exists()
     own = trunk.state_dict()
     assert all(torch.equal(own[k], sd[k]) for k in own)
+
+
+def test_track_routing_and_checkpoint_sweep_like_main(tmp_path):
+    """main.py:258-371,406-451: track loop (skip existing score files, comment suffix, InTheWild path derived from
+    DF21's) and the --score_all_folder_path sweep (every *.pt, 'module.'-prefixed or not, comment from the file name)."""
+    from afx import harness
+
+    class Toy(torch.utils.data.Dataset):
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return f"u{i}", torch.full((4,), float(i)), 0
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(1))
+
+        def forward(self, x):
+            return torch.stack([-x[:, 0], x[:, 0] * self.w], dim=1)
+
+    built = []
+    datasets = {"LA19": lambda: built.append("LA19") or Toy(3), "DF21": lambda: built.append("DF21") or Toy(2),
+                "InTheWild": lambda: built.append("ITW") or Toy(1)}
+    paths = {"LA19": str(tmp_path / "LA19.txt"), "DF21": str(tmp_path / "DF21.txt")}
+    (tmp_path / "DF21_c1.txt").write_text("already there\n")
+    done = harness.score_tracks(Model(), ["LA19", "DF21", "InTheWild"], datasets, paths, "cpu", 2, comment="c1", num_workers=0, log=lambda *_: None)
+    assert built == ["LA19", "ITW"] and set(done) == {"LA19", "InTheWild"}  # DF21 skipped: its file existed
+    assert (tmp_path / "LA19_c1.txt").read_text() == "u0 0.0\nu1 1.0\nu2 2.0\n"
+    assert done["InTheWild"].endswith("InTheWild_c1.txt")
+    with pytest.raises(ValueError, match="not found"):
+        harness.score_tracks(Model(), ["XX"], datasets, paths, "cpu", 2, num_workers=0, log=lambda *_: None)
+    ck = tmp_path / "ckpts"
+    ck.mkdir()
+    torch.save({"module.w": torch.tensor([2.0])}, ck / "run_ep_3_acc_97.pt")   # saved from a DDP-wrapped model (main.py:176-179)
+    torch.save({"w": torch.tensor([3.0])}, ck / "run_ep_4_acc_98.pt")
+    (ck / "notes.md").write_text("not a checkpoint")
+    res = harness.score_all_checkpoints(str(ck), Model, ["LA19"], datasets, {"LA19": str(tmp_path / "s" / "LA19.txt")}, "cpu", 2,
+                                        num_workers=0, log=lambda *_: None)
+    assert len(res) == 2
+    assert (tmp_path / "s" / "LA19_3_acc_97.pt.txt").read_text().split("\n")[1] == "u1 2.0"
+    assert (tmp_path / "s" / "LA19_4_acc_98.pt.txt").read_text().split("\n")[1] == "u1 3.0"

@@ -369,3 +369,89 @@ class _FakeOtherDevice:
     """Stands for a tensor on another GPU (this box has one): only what Engine._on_device looks at."""
     is_cuda = True
     device = torch.device("cuda", 1)
+
+
+def test_kd_forward_hooks_by_module_path(afx_mod):
+    """trainer.py:156-195,263-270: ForwardHookManager.add_hook(model, module_path, requires_input, requires_output) +
+    pop_io_dict() on the drop-in modules (one native call, so the values come from the engine's taps) against the
+    oracle's intermediates at the same paths."""
+    engine, synth = afx_mod
+    from afx.kd import ForwardHookManager
+    from models.conformer_baseline import MyModel
+    from oracle import models as omodels
+    stu = MyModel(device="cuda", ssl_cpkt_path=None, num_layers=2, order="first", n_encoders=2).to("cuda").eval()
+    sd = synth.model_state_dict("ConformerModel", n_layers=2, n_encoders=2)
+    stu.load_state_dict(sd)
+    mgr = ForwardHookManager("cuda:0")
+    mgr.add_hook(stu, "ssl_model.model.encoder.layers.1", requires_input=True, requires_output=True)
+    mgr.add_hook(stu, "conformer.encoder_blocks.0", requires_input=False, requires_output=True)
+    mgr.add_hook(stu, "ssl_model", requires_input=False, requires_output=True)
+    with pytest.raises(AttributeError):
+        mgr.add_hook(stu, "no.such.module")
+    with pytest.raises(ValueError, match="no native tap"):
+        mgr.add_hook(stu, "first_bn")
+    wave = synth.waveforms(2, 16000, batch_idx=41)
+    with torch.no_grad():
+        out = stu(wave.cuda())
+    io = mgr.pop_io_dict()
+    assert mgr.pop_io_dict() == {}  # popped
+    taps = {}
+    ref = omodels.conformer_forward(sd, wave, taps=taps)
+    assert (out.cpu() - ref).abs().max().item() <= SCORE_TOL
+
+    def rel(a, b):
+        return ((a.cpu().reshape(-1) - b.reshape(-1)).norm() / b.norm()).item()
+    lay = io["ssl_model.model.encoder.layers.1"]
+    assert lay["input"].shape == (2, 49, 1024) and rel(lay["input"], taps["layer0"]) < 2e-3
+    assert rel(lay["output"], taps["layer1"]) < 2e-3
+    assert "input" not in io["conformer.encoder_blocks.0"]
+    assert io["conformer.encoder_blocks.0"]["output"].shape == (2, 50, 144) and rel(io["conformer.encoder_blocks.0"]["output"], taps["block0"]) < 3e-3
+    assert rel(io["ssl_model"]["output"], taps["ssl"]) < 2e-3
+    mgr.clear()
+    with torch.no_grad():
+        stu(wave.cuda())
+    assert mgr.pop_io_dict() == {}
+
+
+def test_checkpoint_files_through_the_gpu_path(afx_mod, tmp_path):
+    """SURVEY 8(f) row 3 end to end on the GPU: a fairseq-style ``xlsr2_300m.pt`` (config object of an absent package +
+    'model' state_dict with pre-training heads) is what ``ssl_cpkt_path`` points at (models/fe.py:11-14), a fine-tuned
+    checkpoint saved from a DDP-wrapped model ('module.' keys, main.py:176-179) is loaded the way main.py:98-103 /
+    :391-395 do, and the scores equal the oracle's on the same tensors."""
+    import sys
+    import types
+    engine, synth = afx_mod
+    from afx.harness import f_state_dict_wrapper
+    from models.xlsr_aasist import My_XLSR_AASIST
+    from oracle import models as omodels
+    # 1. an SSL checkpoint (all 24 layers, like xlsr2_300m.pt: My_XLSR_FE truncates AFTER loading, models/fe.py:63-74)
+    #    whose values differ from the seeded defaults, so that loading it matters
+    ssl = {k: v * 1.01 for k, v in synth.ssl_state_dict(24, prefix="").items()}
+    fake = types.ModuleType("fairseq_absent_pkg2")
+
+    class Cfg:
+        pass
+    Cfg.__module__, Cfg.__qualname__ = "fairseq_absent_pkg2", "Cfg"
+    fake.Cfg = Cfg
+    sys.modules["fairseq_absent_pkg2"] = fake
+    try:
+        path = tmp_path / "xlsr_like.pt"
+        torch.save({"cfg": Cfg(), "model": dict(ssl, **{"mask_emb": torch.zeros(1024), "final_proj.weight": torch.zeros(768, 1024)})}, path)
+    finally:
+        del sys.modules["fairseq_absent_pkg2"]
+    model = My_XLSR_AASIST(device="cuda", ssl_cpkt_path=str(path), num_layers=2, order="first").to("cuda").eval()
+    got_ssl = {k: v.detach().cpu() for k, v in model.ssl_model.model.state_dict().items()}
+    assert len(model.ssl_model.model.encoder.layers) == 2 and all(torch.equal(got_ssl[k], ssl[k]) for k in got_ssl)
+    # 2. a fine-tuned checkpoint of the whole (truncated) model, saved with the DDP prefix
+    full = {("ssl_model.model." + k): v for k, v in ssl.items() if k in got_ssl}
+    full.update(synth.aasist_head_state_dict())
+    ck = tmp_path / "finetuned_ep_1_acc_99.pt"
+    torch.save({"module." + k: v for k, v in full.items()}, ck)
+    wrapped = torch.nn.DataParallel(model)
+    wrapped.load_state_dict(f_state_dict_wrapper(torch.load(ck, map_location="cuda"), data_parallel=True))
+    model = wrapped.module
+    wave = synth.waveforms(3, 16000, batch_idx=17)
+    with torch.no_grad():
+        got = model(wave.cuda()).cpu()
+    ref = omodels.xlsr_aasist_forward(full, wave)
+    assert (got - ref).abs().max().item() <= SCORE_TOL
