@@ -630,9 +630,14 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
   }
   // ---- max-pool + BN + SELU into a 1-channel padded image ---------------------------
   float *X = ws.imgA, *Y = ws.imgB, *D = ws.imgC;
-  HOK(hipMemsetAsync(ws.imgA, 0, pixbytes * 64, s));
-  HOK(hipMemsetAsync(ws.imgB, 0, pixbytes * 64, s));
-  HOK(hipMemsetAsync(ws.imgC, 0, pixbytes * 64, s));
+  // Only what no kernel writes has to be zeroed: every conv stores ALL virtual pixels at rows [wp+1, M+wp+1) (zeros
+  // where they fall in the padding -- that re-creates the border), so of each image just the first padded row + 1
+  // pixel; rows past M+wp+1 are read by invalid (masked-by-assignment) outputs only.  (Round 1 cleared 3 x 12.8 MB
+  // per forward here.)
+  const size_t head_bytes = (size_t)(wp + 1) * 64 * 4;  // first padded row + 1 pixel, 64 channels
+  HOK(hipMemsetAsync(ws.imgA, 0, head_bytes, s));
+  HOK(hipMemsetAsync(ws.imgB, 0, head_bytes, s));
+  HOK(hipMemsetAsync(ws.imgC, 0, head_bytes, s));
   float* x1 = ws.wmap2;  // 1-channel image borrowed from a later buffer
   HOK(hipMemsetAsync(x1, 0, pixbytes, s));
   hipLaunchKernelGGL(pool_bn_selu_kernel, dim3((AAS_F * wd + 255) / 256, B), dim3(256), 0, s, ws.ll, T, wd, wp, img,
@@ -650,7 +655,6 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
     g.img = img; g.wp = wp; g.hout = AAS_F; g.wd = wd; g.out = X; g.ldo = K.cout; g.o_off = wp + 1;
     AOK(launch_f32_gemm(g, s));
   }
-  const size_t head_bytes = (size_t)(wp + 1) * 64 * 4;  // first padded row + 1 pixel, 64 channels
   for (int i = 1; i < 6; ++i) {
     const AasistWeights::Block& K = w.blk[i];
     if (K.cin != K.cout) {  // Y and D switch to the wider channel-last layout: re-zero their borders

@@ -75,7 +75,12 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
   if (MHSA_DBG & 2) return;
 
   const int ql = lane & 15, g = lane >> 4;
-  const int nqt = (T + 15) >> 4;
+  // gridDim.z splits the query tiles of one (utterance, head) over several workgroups (each stages K / V itself):
+  // at small batches B x H workgroups do not fill the chip (B = 16: 256 of them for 256 CUs x 2 slots)
+  const int nqt_all = (T + 15) >> 4;
+  const int per_z = (nqt_all + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int qt_first = (int)blockIdx.z * per_z;
+  const int nqt = min(nqt_all, qt_first + per_z);
   auto load_q = [&](int qt, V8 (&f)[2]) {
     int qrow = qt * 16 + ql;
     qrow = qrow < T ? qrow : T - 1;
@@ -83,8 +88,8 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
     for (int ks = 0; ks < 2; ++ks) f[ks] = *(const V8*)(base + (long)qrow * ld + ks * 32 + g * 8);
   };
   V8 qnext[2];
-  if (wave < nqt) load_q(wave, qnext);
-  for (int qt = wave; qt < nqt; qt += 4) {
+  if (qt_first + wave < nqt) load_q(qt_first + wave, qnext);
+  for (int qt = qt_first + wave; qt < nqt; qt += 4) {
     const int q0 = qt * 16;
     V8 qf[2] = {qnext[0], qnext[1]};
     if (qt + 4 < nqt) load_q(qt + 4, qnext);  // the next tile's Q rows are in flight under this tile's work
@@ -377,7 +382,8 @@ void mhsa_set_force_long(int v) { g_mhsa_force_long = v != 0; }
 template <class HT>
 static void launch_mhsa_t(const void* qkv, void* out, int B, int T, int H, float scale, hipStream_t s) {
   typedef typename HT::T Tt;
-  dim3 grid(H, B), blk(256);
+  // two workgroups fit a CU: below one full wave of them (B x H < 512), split each head's query tiles in two
+  dim3 grid(H, B, (long)H * B < 512 && T > 64 ? 2 : 1), blk(256);
   if (T > ATT_KEYS || g_mhsa_force_long)
     hipLaunchKernelGGL((mhsa_long_kernel<HT>), dim3(H, B, (T + 63) / 64), blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale);
   else if (T <= 64)

@@ -271,11 +271,10 @@ const char* launch_tile_crop(const float* x, const long long* offs, const long l
 // fp32 like torch.  Used for the conv-stack LayerNorm+GELU, every transformer /
 // Conformer LayerNorm and the final encoder LayerNorm.  HBM-bound.
 // ---------------------------------------------------------------------------------
-template <class HT>
+template <class HT, int RPW>  // RPW rows per wave: all their loads are in flight before any is reduced
 __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
   typedef typename HT::T T;
   typedef typename HT::V4 V4;
-  constexpr int RPW = 2;  // rows per wave: both rows' loads are in flight before either is reduced
   const int lane = threadIdx.x & 63;
   const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
   if (r0 >= a.rows) return;
@@ -359,8 +358,13 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
 const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
   if (a.rows <= 0 || a.C <= 0 || a.C > 1024 || a.C % 4) return "rownorm: need 0 < C <= 1024, C % 4 == 0";
   if (!a.out_f && !a.out_h) return "rownorm: no output";
-  dim3 grid((a.rows + 7) / 8);  // 4 waves x 2 rows
-  AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL(rownorm_kernel<HT>, grid, dim3(256), 0, s, a));
+  // two rows per wave once there are enough rows to keep 8+ waves on every CU; below that (the teacher's
+  // 16 x 199 rows) one row per wave = twice the waves in flight, which is what this latency-bound size lacks
+  if (a.rows >= 16384) {
+    AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL((rownorm_kernel<HT, 2>), dim3((a.rows + 7) / 8), dim3(256), 0, s, a));
+  } else {
+    AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL((rownorm_kernel<HT, 1>), dim3((a.rows + 3) / 4), dim3(256), 0, s, a));
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
