@@ -86,16 +86,34 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(F32GemmArgs p) {
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][s], a[mt][s], acc[mt][nt], 0, 0, 0);
   };
-  f32x4 a0[2], b0[NT], a1[2], b1[NT];
-  load(0, a0, b0);
-  for (int st = 0; st < nsteps; st += 2) {
-    if (st + 1 < nsteps) load(st + 1, a1, b1);
-    mfmas(a0, b0);
-    if (st + 1 < nsteps) {
-      if (st + 2 < nsteps) load(st + 2, a0, b0);
-      mfmas(a1, b1);
-    }
+  // Fragments are requested TWO k-steps ahead into three rotating register sets (12 loads = 2 x 1024 MFMA cycles in
+  // flight: an L2 hit under load takes about one of those).  Two things hipcc does to such a loop unless told otherwise,
+  // both seen in the ISA of earlier versions: (1) behind a branch that may or may not have issued loads its waitcnt
+  // pass assumes the worst at the join and emits vmcnt(0), which waits for the loads just issued -- so the steady state
+  // has no conditional load, the tail is peeled; (2) its scheduler sinks each load block down to its first use -- so
+  // every block sits between sched_barriers.  With both, the MFMAs wait with vmcnt(12).
+  f32x4 aA[2], bA[NT], aB[2], bB[NT], aC[2], bC[NT];
+#define AFX_SB() __builtin_amdgcn_sched_barrier(0)
+  load(0, aA, bA);
+  if (nsteps > 1) load(1, aB, bB);
+  int st = 0;
+  for (; st + 4 < nsteps; st += 3) {
+    load(st + 2, aC, bC); AFX_SB(); mfmas(aA, bA); AFX_SB();
+    load(st + 3, aA, bA); AFX_SB(); mfmas(aB, bB); AFX_SB();
+    load(st + 4, aB, bB); AFX_SB(); mfmas(aC, bC); AFX_SB();
   }
+  {  // tail: 1..4 steps left, set A holds step st, set B step st + 1
+    const int rem = nsteps - st;
+    if (rem >= 3) load(st + 2, aC, bC);
+    AFX_SB(); mfmas(aA, bA); AFX_SB();
+    if (rem >= 2) {
+      if (rem >= 4) load(st + 3, aA, bA);
+      AFX_SB(); mfmas(aB, bB); AFX_SB();
+    }
+    if (rem >= 3) mfmas(aC, bC);
+    if (rem >= 4) mfmas(aA, bA);
+  }
+#undef AFX_SB
   // operands swapped: lane holds out[m = .. + (lane&15)][n = n0 + 16nt + 4*(lane>>4) + 0..3]
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
