@@ -45,8 +45,7 @@ struct F32GemmArgs {
 
 // One wave = 32 rows x 16 NT columns; blockIdx.y walks column blocks of 16 NT (the launcher picks NT so that the grid
 // gives every SIMD of the chip at least one wave: the LL product, M = 16 x 199 rows, was 25 workgroups before).
-// Operand fragments come straight from L2 (a lane's 16 B of a row per k-step of 16: 6 loads per 32-64 MFMAs) and are
-// requested one k-step AHEAD into a second register set, so the loads' latency sits under the previous step's MFMAs.
+// Operand fragments come straight from L2 (a lane's 16 B of a row per k-step of 16: 6 loads per 32-64 MFMAs).
 template <int NT>
 __global__ __launch_bounds__(256) void f32_gemm_kernel(F32GemmArgs p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,52 +67,27 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(F32GemmArgs p) {
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int spc = p.kc >> 4, nsteps = p.nch * spc;  // k-steps of 16 per chunk, in all
-  auto load = [&](int st, f32x4 (&a)[2], f32x4 (&b)[NT]) {
-    const int ch = st / spc, k0 = (st - ch * spc) << 4;
-    const long ao = (long)ch * p.chunk_stride + k0, wo = (long)ch * p.kc + k0;
+  // (Measured and dropped, profiles/r02_aasist_gemm_prefetch_ab.txt: fragments one / two k-steps ahead in rotating
+  // register sets -- 38.2 / 42.8 us against 36.3 us for this plain loop on the (2,3) convs: two to four waves per SIMD
+  // already cover each other's L2 round trips, the extra registers only cost occupancy.)
+  for (int ch = 0; ch < p.nch; ++ch) {
+    const long ao = (long)ch * p.chunk_stride;
+    const long wo = (long)ch * p.kc;
+    for (int k0 = 0; k0 < p.kc; k0 += 16) {
+      f32x4 a[2], b[NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) a[mt] = *(const f32x4*)(arow[mt] + ao);
+      for (int mt = 0; mt < 2; ++mt) a[mt] = *(const f32x4*)(arow[mt] + ao + k0);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)(wrow + (long)nt * 16 * ldw + wo);
-  };
-  auto mfmas = [&](const f32x4 (&a)[2], const f32x4 (&b)[NT]) {
+      for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)(wrow + (long)nt * 16 * ldw + wo + k0);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][s], a[mt][s], acc[mt][nt], 0, 0, 0);
-  };
-  // Fragments are requested TWO k-steps ahead into three rotating register sets (12 loads = 2 x 1024 MFMA cycles in
-  // flight: an L2 hit under load takes about one of those).  Two things hipcc does to such a loop unless told otherwise,
-  // both seen in the ISA of earlier versions: (1) behind a branch that may or may not have issued loads its waitcnt
-  // pass assumes the worst at the join and emits vmcnt(0), which waits for the loads just issued -- so the steady state
-  // has no conditional load, the tail is peeled; (2) its scheduler sinks each load block down to its first use -- so
-  // every block sits between sched_barriers.  With both, the MFMAs wait with vmcnt(12).
-  f32x4 aA[2], bA[NT], aB[2], bB[NT], aC[2], bC[NT];
-#define AFX_SB() __builtin_amdgcn_sched_barrier(0)
-  load(0, aA, bA);
-  if (nsteps > 1) load(1, aB, bB);
-  int st = 0;
-  for (; st + 4 < nsteps; st += 3) {
-    load(st + 2, aC, bC); AFX_SB(); mfmas(aA, bA); AFX_SB();
-    load(st + 3, aA, bA); AFX_SB(); mfmas(aB, bB); AFX_SB();
-    load(st + 4, aB, bB); AFX_SB(); mfmas(aC, bC); AFX_SB();
-  }
-  {  // tail: 1..4 steps left, set A holds step st, set B step st + 1
-    const int rem = nsteps - st;
-    if (rem >= 3) load(st + 2, aC, bC);
-    AFX_SB(); mfmas(aA, bA); AFX_SB();
-    if (rem >= 2) {
-      if (rem >= 4) load(st + 3, aA, bA);
-      AFX_SB(); mfmas(aB, bB); AFX_SB();
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][s], a[mt][s], acc[mt][nt], 0, 0, 0);
     }
-    if (rem >= 3) mfmas(aC, bC);
-    if (rem >= 4) mfmas(aA, bA);
   }
-#undef AFX_SB
   // operands swapped: lane holds out[m = .. + (lane&15)][n = n0 + 16nt + 4*(lane>>4) + 0..3]
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
