@@ -76,6 +76,18 @@ int afx_forward(afx_handle h, const float* wave, int B, int L, float* logits, vo
 /* SSL features only: feats device (B,T,1024) fp32 == extract_feat() of models/fe.py:17-21 */
 int afx_ssl_forward(afx_handle h, const float* wave, int B, int L, float* feats, void* ws, size_t ws_bytes,
                     void* stream);
+/* Ragged batches (clips of different lengths in one call; the length policy of data/test_set.py:201-248 is what makes
+ * the reference's batches uniform -- un-cropped clips are the case it leaves to batch size 1).  wave: device (B,Lmax) fp32,
+ * row b holds clip b's n_samples[b] samples followed by ZEROS; n_samples: HOST int[B].  Each clip is scored exactly as if it
+ * were alone: key-padding masks in both attentions, zero padding past its own frames in the positional / depthwise convs,
+ * per-length sub-batches for the AASIST graphs.  logits (B,2).  Synchronises the stream once (length upload). */
+size_t afx_ragged_workspace_bytes(afx_handle h, int B, int Lmax);
+int afx_forward_ragged(afx_handle h, const float* wave, int B, int Lmax, const int* n_samples, float* logits, void* ws,
+                       size_t ws_bytes, void* stream);
+/* feats device (B,Tmax,1024) fp32 with Tmax = afx_num_frames(Lmax), rows past a clip's own frames zeroed;
+ * n_frames (HOST int[B], may be NULL) receives the frame counts */
+int afx_ssl_forward_ragged(afx_handle h, const float* wave, int B, int Lmax, const int* n_samples, float* feats,
+                           int* n_frames, void* ws, size_t ws_bytes, void* stream);
 /* The path from the OUTPUT OF CONV LAYER 5 on: conv5_h device (B,T5,512) in the operand type (fp16 / bf16; fp32 in exact
  * mode) -> conv layer 6, feature LayerNorm, projection, positional conv, transformer layers, head -> logits (B,2).
  * Same kernels in the same order as afx_forward from that point, so a caller that keeps conv layers 0-5 incrementally

@@ -41,6 +41,9 @@ SIGNATURES = {
     "afx_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
     "afx_ssl_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
     "afx_head_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
+    "afx_ragged_workspace_bytes": (_Z, [_P, _I, _I]),
+    "afx_forward_ragged": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int), _P, _P, _Z, _P]),
+    "afx_ssl_forward_ragged": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), _P, _Z, _P]),
     "afx_tail_workspace_bytes": (_Z, [_P, _I, _I]),
     "afx_tail_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
     "afx_enable_taps": (_I, [_P, _I]),

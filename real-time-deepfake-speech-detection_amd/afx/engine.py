@@ -139,6 +139,41 @@ class Engine:
             check(l.afx_head_forward(self._h, ptr(f), B, T, ptr(out), ptr(ws), ws.numel(), self._stream()))
         return out
 
+    # ---- ragged batches: clips of different lengths, each scored as if alone ----------------
+    def _pack_ragged(self, clips):
+        lens = [int(c.numel()) for c in clips]
+        if not lens or min(lens) < 400:
+            raise ValueError("every clip needs at least 400 samples (one SSL frame)")
+        batch = torch.zeros(len(clips), max(lens), dtype=torch.float32, device=self.device)
+        for b, c in enumerate(clips):  # plumbing: zero-padded rows
+            batch[b, : lens[b]] = c.reshape(-1).to(device=self.device, dtype=torch.float32)
+        return batch, (C.c_int * len(lens))(*lens), lens
+
+    def forward_ragged(self, clips):
+        """clips: list of 1-D waveforms of ANY lengths (>= 400 samples) -> logits (B,2); clip b's row equals
+        ``forward(clips[b][None])`` (key-padding masks, afx_forward_ragged)."""
+        batch, n, _ = self._pack_ragged(clips)
+        B, Lmax = batch.shape
+        l = lib()
+        with torch.cuda.device(self.device):
+            ws = self._workspace(l.afx_ragged_workspace_bytes(self._h, B, Lmax))
+            out = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+            check(l.afx_forward_ragged(self._h, ptr(batch), B, Lmax, n, ptr(out), ptr(ws), ws.numel(), self._stream()))
+        return out
+
+    def ssl_ragged(self, clips):
+        """-> (feats (B,Tmax,1024) with rows past each clip's frames zeroed, list of frame counts)."""
+        batch, n, _ = self._pack_ragged(clips)
+        B, Lmax = batch.shape
+        l = lib()
+        T = l.afx_num_frames(Lmax)
+        frames = (C.c_int * B)()
+        with torch.cuda.device(self.device):
+            ws = self._workspace(l.afx_ragged_workspace_bytes(self._h, B, Lmax))
+            buf = torch.empty(B, T, 1024, dtype=torch.float32, device=self.device)
+            check(l.afx_ssl_forward_ragged(self._h, ptr(batch), B, Lmax, n, ptr(buf), frames, ptr(ws), ws.numel(), self._stream()))
+        return buf, list(frames)
+
     def tail(self, conv5):
         """conv5: (B,T5,512) output of conv layer 5 in the operand type -> logits (B,2) (afx_tail_forward)."""
         self._on_device(conv5, "conv-layer-5 activations")

@@ -210,6 +210,29 @@ def score_all_checkpoints(folder, build_model, tracks, datasets, save_paths, dev
     return out
 
 
+def ragged_collate(batch):
+    """utils.py:102-106 (``my_collate``) for (utt_id, waveform, label) samples: lists, no stacking -- the clips keep
+    their own lengths."""
+    return [b[0] for b in batch], [b[1] for b in batch], [b[2] for b in batch]
+
+
+def produce_evaluation_file_ragged(dataset, model, device, save_path, batch_size, num_workers=4):
+    """main.py:199-221 for UN-CROPPED clips: batches of different lengths go through ``model.forward_ragged`` (each clip
+    scored exactly as if alone), one score line per utterance in dataset order."""
+    from torch.utils import data
+    model.eval()
+    names, chunks = [], []
+    loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=False, drop_last=False, num_workers=num_workers,
+                             collate_fn=ragged_collate)
+    with torch.no_grad():
+        for utt_id, clips, _label in loader:
+            chunks.append(model.forward_ragged([torch.as_tensor(c) for c in clips])[:, 1])
+            names.extend(utt_id)
+    scores = torch.cat(chunks).cpu().numpy().ravel().tolist() if chunks else []
+    write_score_file(save_path, names, scores)
+    return names, scores
+
+
 def evaluate(model, loader, device, loss_fn=None, preprocessor=None):
     """trainer.py:85-132: (mean loss, accuracy %) over a loader."""
     model.eval()

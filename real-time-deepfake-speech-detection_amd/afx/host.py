@@ -198,6 +198,14 @@ class AfxModule(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("input must be on the GPU: the native path has no CPU fallback")
 
+    def forward_ragged(self, clips):
+        """Score clips of different lengths in one native call, each exactly as ``self(clip[None])`` would
+        (key-padding masks; the reference reaches un-cropped clips only with batch size 1)."""
+        if self.training:
+            raise RuntimeError("the MI355X-native path is inference-only: call model.eval() first")
+        eng = self._afx_engine()
+        return eng.ssl_ragged(clips) if self.afx_arch == "ssl" else eng.forward_ragged(clips)
+
     def set_precision(self, dtype):
         """'fp16' (default) or 'bf16' matrix-core operands."""
         self.__dict__["afx_dtype"] = dtype

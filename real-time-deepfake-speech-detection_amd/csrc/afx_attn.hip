@@ -26,7 +26,8 @@ constexpr int ATT_VT_STRIDE = 232;  // halfs per V^T row: 464 B, conflict-free d
 
 template <class HT, int KS>  // KS = number of 32-key steps actually computed
 __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __restrict__ qkv,
-                                                   typename HT::T* __restrict__ out, int T, int H, float scale) {
+                                                   typename HT::T* __restrict__ out, int T, int H, float scale,
+                                                   const int* __restrict__ lens) {
   typedef typename HT::T Tt;
   typedef typename HT::V8 V8;
   typedef typename HT::V4 V4;
@@ -38,7 +39,11 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long ld = 3L * H * 64;
-  const Tt* base = qkv + (long)b * T * ld + h * 64;
+  // Ragged batch (key-padding mask): utterance b has lens[b] valid frames of the Trow rows it owns in memory; from
+  // here on T is ITS length -- keys beyond it are staged as zeros and masked, queries beyond it are not computed.
+  const int Trow = T;
+  if (lens) T = lens[b];
+  const Tt* base = qkv + (long)b * Trow * ld + h * 64;
   const Tt* kbase = base + (long)H * 64;
   const Tt* vbase = base + 2L * H * 64;
 
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
           hv[r] = (Tt)va[r];
           hv[4 + r] = (Tt)vb[r];
         }
-        *(V8*)(out + ((long)b * T + q) * (H * 64) + h * 64 + np * 32 + cb) = hv;
+        *(V8*)(out + ((long)b * Trow + q) * (H * 64) + h * 64 + np * 32 + cb) = hv;
       }
     }
   }
@@ -230,7 +235,8 @@ constexpr int ATTL_VT_STRIDE = 136;  // halfs per V^T row (68 words: conflict-fr
 
 template <class HT>
 __global__ __launch_bounds__(256, 2) void mhsa_long_kernel(const typename HT::T* __restrict__ qkv,
-                                                        typename HT::T* __restrict__ out, int T, int H, float scale) {
+                                                        typename HT::T* __restrict__ out, int T, int H, float scale,
+                                                        const int* __restrict__ lens) {
   typedef typename HT::T Tt;
   typedef typename HT::V8 V8;
   typedef typename HT::V4 V4;
@@ -240,7 +246,9 @@ __global__ __launch_bounds__(256, 2) void mhsa_long_kernel(const typename HT::T*
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long ld = 3L * H * 64;
-  const Tt* base = qkv + (long)b * T * ld + h * 64;
+  const int Trow = T;  // ragged batch: see mhsa_kernel
+  if (lens) T = lens[b];
+  const Tt* base = qkv + (long)b * Trow * ld + h * 64;
   const Tt* kbase = base + (long)H * 64;
   const Tt* vbase = base + 2L * H * 64;
   const int ql = lane & 15, g = lane >> 4;
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_long_kernel(const typename HT::T*
         hv[r] = (Tt)va[r];
         hv[4 + r] = (Tt)vb[r];
       }
-      *(V8*)(out + ((long)b * T + q) * (H * 64) + h * 64 + np * 32 + cb) = hv;
+      *(V8*)(out + ((long)b * Trow + q) * (H * 64) + h * 64 + np * 32 + cb) = hv;
     }
   }
 }
@@ -380,32 +388,32 @@ static int g_mhsa_force_long = 0;  // test knob: the blocked kernel at any lengt
 void mhsa_set_force_long(int v) { g_mhsa_force_long = v != 0; }
 
 template <class HT>
-static void launch_mhsa_t(const void* qkv, void* out, int B, int T, int H, float scale, hipStream_t s) {
+static void launch_mhsa_t(const void* qkv, void* out, int B, int T, int H, float scale, const int* lens, hipStream_t s) {
   typedef typename HT::T Tt;
   // two workgroups fit a CU: below one full wave of them (B x H < 512), split each head's query tiles in two
   dim3 grid(H, B, (long)H * B < 512 && T > 64 ? 2 : 1), blk(256);
   if (T > ATT_KEYS || g_mhsa_force_long)
-    hipLaunchKernelGGL((mhsa_long_kernel<HT>), dim3(H, B, (T + 63) / 64), blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale);
+    hipLaunchKernelGGL((mhsa_long_kernel<HT>), dim3(H, B, (T + 63) / 64), blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
   else if (T <= 64)
-    hipLaunchKernelGGL((mhsa_kernel<HT, 2>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale);
+    hipLaunchKernelGGL((mhsa_kernel<HT, 2>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
   else if (T <= 128)
-    hipLaunchKernelGGL((mhsa_kernel<HT, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale);
+    hipLaunchKernelGGL((mhsa_kernel<HT, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
   else
-    hipLaunchKernelGGL((mhsa_kernel<HT, 7>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale);
+    hipLaunchKernelGGL((mhsa_kernel<HT, 7>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
 }
 
-const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t s) {
+const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t s, const int* lens) {
   if (T <= 0 || B <= 0 || H <= 0) return "mhsa: bad shape";
   if (B > 65535 || (T + 63) / 64 > 65535) return "mhsa: batch / length beyond the launch grid";
   const float scale = 0.125f;  // 64^-0.5
   if (dtype == DT_FP32) {  // exact mode: fp32 VALU attention (afx_conformer.hip), q | k | v fp32 rows
     const float* f = (const float*)qkv;
-    return launch_conf_attn(f, 3L * H * 64, f + H * 64, 3L * H * 64, nullptr, 0, B, T, H, 64, out, (long)H * 64, DT_FP32, s);
+    return launch_conf_attn(f, 3L * H * 64, f + H * 64, 3L * H * 64, nullptr, 0, B, T, H, 64, out, (long)H * 64, DT_FP32, s, lens, 0);
   }
   if (dtype == DT_BF16)
-    launch_mhsa_t<BF16>(qkv, out, B, T, H, scale, s);
+    launch_mhsa_t<BF16>(qkv, out, B, T, H, scale, lens, s);
   else
-    launch_mhsa_t<FP16>(qkv, out, B, T, H, scale, s);
+    launch_mhsa_t<FP16>(qkv, out, B, T, H, scale, lens, s);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -47,9 +47,13 @@ template <int DH, class HT, bool REL>
 __global__ __launch_bounds__(256) void conf_attn_kernel(const float* __restrict__ q, long ldq,
                                                         const float* __restrict__ kv, long ldkv,
                                                         const float* __restrict__ rel, int max_pos, int N, int H,
-                                                        int KB, typename HT::T* __restrict__ out, long ldo) {
+                                                        int KB, typename HT::T* __restrict__ out, long ldo,
+                                                        const int* __restrict__ lens, int len_add) {
   typedef typename HT::T Tt;
   extern __shared__ __attribute__((aligned(16))) float sm_f[];
+  const int Nrow = N;  // ragged batch: utterance b owns Nrow rows in memory, lens[b] + len_add of them are tokens;
+  if (lens) N = lens[blockIdx.y] + len_add;  // from here on N is ITS token count (keys beyond are zeros and masked)
+
   // Keys go through LDS KB at a time (KB = N, one pass, whenever the sequence fits: 4-s clips; longer clips
   // -- test_duration_sec is a free config value, data/test_set.py -- take blocks of 64 keys and 256-query
   // chunks on blockIdx.z).  The running max / sum walk the keys in the same order either way, so the
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void conf_attn_kernel(const float* __restrict_
   const int i = i0 + (live ? tid : nq - 1);
   const float scale = 1.0f / sqrtf((float)DH);
   float qv[DH], o[DH];
-  const float* qrow = q + ((long)b * N + i) * ldq + h * DH;
+  const float* qrow = q + ((long)b * Nrow + i) * ldq + h * DH;
 #pragma unroll
   for (int d = 0; d < DH; d += 4) {
     const f32x4 t = *(const f32x4*)(qrow + d);
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void conf_attn_kernel(const float* __restrict_
     if (jb) __syncthreads();
     for (int idx = tid; idx < nk * (DH / 4); idx += 256) {
       const int j = idx / (DH / 4), d4 = idx % (DH / 4);
-      const float* row = kv + ((long)b * N + jb + j) * ldkv + h * DH + d4 * 4;
+      const float* row = kv + ((long)b * Nrow + jb + j) * ldkv + h * DH + d4 * 4;
       *(f32x4*)(Ks + j * DH + d4 * 4) = *(const f32x4*)row;
       *(f32x4*)(Vs + j * DH + d4 * 4) = *(const f32x4*)(row + inner);
     }
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256) void conf_attn_kernel(const float* __restrict_
   }
   if (!live) return;
   const float rl = 1.0f / l;
-  Tt* orow = out + ((long)b * N + i) * ldo + h * DH;
+  Tt* orow = out + ((long)b * Nrow + i) * ldo + h * DH;
 #pragma unroll
   for (int d = 0; d < DH; d += 4) {
     typename HT::V4 v4;
@@ -153,7 +157,8 @@ void conf_attn_set_block(int v) { g_conf_attn_block = v > 0 ? (v + 3) & ~3 : 0; 
 
 template <int DH, class HT, bool REL>
 static hipError_t launch_conf_attn_t(const float* q, long ldq, const float* kv, long ldkv, const float* rel,
-                                     int max_pos, int B, int N, int H, void* out, long ldo, hipStream_t s) {
+                                     int max_pos, int B, int N, int H, void* out, long ldo, hipStream_t s,
+                                     const int* lens, int len_add) {
   auto lds_of = [&](int kb) { return (int)((2L * kb + (REL ? min(256, N) + kb - 1 : 0)) * DH * sizeof(float)); };
   int KB = N;  // one pass when a 256-query workgroup sees the whole sequence and it fits
   if (g_conf_attn_block && g_conf_attn_block < N) KB = g_conf_attn_block;
@@ -162,20 +167,21 @@ static hipError_t launch_conf_attn_t(const float* q, long ldq, const float* kv, 
   static LdsLimit lim;  // sticky per device: raised only when a larger request arrives (graph-capture friendly)
   if (hipError_t e = lim.ensure((const void*)conf_attn_kernel<DH, HT, REL>, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((conf_attn_kernel<DH, HT, REL>), dim3(H, B, (N + 255) / 256), dim3(256), lds, s, q, ldq, kv, ldkv, rel,
-                     max_pos, N, H, KB, (typename HT::T*)out, ldo);
+                     max_pos, N, H, KB, (typename HT::T*)out, ldo, lens, len_add);
   return hipGetLastError();
 }
 
 const char* launch_conf_attn(const float* q, long ldq, const float* kv, long ldkv, const float* rel, int max_pos,
-                             int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s) {
+                             int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s,
+                             const int* lens, int len_add) {
   if (N <= 0 || B <= 0 || B > 65535) return "conf_attn: bad shape";
   if ((ldq % 4) || (ldkv % 4) || (ldo % 4)) return "conf_attn: row strides must be multiples of 4";
   hipError_t e = hipSuccess;
 #define AFX_CA(DHv)                                                                                             \
-  AFX_DISPATCH_HT(dtype, e = launch_conf_attn_t<DHv, HT, true>(q, ldq, kv, ldkv, rel, max_pos, B, N, H, out_h, ldo, s))
+  AFX_DISPATCH_HT(dtype, e = launch_conf_attn_t<DHv, HT, true>(q, ldq, kv, ldkv, rel, max_pos, B, N, H, out_h, ldo, s, lens, len_add))
   if (!rel) {  // plain attention (exact-mode trunk): fp32 in, fp32 out, head dim 64
     if (dh != 64 || dtype != DT_FP32) return "conf_attn: the no-relative-term form is the fp32 trunk attention (dh 64)";
-    e = launch_conf_attn_t<64, F32T, false>(q, ldq, kv, ldkv, nullptr, 0, B, N, H, out_h, ldo, s);
+    e = launch_conf_attn_t<64, F32T, false>(q, ldq, kv, ldkv, nullptr, 0, B, N, H, out_h, ldo, s, lens, len_add);
   }
   else if (dh == 36) { AFX_CA(36); }
   else if (dh == 32) { AFX_CA(32); }
@@ -207,10 +213,13 @@ template <class HT, int DH>
 __global__ __launch_bounds__(256) void conf_attn_mfma_kernel(const float* __restrict__ q, long ldq,
                                                              const float* __restrict__ kv, long ldkv,
                                                              const typename HT::T* __restrict__ rel_h, int max_pos,
-                                                             int N, int H, typename HT::T* __restrict__ out, long ldo) {
+                                                             int N, int H, typename HT::T* __restrict__ out, long ldo,
+                                                             const int* __restrict__ lens, int len_add) {
   typedef typename HT::T Tt;
   typedef typename HT::V8 V8;
   typedef typename HT::V4 V4;
+  const int Nrow = N;  // ragged batch: utterance b owns Nrow rows in memory, lens[b] + len_add of them are tokens;
+  if (lens) N = lens[blockIdx.y] + len_add;  // from here on N is ITS token count (keys beyond are zeros and masked)
   constexpr int DT = (DH + 15) / 16;  // 16-wide head-dim tiles of the output
   static_assert(DH % 4 == 0 && DH <= 64, "head dim");
   extern __shared__ __attribute__((aligned(16))) float sm_f[];
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(256) void conf_attn_mfma_kernel(const float* __rest
       const int idx = tid + it * 256;
       if (idx < N * (DH / 4)) {
         const int key = idx / (DH / 4), q4 = idx % (DH / 4);
-        const float* row = kv + ((long)b * N + key) * ldkv + h * DH + q4 * 4;
+        const float* row = kv + ((long)b * Nrow + key) * ldkv + h * DH + q4 * 4;
         kreg[it] = *(const f32x4*)row;
         vreg[it] = *(const f32x4*)(row + inner);
       }
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(256) void conf_attn_mfma_kernel(const float* __rest
     // Q fragments (scaled, operand type): k-slot (g, j) of step ks <-> head dim 32 ks + 8 g + j
     V8 qf[2];
     {
-      const float* qp = q + ((long)b * N + qrow) * ldq + h * DH;
+      const float* qp = q + ((long)b * Nrow + qrow) * ldq + h * DH;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(256) void conf_attn_mfma_kernel(const float* __rest
           V4 hv;
 #pragma unroll
           for (int c = 0; c < 4; ++c) hv[c] = (Tt)(o[nt][c] * rinv);
-          *(V4*)(out + ((long)b * N + qi) * ldo + h * DH + d) = hv;
+          *(V4*)(out + ((long)b * Nrow + qi) * ldo + h * DH + d) = hv;
         }
       }
     }
@@ -407,10 +416,13 @@ template <class HT, int DH>
 __global__ __launch_bounds__(256, 2) void conf_attn_mfma_long_kernel(const float* __restrict__ q, long ldq,
                                                                   const float* __restrict__ kv, long ldkv,
                                                                   const typename HT::T* __restrict__ rel_h, int max_pos,
-                                                                  int N, int H, typename HT::T* __restrict__ out, long ldo) {
+                                                                  int N, int H, typename HT::T* __restrict__ out, long ldo,
+                                                                  const int* __restrict__ lens, int len_add) {
   typedef typename HT::T Tt;
   typedef typename HT::V8 V8;
   typedef typename HT::V4 V4;
+  const int Nrow = N;  // ragged batch: utterance b owns Nrow rows in memory, lens[b] + len_add of them are tokens;
+  if (lens) N = lens[blockIdx.y] + len_add;  // from here on N is ITS token count (keys beyond are zeros and masked)
   constexpr int DT = (DH + 15) / 16;
   static_assert(DH % 4 == 0 && DH <= 64, "head dim");
   extern __shared__ __attribute__((aligned(16))) float sm_f[];
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void conf_attn_mfma_long_kernel(const float
   V8 qf[2];
   {
     const int qrow = q0 + ql < N ? q0 + ql : N - 1;
-    const float* qp = q + ((long)b * N + qrow) * ldq + h * DH;
+    const float* qp = q + ((long)b * Nrow + qrow) * ldq + h * DH;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -458,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void conf_attn_mfma_long_kernel(const float
         const int idx = tid + it * 256;
         if (idx < nk * (DH / 4)) {
           const int key = idx / (DH / 4), q4 = idx % (DH / 4);
-          const float* row = kv + ((long)b * N + j0 + key) * ldkv + h * DH + q4 * 4;
+          const float* row = kv + ((long)b * Nrow + j0 + key) * ldkv + h * DH + q4 * 4;
           kreg[it] = *(const f32x4*)row;
           vreg[it] = *(const f32x4*)(row + inner);
         }
@@ -571,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void conf_attn_mfma_long_kernel(const float
         V4 hv;
 #pragma unroll
         for (int c = 0; c < 4; ++c) hv[c] = (Tt)(o[nt][c] * rinv);
-        *(V4*)(out + ((long)b * N + qi) * ldo + h * DH + d) = hv;
+        *(V4*)(out + ((long)b * Nrow + qi) * ldo + h * DH + d) = hv;
       }
     }
   }
@@ -581,7 +593,8 @@ static int g_conf_attn_force_long = 0;  // test knob: the blocked kernel at ever
 void conf_attn_mfma_set_force_long(int v) { g_conf_attn_force_long = v != 0; }
 
 const char* launch_conf_attn_mfma(const float* q, long ldq, const float* kv, long ldkv, const void* rel_h, int max_pos,
-                                  int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s) {
+                                  int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s,
+                                  const int* lens, int len_add) {
   if (dh != 36) return "conf_attn_mfma: built for head dim 36 (emb 144 / 4 heads)";
   if (N <= 0 || B <= 0 || B > 65535) return "conf_attn_mfma: bad shape";
   if (dtype == DT_FP32) return "conf_attn_mfma: half-precision operands only";
@@ -596,12 +609,12 @@ const char* launch_conf_attn_mfma(const float* q, long ldq, const float* kv, lon
       el = liml[0].ensure((const void*)conf_attn_mfma_long_kernel<BF16, 36>, ldsl);
       if (el == hipSuccess)
         hipLaunchKernelGGL((conf_attn_mfma_long_kernel<BF16, 36>), grid, dim3(256), ldsl, s, q, ldq, kv, ldkv, (const __bf16*)rel_h,
-                           max_pos, N, H, (__bf16*)out_h, ldo);
+                           max_pos, N, H, (__bf16*)out_h, ldo, lens, len_add);
     } else {
       el = liml[1].ensure((const void*)conf_attn_mfma_long_kernel<FP16, 36>, ldsl);
       if (el == hipSuccess)
         hipLaunchKernelGGL((conf_attn_mfma_long_kernel<FP16, 36>), grid, dim3(256), ldsl, s, q, ldq, kv, ldkv, (const _Float16*)rel_h,
-                           max_pos, N, H, (_Float16*)out_h, ldo);
+                           max_pos, N, H, (_Float16*)out_h, ldo, lens, len_add);
     }
     if (el == hipSuccess) el = hipGetLastError();
     return el == hipSuccess ? nullptr : hipGetErrorString(el);
@@ -613,12 +626,12 @@ const char* launch_conf_attn_mfma(const float* q, long ldq, const float* kv, lon
     e = lim[0].ensure((const void*)conf_attn_mfma_kernel<BF16, 36>, lds);
     if (e == hipSuccess)
       hipLaunchKernelGGL((conf_attn_mfma_kernel<BF16, 36>), dim3(H, B), dim3(256), lds, s, q, ldq, kv, ldkv, (const __bf16*)rel_h,
-                         max_pos, N, H, (__bf16*)out_h, ldo);
+                         max_pos, N, H, (__bf16*)out_h, ldo, lens, len_add);
   } else {
     e = lim[1].ensure((const void*)conf_attn_mfma_kernel<FP16, 36>, lds);
     if (e == hipSuccess)
       hipLaunchKernelGGL((conf_attn_mfma_kernel<FP16, 36>), dim3(H, B), dim3(256), lds, s, q, ldq, kv, ldkv, (const _Float16*)rel_h,
-                         max_pos, N, H, (_Float16*)out_h, ldo);
+                         max_pos, N, H, (_Float16*)out_h, ldo, lens, len_add);
   }
   if (e == hipSuccess) e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
@@ -635,8 +648,11 @@ __global__ __launch_bounds__(256) void conf_dwconv_kernel(const float* __restric
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           const float* __restrict__ bn_scale,
                                                           const float* __restrict__ bn_shift, int N, int NC, int C, int k,
-                                                          typename HT::T* __restrict__ out, long ldo) {
+                                                          typename HT::T* __restrict__ out, long ldo,
+                                                          const int* __restrict__ lens, int len_add) {
   typedef typename HT::T Tt;
+  const int Nrow = N;  // ragged batch: utterance b owns Nrow rows in memory, lens[b] + len_add of them are tokens;
+  if (lens) N = lens[blockIdx.y] + len_add;  // from here on N is ITS token count (keys beyond are zeros and masked)
   constexpr bool EXACT = sizeof(Tt) == 4;  // fp32 "exact mode": accurate exp / division
   constexpr int KMAX = 31, TB = 8;         // taps held in registers; outputs per register window
   extern __shared__ __attribute__((aligned(16))) float sm_f[];
@@ -655,7 +671,7 @@ __global__ __launch_bounds__(256) void conf_dwconv_kernel(const float* __restric
     const int t = f0 + r - pl;
     float u = 0.f;
     if (cok && t >= 0 && t < N) {
-      const float* row = x + ((long)b * N + t) * ldx;
+      const float* row = x + ((long)b * Nrow + t) * ldx;
       u = row[c] * (EXACT ? sigmoid_acc(row[C + c]) : sigmoid_fast(row[C + c]));
     }
     us[r * 32 + cl] = u;
@@ -686,7 +702,7 @@ __global__ __launch_bounds__(256) void conf_dwconv_kernel(const float* __restric
 #pragma unroll
       for (int u = 0; u < TB; ++u) {
         const float y = fmaf(acc[u], sc, sh);
-        if (t0 + u < t_end) out[((long)b * N + f0 + t0 + u) * ldo + c] = (Tt)(EXACT ? swish(y) : swish_fast(y));
+        if (t0 + u < t_end) out[((long)b * Nrow + f0 + t0 + u) * ldo + c] = (Tt)(EXACT ? swish(y) : swish_fast(y));
       }
     }
   }
@@ -694,7 +710,7 @@ __global__ __launch_bounds__(256) void conf_dwconv_kernel(const float* __restric
 
 const char* launch_conf_dwconv(const float* x, long ldx, const float* w, const float* bias, const float* bn_scale,
                                const float* bn_shift, int B, int N, int C, int k, void* out_h, long ldo, int dtype,
-                               hipStream_t s) {
+                               hipStream_t s, const int* lens, int len_add) {
   if (k > 31) return "conf_dwconv: depthwise kernels up to 31 taps";
   if (N <= 0 || B <= 0 || B > 65535) return "conf_dwconv: bad shape";
   const int NC = N < 1024 ? N : 1024;
@@ -707,7 +723,7 @@ const char* launch_conf_dwconv(const float* x, long ldx, const float* w, const f
     e = lim[dtype].ensure((const void*)conf_dwconv_kernel<HT>, lds);
     if (e == hipSuccess)
       hipLaunchKernelGGL(conf_dwconv_kernel<HT>, grid, dim3(256), lds, s, x, ldx, w, bias, bn_scale, bn_shift, N, NC, C, k,
-                         (HT::T*)out_h, ldo);
+                         (HT::T*)out_h, ldo, lens, len_add);
   });
   if (e == hipSuccess) e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);

@@ -513,6 +513,10 @@ struct Ws {
   int T[7];
   void *bufA, *bufB, *feats_h, *xpad, *hbuf, *qkv, *att, *ff, *ssl_h;
   float *tmp32, *x, *ssl_f;
+  // ragged batch (afx_forward_ragged): valid SSL frames per utterance on the device (null = uniform batch), and the
+  // AASIST bucket buffers (utterances of equal length gathered into a uniform sub-batch for the graph back-end)
+  int* lens = nullptr;
+  float *bucket_f = nullptr, *bucket_logits = nullptr;
   // Conformer
   float *ll32, *xc, *qkv32, *glu32;
   void *hc, *hid, *ao, *u;
@@ -522,10 +526,12 @@ struct Ws {
 
 // Three entry shapes share one walk: the whole path (L > 0 samples), the path from the output of conv layer 5
 // (T5 > 0 frames: afx_tail_forward, the streaming mode's per-hop call), the head alone (Tfeat SSL frames).
-static size_t carve(const afx_engine* e, int B, int L, int Tfeat, void* base, Ws* w, int T5 = 0) {
+static size_t carve(const afx_engine* e, int B, int L, int Tfeat, void* base, Ws* w, int T5 = 0, bool ragged = false) {
   Carver c(base);
   const size_t hs = dtype_size(e->dt);
   int T = Tfeat;
+  w->lens = nullptr;
+  w->bucket_f = w->bucket_logits = nullptr;
   if (L > 0 || T5 > 0) {
     if (L > 0) {
       conv_lengths(L, w->T);
@@ -551,6 +557,13 @@ static size_t carve(const afx_engine* e, int B, int L, int Tfeat, void* base, Ws
   }
   w->ssl_f = (float*)c.take((size_t)B * T * kD * 4);
   w->ssl_h = c.take((size_t)B * T * kD * hs);
+  if (ragged) {
+    w->lens = (int*)c.take((size_t)B * 4);
+    if (e->cfg.arch == AFX_ARCH_XLSR_AASIST) {
+      w->bucket_f = (float*)c.take((size_t)B * T * kD * 4);
+      w->bucket_logits = (float*)c.take((size_t)B * 2 * 4);
+    }
+  }
   if (e->cfg.arch == AFX_ARCH_CONFORMER) {
     const size_t M = (size_t)B * (T + 1);
     w->ll32 = (float*)c.take((size_t)B * T * e->E * 4);
@@ -800,11 +813,13 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     g.out_f = w.x; g.ldo_f = kD; g.o_batch_rows = Tt; g.o_row_off = 0;
     g.out_h = w.xpad; g.ldo_h = kD; g.oh_batch_rows = Tt + kPosK; g.oh_row_off = kPosPad;
     KOK(launch_gemm(g, dt, 1, s));
-    KOK(timed(PC_MISC, 0, s, [&] { return launch_zero_pad_rows(w.xpad, B, Tt, kD, kPosPad, kPosK - kPosPad, dt, s); }));
+    // (ragged batch: the frames past an utterance's own length are zeroed too -- alone, its positional conv would
+    // see zero padding there)
+    KOK(timed(PC_MISC, 0, s, [&] { return launch_zero_pad_rows(w.xpad, B, Tt, kD, kPosPad, kPosK - kPosPad, dt, s, w.lens); }));
   }
   if (tap(e, "proj", w.x, (size_t)M * kD, false, s)) return 1;
   // positional conv (grouped, k=128) + GELU, added to x in place
-  if (g_posconv_sliding && dt != DT_FP32 && Tt <= 224) {
+  if (g_posconv_sliding && dt != DT_FP32 && Tt <= 224) {  // (reads the zero-padded operand copy: ragged batches need nothing more)
     PosConvArgs pc;
     memset(&pc, 0, sizeof pc);
     pc.xpad = w.xpad; pc.xpad_batch = (long)(Tt + kPosK) * kD; pc.W = e->posw; pc.bias = e->F("ssl.encoder.pos_conv.0.bias");
@@ -838,7 +853,7 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     q.bias = e->bqkv[l];
     q.out_h = w.qkv; q.ldo_h = 3 * kD;
     KOK(launch_gemm(q, dt, 1, s));
-    KOK(timed(PC_MHSA, 4.0 * B * kH * (double)Tt * Tt * 64, s, [&] { return launch_mhsa(w.qkv, w.att, B, Tt, kH, dt, s); }));
+    KOK(timed(PC_MHSA, 4.0 * B * kH * (double)Tt * Tt * 64, s, [&] { return launch_mhsa(w.qkv, w.att, B, Tt, kH, dt, s, w.lens); }));
     KOK(resid_product(w.att, kD, e->wo[l], kD, e->F(P + "self_attn.out_proj.bias")));
     RowNormArgs n2 = plain_norm(w.x, kD, M, kD, e->F(P + "final_layer_norm.weight"), e->F(P + "final_layer_norm.bias"));
     n2.out_h = w.hbuf; n2.ldo_h = kD;
@@ -902,9 +917,9 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     KOK(timed(PC_CONF_ATTN, 6.0 * B * e->heads * (double)N * N * e->dh, s, [&] {
       if (g_conf_attn_mfma && dt != DT_FP32 && e->dh == 36)
         return launch_conf_attn_mfma(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner, K.rel_h, 512, B, N, e->heads,
-                                     e->dh, w.ao, Ep, dt, s);
+                                     e->dh, w.ao, Ep, dt, s, w.lens, 1);
       return launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
-                              e->F(P + "attn.fn.rel_pos_emb.weight"), 512, B, N, e->heads, e->dh, w.ao, Ep, dt, s);
+                              e->F(P + "attn.fn.rel_pos_emb.weight"), 512, B, N, e->heads, e->dh, w.ao, Ep, dt, s, w.lens, 1);
     }));
     c.in_h = w.ao; c.ld_in_h = Ep;
     c.params = K.chain_prm[1];
@@ -915,7 +930,7 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     KOK(timed(PC_CONF_DWCONV, 2.0 * B * N * e->C2 * e->ck, s, [&] {
       return launch_conf_dwconv(w.glu32, 2 * e->C2, e->F(P + "conv.net.4.conv.weight"),
                                 e->F(P + "conv.net.4.conv.bias"), K.bn_scale, K.bn_shift, B, N, e->C2, e->ck, w.u,
-                                e->C2p, dt, s);
+                                e->C2p, dt, s, w.lens, 1);
     }));
     c.in_h = w.u; c.ld_in_h = e->C2p;
     c.params = K.chain_prm[2];
@@ -959,9 +974,9 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     KOK(timed(PC_CONF_ATTN, 6.0 * B * e->heads * (double)N * N * e->dh, s, [&] {
       if (g_conf_attn_mfma && dt != DT_FP32 && e->dh == 36)
         return launch_conf_attn_mfma(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner, K.rel_h, 512, B, N, e->heads,
-                                     e->dh, w.ao, Ep, dt, s);
+                                     e->dh, w.ao, Ep, dt, s, w.lens, 1);
       return launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
-                              e->F(P + "attn.fn.rel_pos_emb.weight"), 512, B, N, e->heads, e->dh, w.ao, Ep, dt, s);
+                              e->F(P + "attn.fn.rel_pos_emb.weight"), 512, B, N, e->heads, e->dh, w.ao, Ep, dt, s, w.lens, 1);
     }));
     GemmArgs o = plain_gemm(w.ao, Ep, K.wout, Ep, M, E, Ep);
     o.k_algo = e->inner;
@@ -978,7 +993,7 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     KOK(timed(PC_CONF_DWCONV, 2.0 * B * N * e->C2 * e->ck, s, [&] {
       return launch_conf_dwconv(w.glu32, 2 * e->C2, e->F(P + "conv.net.4.conv.weight"),
                                 e->F(P + "conv.net.4.conv.bias"), K.bn_scale, K.bn_shift, B, N, e->C2, e->ck, w.u,
-                                e->C2p, dt, s);
+                                e->C2p, dt, s, w.lens, 1);
     }));
     GemmArgs p2 = plain_gemm(w.u, e->C2p, K.pw2, e->C2p, M, E, e->C2p);
     p2.k_algo = e->C2;
@@ -1060,6 +1075,95 @@ extern "C" int afx_tail_forward(afx_handle h, const void* conv5_h, int B, int T5
   t_prof = h->prof;
   if (run_trunk(h, nullptr, B, 0, w, s, conv5_h)) return 1;
   return run_head(h, B, w.T[6], w, logits, s);
+}
+
+// ---------------------------------------------------------------------------------
+// ragged batches: clips of different lengths in ONE forward, each scored exactly as if alone.
+// The conv stack is local and unpadded, so frame t of a clip depends on its first 400 + 320 t samples only: a clip
+// zero-padded to the batch's longest gives its own T_b frames unchanged, followed by frames nobody may look at.
+// "Nobody looks" = key-padding masks (attention keys beyond T_b staged as zeros and masked to -1e30: they contribute
+// exactly 0), zeros in the positional conv's operand copy and in the depthwise conv's input beyond T_b, and the
+// class token / logits taken per utterance.  Everything else on the path is row-local.  The AASIST graph back-end has
+// per-utterance graph sizes (T_b / 3 temporal nodes): it runs once per distinct length on the gathered sub-batch.
+// ---------------------------------------------------------------------------------
+static int ragged_setup(afx_engine* h, int B, int Lmax, const int* n_samples, Ws& w, std::vector<int>& frames, hipStream_t s) {
+  frames.resize(B);
+  for (int b = 0; b < B; ++b) {
+    if (n_samples[b] > Lmax) return fail("afx_forward_ragged: clip %d has %d samples, the batch rows hold %d", b, n_samples[b], Lmax);
+    int T[7];
+    conv_lengths(n_samples[b], T);
+    if (T[6] < 1) return fail("afx_forward_ragged: clip %d has %d samples, too few for one output frame (need >= 400)", b, n_samples[b]);
+    frames[b] = T[6];
+  }
+  HIP_OK(hipMemcpyAsync(w.lens, frames.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+  HIP_OK(hipStreamSynchronize(s));  // `frames` is pageable host memory: the copy must have read it before it dies
+  return 0;
+}
+
+extern "C" size_t afx_ragged_workspace_bytes(afx_handle h, int B, int Lmax) {
+  if (!h || B <= 0 || Lmax <= 0) return 0;
+  Ws w;
+  return carve(h, B, Lmax, 0, nullptr, &w, 0, true);
+}
+
+extern "C" int afx_forward_ragged(afx_handle h, const float* wave, int B, int Lmax, const int* n_samples, float* logits,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  if (check_call(h, wave, B, Lmax, logits, ws)) return 1;
+  if (!n_samples) return fail("afx_forward_ragged: null lengths");
+  if (h->cfg.arch == AFX_ARCH_SSL) return fail("afx_forward_ragged: this handle is an SSL feature extractor; use afx_ssl_forward_ragged");
+  if (h->cfg.pre_emphasis) return fail("afx_forward_ragged: engine-side pre-emphasis is not supported on ragged batches");
+  Ws w;
+  const size_t needb = carve(h, B, Lmax, 0, ws, &w, 0, true);
+  if (ws_bytes < needb) return fail("afx_forward_ragged: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<int> frames;
+  if (ragged_setup(h, B, Lmax, n_samples, w, frames, s)) return 1;
+  t_prof = h->prof;
+  if (run_trunk(h, wave, B, Lmax, w, s)) return 1;
+  const int Tmax = w.T[6];
+  if (h->cfg.arch == AFX_ARCH_CONFORMER) return run_head(h, B, Tmax, w, logits, s);
+  // AASIST: one uniform sub-batch per distinct length
+  std::vector<char> done(B, 0);
+  for (int b0 = 0; b0 < B; ++b0) {
+    if (done[b0]) continue;
+    const int t = frames[b0];
+    std::vector<int> idx;
+    for (int b = b0; b < B; ++b)
+      if (!done[b] && frames[b] == t) { idx.push_back(b); done[b] = 1; }
+    const int nb = (int)idx.size();
+    for (int k = 0; k < nb; ++k)
+      HIP_OK(hipMemcpyAsync(w.bucket_f + (size_t)k * t * kD, w.ssl_f + (size_t)idx[k] * Tmax * kD, (size_t)t * kD * 4,
+                            hipMemcpyDeviceToDevice, s));
+    if (const char* m = aasist_forward(h->aw, w.bucket_f, nb, t, w.aa, w.bucket_logits, s)) return fail("%s", m);
+    for (int k = 0; k < nb; ++k)
+      HIP_OK(hipMemcpyAsync(logits + (size_t)idx[k] * 2, w.bucket_logits + (size_t)k * 2, 8, hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
+}
+
+// feats: device (B,Tmax,1024) fp32, rows past an utterance's own frame count are zeroed; n_frames (host int[B], may be
+// null) receives the frame counts
+extern "C" int afx_ssl_forward_ragged(afx_handle h, const float* wave, int B, int Lmax, const int* n_samples, float* feats,
+                                      int* n_frames, void* ws, size_t ws_bytes, void* stream) {
+  if (check_call(h, wave, B, Lmax, feats, ws)) return 1;
+  if (!n_samples) return fail("afx_ssl_forward_ragged: null lengths");
+  if (h->cfg.pre_emphasis) return fail("afx_ssl_forward_ragged: engine-side pre-emphasis is not supported on ragged batches");
+  Ws w;
+  const size_t needb = carve(h, B, Lmax, 0, ws, &w, 0, true);
+  if (ws_bytes < needb) return fail("afx_ssl_forward_ragged: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<int> frames;
+  if (ragged_setup(h, B, Lmax, n_samples, w, frames, s)) return 1;
+  t_prof = h->prof;
+  if (run_trunk(h, wave, B, Lmax, w, s)) return 1;
+  const int Tmax = w.T[6];
+  HIP_OK(hipMemcpyAsync(feats, w.ssl_f, (size_t)B * Tmax * kD * 4, hipMemcpyDeviceToDevice, s));
+  for (int b = 0; b < B; ++b) {
+    if (frames[b] < Tmax)
+      HIP_OK(hipMemsetAsync(feats + ((size_t)b * Tmax + frames[b]) * kD, 0, (size_t)(Tmax - frames[b]) * kD * 4, s));
+    if (n_frames) n_frames[b] = frames[b];
+  }
+  return 0;
 }
 
 extern "C" int afx_ssl_forward(afx_handle h, const float* wave, int B, int L, float* feats, void* ws, size_t ws_bytes,

@@ -373,22 +373,23 @@ const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
 // zero the time-padding rows of the positional-conv operand buffer (B, pf+T+pb, C)
 // ---------------------------------------------------------------------------------
 // (C counts 2-byte units: an fp32 buffer passes 2 x its channel count)
-__global__ void zero_pad_rows_kernel(uint16_t* buf, int T, int C, int pf, int pb) {
+__global__ void zero_pad_rows_kernel(uint16_t* buf, int T, int C, int pf, int pb, const int* __restrict__ lens) {
   const int b = blockIdx.y;
-  const int rows = pf + pb;
+  const int keep = lens ? lens[b] : T;  // ragged batch: the frames past this utterance's own length count as padding
+  const int rows = pf + pb + (T - keep);
   const long per = (long)(pf + T + pb) * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)rows * C / 8; i += (long)gridDim.x * blockDim.x) {
     const long e = i * 8;
     int r = (int)(e / C);
     const int c = (int)(e % C);
-    if (r >= pf) r += T;
+    if (r >= pf) r += keep;
     *(u32x4*)(buf + b * per + (long)r * C + c) = u32x4{0u, 0u, 0u, 0u};
   }
 }
-const char* launch_zero_pad_rows(void* buf_h, int B, int T, int C, int pf, int pb, int dtype, hipStream_t s) {
+const char* launch_zero_pad_rows(void* buf_h, int B, int T, int C, int pf, int pb, int dtype, hipStream_t s, const int* lens) {
   if (C % 8) return "zero_pad_rows: C % 8 != 0";
   if (dtype == DT_FP32) C *= 2;
-  hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(32, B), dim3(256), 0, s, (uint16_t*)buf_h, T, C, pf, pb);
+  hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(32, B), dim3(256), 0, s, (uint16_t*)buf_h, T, C, pf, pb, lens);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

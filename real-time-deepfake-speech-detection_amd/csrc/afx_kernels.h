@@ -91,8 +91,9 @@ struct RowNormArgs {
 };
 const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s);
 // zero the time padding rows of the positional-conv operand buffer (B, T+128, C)
+// (lens: ragged batch -- rows [pad_front + lens[b], end) of utterance b are zeroed as well)
 const char* launch_zero_pad_rows(void* buf_h, int B, int T, int C, int pad_front, int pad_back, int dtype,
-                                 hipStream_t s);
+                                 hipStream_t s, const int* lens = nullptr);
 // fp32 -> operand type conversion with optional layout permutes (weight packing)
 const char* launch_pack_linear(const float* w, int N, int K, int Kpad, void* out_h, int dtype, hipStream_t s);
 const char* launch_pack_conv(const float* w, int N, int Cin, int k, void* out_h, int dtype, hipStream_t s);
@@ -113,7 +114,8 @@ const char* launch_posconv(const PosConvArgs& p, int dtype, hipStream_t s);
 
 // ---- transformer self-attention (afx_attn.hip) -----------------------------------
 // qkv: (B*T, 3*H*64) operand type [q | k | v]; out: (B*T, H*64) operand type.
-const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t s);
+// lens (device int32[B], or null): ragged batch -- utterance b has lens[b] valid frames of its T rows (key-padding mask)
+const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t s, const int* lens = nullptr);
 
 // ---- Conformer student head (afx_conformer.hip) ----------------------------------
 // y = selu(bn(x)) for rows 1..T of each utterance, row 0 = class token; x is the LL
@@ -123,15 +125,17 @@ const char* launch_conf_tokens(const float* ll, const float* cls, float bn_scale
 // Shaw relative-position attention; q (B*N, H*dh) fp32, kv (B*N, 2*H*dh) fp32,
 // rel (2*max_pos+1, dh) fp32; out operand-type rows of stride ldo.
 const char* launch_conf_attn(const float* q, long ldq, const float* kv, long ldkv, const float* rel, int max_pos,
-                             int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s);
+                             int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s,
+                             const int* lens = nullptr, int len_add = 0);  // ragged: tokens of utterance b = lens[b] + len_add
 // the same on the matrix cores: rel_h is the embedding table in operand type, rows padded to 64
 // (pack_linear with Kpad = 64); N <= 209 tokens, head dim 36
 const char* launch_conf_attn_mfma(const float* q, long ldq, const float* kv, long ldkv, const void* rel_h, int max_pos,
-                                  int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s);
+                                  int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s,
+                                  const int* lens = nullptr, int len_add = 0);
 // GLU -> depthwise conv (same pad) -> BatchNorm(eval) -> Swish.  x (B*N, 2*C) fp32.
 const char* launch_conf_dwconv(const float* x, long ldx, const float* w /*[C][k]*/, const float* bias,
                                const float* bn_scale, const float* bn_shift, int B, int N, int C, int k,
-                               void* out_h, long ldo, int dtype, hipStream_t s);
+                               void* out_h, long ldo, int dtype, hipStream_t s, const int* lens = nullptr, int len_add = 0);
 // Row-local chains of a Conformer block, 16 token rows per wave, registers only
 // (afx_conformer_fused.hip).  stage 0: x += 1/2 FF1(x), out2 = W_a LN2(x) (q|k|v, no bias);
 // stage 1: x += W_a in_h + b_a, out2 = W_b LN2(x) + b_b (pointwise conv 1, GLU input);

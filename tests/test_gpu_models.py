@@ -455,3 +455,62 @@ def test_checkpoint_files_through_the_gpu_path(afx_mod, tmp_path):
         got = model(wave.cuda()).cpu()
     ref = omodels.xlsr_aasist_forward(full, wave)
     assert (got - ref).abs().max().item() <= SCORE_TOL
+
+
+@pytest.mark.parametrize("arch", ["conformer", "xlsr_aasist"])
+def test_ragged_batch_scores_each_clip_as_if_alone(afx_mod, arch, tmp_path):
+    """SURVEY 8(f) row 1, second half: clips of different lengths in ONE forward (afx_forward_ragged: key-padding masks
+    in both attentions, zero padding past a clip's own frames in the positional / depthwise convs, per-length AASIST
+    sub-batches).  Every clip's logits must equal what the same engine gives for that clip alone -- bit for bit: a
+    masked key contributes exactly 0 -- and match the CPU oracle on the clip alone within the score tolerance."""
+    engine, synth = afx_mod
+    from afx import harness
+    from oracle import models as omodels
+    if arch == "conformer":
+        sd = synth.model_state_dict("ConformerModel", n_layers=2, n_encoders=2)
+        eng = engine.Engine("conformer", n_layers=2, dtype="fp16", conf_blocks=2)
+        ofwd = omodels.conformer_forward
+    else:
+        sd = synth.model_state_dict("XLSR_AASIST", n_layers=2)
+        eng = engine.Engine("xlsr_aasist", n_layers=2, dtype="fp16")
+        ofwd = omodels.xlsr_aasist_forward
+    eng.load_state_dict(sd)
+    lens = [64000, 16000, 40321, 7000, 64000, 23456, 16000]  # 199, 49, 125, 21, 199, 72, 49 frames
+    clips = [synth.waveforms(1, n, batch_idx=800 + i)[0] for i, n in enumerate(lens)]
+    got = eng.forward_ragged([c.cuda() for c in clips]).cpu()
+    for b, c in enumerate(clips):
+        alone = eng.forward(c[None].cuda()).cpu()[0]
+        assert torch.equal(got[b], alone), f"clip {b} ({lens[b]} samples): {(got[b] - alone).abs().max().item():.2e}"
+        ref = ofwd(sd, c[None])[0]
+        assert (got[b] - ref).abs().max().item() <= SCORE_TOL
+    with pytest.raises(Exception, match="400"):
+        eng.forward_ragged([clips[0].cuda(), torch.zeros(100).cuda()])
+
+    # the un-cropped scoring loop on top of it
+    class Toy(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(clips)
+
+        def __getitem__(self, i):
+            return f"u{i}", clips[i], 0
+
+    class Wrap(torch.nn.Module):
+        def forward_ragged(self, cs):
+            return eng.forward_ragged([c.cuda() for c in cs])
+    names, scores = harness.produce_evaluation_file_ragged(Toy(), Wrap(), "cuda", str(tmp_path / "r.txt"), batch_size=3, num_workers=0)
+    assert names == [f"u{i}" for i in range(len(clips))]
+    assert torch.allclose(torch.tensor(scores), got[:, 1], atol=0, rtol=0)
+
+
+def test_ragged_ssl_features(afx_mod):
+    engine, synth = afx_mod
+    sd = synth.ssl_state_dict(2)
+    eng = engine.Engine("ssl", n_layers=2, dtype="fp16")
+    eng.load_state_dict(sd)
+    clips = [synth.waveforms(1, n, batch_idx=820 + i)[0].cuda() for i, n in enumerate([48000, 9000, 48000, 30000])]
+    feats, frames = eng.ssl_ragged(clips)
+    assert frames == [149, 27, 149, 93] and feats.shape == (4, 149, 1024)
+    for b, c in enumerate(clips):
+        alone = eng.ssl(c[None])[0]
+        assert torch.equal(feats[b, : frames[b]], alone)
+        assert bool((feats[b, frames[b]:] == 0).all())
