@@ -132,29 +132,40 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
         }
       __builtin_amdgcn_sched_barrier(0);
     }
+    // softmax over the keys, in the exp2 domain on the RAW scores: the row maximum does not care about the positive
+    // scale, and exp(scale (s - max)) = exp2((s - max) scale log2 e) is one fma + one v_exp per element.  (The first
+    // version scaled, masked and subtracted per element -- ~9 VALU slots each, 56 elements per lane per query tile:
+    // the softmax, not the 56 MFMAs, was most of this kernel's compute phase.)  The key mask is needed only in the
+    // tiles that reach past T (wave-uniform test: the last one or two tiles of a uniform batch, more in a ragged one).
+    const float c2 = scale * 1.4426950408889634f;
     float mx = -1e30f;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt * 16 + 16 <= T) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + g * 4 + r;
-        const float v = key < T ? s[kt][r] * scale : -1e30f;
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (kt * 16 + g * 4 + r >= T) s[kt][r] = -1e30f;
+          mx = fmaxf(mx, s[kt][r]);
+        }
       }
+    }
     mx = rows_max(mx);
+    const float mc = -mx * c2;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = (MHSA_DBG & 8) ? s[kt][r] - mx : __expf(s[kt][r] - mx);
+        const float a = fmaf(s[kt][r], c2, mc);
+        const float e = (MHSA_DBG & 8) ? a : __builtin_amdgcn_exp2f(a);
         s[kt][r] = e;
         sum += e;
       }
     sum = rows_sum(sum);
     const float rinv = 1.0f / sum;
-
     // O = P V : k-slot (g, jj) of step s2 <-> key 32*s2 + 16*(jj>>2) + 4g + (jj&3)
     f32x4 o[4];
 #pragma unroll

@@ -203,6 +203,28 @@ def test_eer_of_the_build_matches_the_oracle(afx_mod):
     assert abs(eer_got - eer_ref) < 0.005
 
 
+def test_benchmarked_student_1024_trials_scores_and_eer(afx_mod):
+    """SURVEY.md 8(d) on the benchmarked configuration itself (BASELINE configs[1]: first-6 XLS-R trunk + 4 Conformer
+    blocks, fp16, batch 64, 4-s clips): 1024 trials, EVERY bonafide score within 1e-3 of the CPU oracle (committed
+    fixture tests/golden/eer_student_1024.npz, made by tools/make_eer_fixture.py -- the oracle needs minutes for
+    them) and the EER equal to 2 decimal places (asserted tighter: 0.005 percentage points)."""
+    engine, synth = afx_mod
+    from conftest import load_golden
+    from afx import harness
+    z = load_golden("eer_student_1024.npz")
+    sd = synth.model_state_dict("ConformerModel", n_layers=6)
+    eng = engine.Engine("conformer", n_layers=6, dtype="fp16")
+    eng.load_state_dict(sd)
+    got = torch.cat([eng.forward(synth.waveforms(64, 64000, batch_idx=9000 + i).cuda())[:, 1].cpu() for i in range(16)])
+    ref = torch.from_numpy(z["scores"])
+    d = (got - ref).abs()
+    eer_got = harness.calculate_EER(got.numpy(), z["labels"].astype(int))
+    print(f"1024 trials: max|dscore| {d.max().item():.2e} mean {d.mean().item():.2e}; EER oracle {float(z['eer']):.4f} % build {eer_got:.4f} %")
+    assert d.max().item() <= SCORE_TOL
+    assert 5.0 < float(z["eer"]) < 35.0 and abs(eer_got - float(z["eer"])) < 0.005
+    assert f"{eer_got:.2f}" == f"{float(z['eer']):.2f}"
+
+
 def test_length_policy_as_one_batched_device_op(afx_mod):
     """pad-by-tiling, first-N crop and random-start crop for a ragged batch in one
     kernel, against the reference policies restated in oracle/pre.py (data/test_set.py:139-248)."""
