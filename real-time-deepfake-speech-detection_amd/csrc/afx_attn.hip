@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
   constexpr int KEYS = KS * 32;   // keys covered
   __shared__ __attribute__((aligned(16))) char k_lds[ATT_KEYS * 128];
   __shared__ __attribute__((aligned(16))) Tt vt_lds[64 * ATT_VT_STRIDE];
+  __shared__ __attribute__((aligned(16))) float mask_lds[ATT_KEYS];  // 0 for a key of this utterance, -1e30 beyond it
 
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
       }
     }
   }
+  if (tid < KEYS) mask_lds[tid] = tid < T ? 0.f : -1e30f;
   __syncthreads();
   if (MHSA_DBG & 2) return;
 
@@ -121,8 +123,11 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
       V8(&nxt)[2][2] = (kp & 2) ? kfa : kfb;
       if (kp + 2 < NKT) read_k(kp + 2, nxt);
       __builtin_amdgcn_sched_barrier(0);
+      // the accumulators START at the key mask (0 / -1e30: one 16-B LDS read per tile, issued with the K fragments)
+      // instead of at zero: keys past the utterance's length (their K rows are staged as zeros, so q.k adds 0) come
+      // out of the MFMAs already masked -- no compare / select per score
 #pragma unroll
-      for (int u = 0; u < 2; ++u) s[kp + u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < 2; ++u) s[kp + u] = *(const f32x4*)(mask_lds + (kp + u) * 16 + g * 4);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -135,23 +140,13 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
     // softmax over the keys, in the exp2 domain on the RAW scores: the row maximum does not care about the positive
     // scale, and exp(scale (s - max)) = exp2((s - max) scale log2 e) is one fma + one v_exp per element.  (The first
     // version scaled, masked and subtracted per element -- ~9 VALU slots each, 56 elements per lane per query tile:
-    // the softmax, not the 56 MFMAs, was most of this kernel's compute phase.)  The key mask is needed only in the
-    // tiles that reach past T (wave-uniform test: the last one or two tiles of a uniform batch, more in a ragged one).
+    // the softmax, not the 56 MFMAs, was most of this kernel's compute phase.)
     const float c2 = scale * 1.4426950408889634f;
     float mx = -1e30f;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (kt * 16 + 16 <= T) {
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (kt * 16 + g * 4 + r >= T) s[kt][r] = -1e30f;
-          mx = fmaxf(mx, s[kt][r]);
-        }
-      }
-    }
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
     mx = rows_max(mx);
     const float mc = -mx * c2;
     float sum = 0.f;
