@@ -35,6 +35,8 @@ extern "C" {
 typedef struct afx_engine* afx_handle;
 
 enum { AFX_ARCH_SSL = 0, AFX_ARCH_XLSR_AASIST = 1, AFX_ARCH_CONFORMER = 2 };
+enum { AFX_EXTRACTOR_LAYER_NORM = 0, /* XLS-R: every conv layer conv+bias -> LayerNorm(512) -> GELU (what the reference loads) */
+       AFX_EXTRACTOR_GROUP_NORM = 1  /* wav2vec2-base: bias-free convs, GroupNorm(512,512) on layer 0 only, GELU */ };
 enum { AFX_DT_BF16 = 0, AFX_DT_FP16 = 1, AFX_DT_FP32 = 2 }; /* operand type (FP32: exact mode, fp32 MFMA); accumulation is always fp32 */
 
 typedef struct afx_config {
@@ -47,6 +49,8 @@ typedef struct afx_config {
   int conf_blocks;   /*            n_encoders (:41) */
   int pre_emphasis;  /* 1: apply data/preprocess.py:16-29 inside the first kernel */
   float pre_emphasis_coef;
+  int extractor_mode; /* AFX_EXTRACTOR_* (fairseq extractor_mode "layer_norm" / "default"); checkpoint keys
+                         feature_extractor.conv_layers.0.2.{weight,bias} instead of ....{i}.2.1.* and no conv biases */
 } afx_config;
 
 /* ---- lifecycle ---------------------------------------------------------------- */

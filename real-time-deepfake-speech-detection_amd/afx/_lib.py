@@ -22,7 +22,8 @@ class AfxError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("arch", C.c_int), ("dtype", C.c_int), ("n_layers", C.c_int),
                 ("conf_emb", C.c_int), ("conf_heads", C.c_int), ("conf_kernel", C.c_int),
-                ("conf_blocks", C.c_int), ("pre_emphasis", C.c_int), ("pre_emphasis_coef", C.c_float)]
+                ("conf_blocks", C.c_int), ("pre_emphasis", C.c_int), ("pre_emphasis_coef", C.c_float),
+                ("extractor_mode", C.c_int)]
 
 
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t

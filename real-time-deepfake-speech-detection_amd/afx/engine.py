@@ -11,6 +11,8 @@ from ._lib import AfxError, Config, check, lib, ptr, stream_ptr
 
 ARCHS = {"ssl": _lib.ARCH_SSL, "xlsr_aasist": _lib.ARCH_XLSR_AASIST, "conformer": _lib.ARCH_CONFORMER}
 DTYPES = {"bf16": _lib.DT_BF16, "fp16": _lib.DT_FP16, "fp32": _lib.DT_FP32}
+# fairseq extractor_mode: "layer_norm" = XLS-R (what the reference loads), "group_norm" = wav2vec2-base ("default")
+EXTRACTORS = {"layer_norm": 0, "group_norm": 1, "default": 1}
 # fp16 and bf16 run at the same matrix-core rate on gfx950; fp16's 3 extra mantissa bits
 # are what keeps the scores within 1e-3 of the fp32 reference (DESIGN.md "Numerics").
 # "fp32" is the exact mode: fp32 operands on the fp32 matrix instruction, 1/16 of the rate,
@@ -39,7 +41,7 @@ class Engine:
     ``torch.cuda.set_device`` (main.py:48,78-82).  Inputs on another GPU are refused, not dereferenced."""
 
     def __init__(self, arch, n_layers=24, dtype=None, conf_emb=144, conf_heads=4, conf_kernel=31,
-                 conf_blocks=4, pre_emphasis=False, pre_emphasis_coef=0.97, device=None):
+                 conf_blocks=4, pre_emphasis=False, pre_emphasis_coef=0.97, device=None, extractor_mode="layer_norm"):
         dtype = dtype or DEFAULT_DTYPE
         if dtype not in DTYPES:
             raise ValueError(f"dtype must be one of {sorted(DTYPES)}, got {dtype!r}")
@@ -47,9 +49,12 @@ class Engine:
             raise AfxError("no HIP device: the MI355X-native path has no CPU fallback")
         self.arch, self.dtype, self.n_layers = arch, dtype, n_layers
         self.pre_emphasis = bool(pre_emphasis)
+        if extractor_mode not in EXTRACTORS:
+            raise ValueError(f"extractor_mode must be one of {sorted(EXTRACTORS)}, got {extractor_mode!r}")
+        self.extractor_mode = "group_norm" if EXTRACTORS[extractor_mode] else "layer_norm"
         self.device = _cuda_device(device)
         cfg = Config(ARCHS[arch], DTYPES[dtype], n_layers, conf_emb, conf_heads, conf_kernel, conf_blocks,
-                     1 if pre_emphasis else 0, pre_emphasis_coef)
+                     1 if pre_emphasis else 0, pre_emphasis_coef, EXTRACTORS[extractor_mode])
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):  # afx_create allocates on the current device
             check(lib().afx_create(C.byref(cfg), C.byref(self._h)))

@@ -90,6 +90,8 @@ class IncrementalScorer(SlidingWindowScorer):
             raise ValueError("exact reuse needs hop % 160 == 0 (the stride of conv layer 5) and window % hop == 0")
         if engine.dtype == "fp32":
             raise ValueError("the incremental scorer runs the half-precision conv kernels (fp16 / bf16 engines)")
+        if getattr(engine, "extractor_mode", "layer_norm") != "layer_norm":
+            raise ValueError("the group-norm extractor normalises layer 0 over the whole window: nothing is reusable")
         if getattr(engine, "pre_emphasis", False):
             raise ValueError("engine-side pre-emphasis makes the window's first frame position-dependent: not reusable")
         self.eng, self.dt = engine, engine.dtype

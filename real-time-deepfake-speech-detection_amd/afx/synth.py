@@ -52,16 +52,20 @@ def _bn(sd, name, n):
 
 
 def ssl_state_dict(n_layers=24, prefix=SSL_PREFIX, dim=1024, ffn=4096, conv_dim=512,
-                   conv_layers=None, pos_k=128, pos_groups=16):
-    """fairseq-named XLS-R trunk (layer_norm extractor mode, biased convs)."""
+                   conv_layers=None, pos_k=128, pos_groups=16, extractor_mode="layer_norm"):
+    """fairseq-named XLS-R trunk (layer_norm extractor mode, biased convs); ``extractor_mode="group_norm"`` gives the
+    wav2vec2-base feature extractor instead (bias-free convs, GroupNorm affine of layer 0 under ``...0.2.*``)."""
     conv_layers = conv_layers or [(conv_dim, k, s) for (_, k, s) in CONV_LAYERS]
     sd = {}
     cin = 1
     for i, (c, k, s) in enumerate(conv_layers):
         n = f"{prefix}feature_extractor.conv_layers.{i}"
         sd[n + ".0.weight"] = _randn(n + ".0.weight", (c, cin, k), math.sqrt(2.0 / (cin * k)))
-        sd[n + ".0.bias"] = _randn(n + ".0.bias", (c,), 0.02)
-        _norm(sd, n + ".2.1", c)
+        if extractor_mode == "layer_norm":
+            sd[n + ".0.bias"] = _randn(n + ".0.bias", (c,), 0.02)
+            _norm(sd, n + ".2.1", c)
+        elif i == 0:
+            _norm(sd, n + ".2", c)
         cin = c
     _norm(sd, prefix + "layer_norm", cin)
     _linear(sd, prefix + "post_extract_proj", dim, cin)

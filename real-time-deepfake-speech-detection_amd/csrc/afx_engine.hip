@@ -150,6 +150,10 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
     return fail("Number of layers must be at least 1 and at most 24.");  // models/fe.py:60-62
   if (cfg->dtype != AFX_DT_BF16 && cfg->dtype != AFX_DT_FP16 && cfg->dtype != AFX_DT_FP32) return fail("afx_create: unknown dtype %d", cfg->dtype);
   if (cfg->arch < AFX_ARCH_SSL || cfg->arch > AFX_ARCH_CONFORMER) return fail("afx_create: unknown arch %d", cfg->arch);
+  if (cfg->extractor_mode != AFX_EXTRACTOR_LAYER_NORM && cfg->extractor_mode != AFX_EXTRACTOR_GROUP_NORM)
+    return fail("afx_create: unknown extractor_mode %d", cfg->extractor_mode);
+  if (cfg->extractor_mode == AFX_EXTRACTOR_GROUP_NORM && cfg->pre_emphasis)
+    return fail("afx_create: fused pre-emphasis is built for the layer_norm extractor only");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail("afx_create: no HIP device visible -- this library has no CPU fallback");
@@ -405,10 +409,15 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
   if (!h) return fail("afx_finalize: null handle");
   hipStream_t s = (hipStream_t)stream;
   const std::string P = "ssl_model.model.";
+  const bool gn = h->cfg.extractor_mode == AFX_EXTRACTOR_GROUP_NORM;
   for (int i = 0; i < 7; ++i) {
     const std::string c = P + "feature_extractor.conv_layers." + std::to_string(i);
-    if (need(h, c + ".0.weight") || need(h, c + ".0.bias") || need(h, c + ".2.1.weight") || need(h, c + ".2.1.bias"))
+    if (need(h, c + ".0.weight")) return 1;
+    if (gn) {  // wav2vec2-base: bias-free convs, GroupNorm(512,512) on layer 0 only
+      if (i == 0 && (need(h, c + ".2.weight") || need(h, c + ".2.bias"))) return 1;
+    } else if (need(h, c + ".0.bias") || need(h, c + ".2.1.weight") || need(h, c + ".2.1.bias")) {
       return 1;
+    }
   }
   for (const char* k : {"layer_norm.weight", "layer_norm.bias", "post_extract_proj.weight", "post_extract_proj.bias",
                         "encoder.pos_conv.0.bias", "encoder.layer_norm.weight", "encoder.layer_norm.bias"})
@@ -513,6 +522,7 @@ struct Ws {
   int T[7];
   void *bufA, *bufB, *feats_h, *xpad, *hbuf, *qkv, *att, *ff, *ssl_h;
   float *tmp32, *x, *ssl_f;
+  float* gn_stats = nullptr;  // group-norm extractor mode: partial sums + mean / rstd of conv layer 0
   // ragged batch (afx_forward_ragged): valid SSL frames per utterance on the device (null = uniform batch), and the
   // AASIST bucket buffers (utterances of equal length gathered into a uniform sub-batch for the graph back-end)
   int* lens = nullptr;
@@ -539,6 +549,7 @@ static size_t carve(const afx_engine* e, int B, int L, int Tfeat, void* base, Ws
       w->bufA = c.take(n0 * hs);
       w->bufB = c.take(n1 * hs);
       w->tmp32 = (float*)c.take(n1 * 4);
+      if (e->cfg.extractor_mode == AFX_EXTRACTOR_GROUP_NORM) w->gn_stats = (float*)c.take(conv0_groupnorm_stats_floats(B, w->T[0]) * 4);
     } else {
       for (int i = 0; i < 5; ++i) w->T[i] = 0;
       w->T[5] = T5;
@@ -757,9 +768,13 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
   auto cf = [&](int i, const char* leaf) {
     return e->F("ssl.feature_extractor.conv_layers." + std::to_string(i) + leaf);
   };
-  // layer 0: waveform -> (B,T0,512) operand type, LN + GELU fused
+  // layer 0: waveform -> (B,T0,512) operand type, normalisation + GELU fused
+  const bool gn = e->cfg.extractor_mode == AFX_EXTRACTOR_GROUP_NORM;
   if (!l5)
     KOK(timed(PC_CONV0, 2.0 * B * T[0] * kC * kConvK[0], s, [&] {
+      if (gn)  // wav2vec2-base: GroupNorm over time per (utterance, channel), two passes over the cheap convolution
+        return launch_conv0_groupnorm(wave, B, L, T[0], cf(0, ".0.weight"), cf(0, ".2.weight"), cf(0, ".2.bias"), kLnEps,
+                                      w.gn_stats, w.bufA, dt, s);
       return launch_conv0(wave, B, L, T[0], cf(0, ".0.weight"), cf(0, ".0.bias"), cf(0, ".2.1.weight"),
                           cf(0, ".2.1.bias"), e->cfg.pre_emphasis, e->cfg.pre_emphasis_coef, w.bufA, dt, s);
     }));
@@ -772,9 +787,16 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     GemmArgs g = plain_gemm(in, 0, e->convw[i], K, M, kC, K);
     g.rpb = T[i]; g.a_batch = (long)T[i - 1] * kC; g.a_row = (long)kConvS[i] * kC;
     g.o_batch_rows = T[i]; g.oh_batch_rows = T[i];
-    g.bias = cf(i, ".0.bias");
+    g.bias = gn ? nullptr : cf(i, ".0.bias");
     g.act = ACT_GELU;
-    if (g_fuse_conv_ln && dt != DT_FP32) {
+    if (gn) {  // wav2vec2-base: conv -> GELU, nothing to normalise in layers 1-6 (plain product, GELU epilogue)
+      if (i < 6) {
+        g.out_h = out; g.ldo_h = kC;
+      } else {
+        g.out_f = w.tmp32; g.ldo_f = kC;
+      }
+      KOK(launch_gemm(g, dt, 1, s));
+    } else if (g_fuse_conv_ln && dt != DT_FP32) {
       g.ln_gamma = cf(i, ".2.1.weight"); g.ln_beta = cf(i, ".2.1.bias"); g.ln_eps = kLnEps;
       if (i < 6) {
         g.out_h = out; g.ldo_h = kC;
@@ -1112,6 +1134,7 @@ extern "C" int afx_forward_ragged(afx_handle h, const float* wave, int B, int Lm
   if (!n_samples) return fail("afx_forward_ragged: null lengths");
   if (h->cfg.arch == AFX_ARCH_SSL) return fail("afx_forward_ragged: this handle is an SSL feature extractor; use afx_ssl_forward_ragged");
   if (h->cfg.pre_emphasis) return fail("afx_forward_ragged: engine-side pre-emphasis is not supported on ragged batches");
+  if (h->cfg.extractor_mode == AFX_EXTRACTOR_GROUP_NORM) return fail("afx_forward_ragged: the group-norm extractor normalises over the whole clip; zero padding would enter its statistics");
   Ws w;
   const size_t needb = carve(h, B, Lmax, 0, ws, &w, 0, true);
   if (ws_bytes < needb) return fail("afx_forward_ragged: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
@@ -1148,6 +1171,7 @@ extern "C" int afx_ssl_forward_ragged(afx_handle h, const float* wave, int B, in
   if (check_call(h, wave, B, Lmax, feats, ws)) return 1;
   if (!n_samples) return fail("afx_ssl_forward_ragged: null lengths");
   if (h->cfg.pre_emphasis) return fail("afx_ssl_forward_ragged: engine-side pre-emphasis is not supported on ragged batches");
+  if (h->cfg.extractor_mode == AFX_EXTRACTOR_GROUP_NORM) return fail("afx_ssl_forward_ragged: the group-norm extractor normalises over the whole clip; zero padding would enter its statistics");
   Ws w;
   const size_t needb = carve(h, B, Lmax, 0, ws, &w, 0, true);
   if (ws_bytes < needb) return fail("afx_ssl_forward_ragged: workspace too small (%zu < %zu bytes)", ws_bytes, needb);

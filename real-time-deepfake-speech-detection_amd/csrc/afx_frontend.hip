@@ -199,6 +199,120 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------
+// conv layer 0 of the wav2vec2-*base* feature extractor (fairseq extractor_mode="default"; SURVEY 8a row 1a, the
+// "GroupNorm/GELU" `north_star` names): bias-free Conv1d(1 -> 512, k=10, s=5) -> GroupNorm(512 groups of one channel
+// = per (utterance, channel) normalisation over TIME, affine) -> erf-GELU.  The statistics span the whole clip, so
+// the layer is two passes over the (cheap: 10 MACs per output) convolution: pass 1 writes per-chunk partial sums
+// (sum, sum of squares) -- fixed chunks, summed in a fixed order in double by the finalize kernel, so the result does
+// not depend on scheduling --, pass 2 recomputes the convolution, normalises, activates and stores.
+// ---------------------------------------------------------------------------------
+constexpr int GN_FB = 256;  // frames per statistics chunk
+__global__ __launch_bounds__(256) void conv0_gn_stats_kernel(const float* __restrict__ wave, int L, int T0,
+                                                             const float* __restrict__ w, float* __restrict__ part /*[B][nchunk][2][512]*/) {
+  __shared__ float xs[GN_FB * 5 + 8];
+  const int b = blockIdx.y, f0 = blockIdx.x * GN_FB, tid = threadIdx.x;
+  const float* x = wave + (long)b * L;
+  for (int i = tid; i < GN_FB * 5 + 5; i += 256) xs[i] = f0 * 5 + i < L ? x[f0 * 5 + i] : 0.f;
+  float w0[10], w1[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    w0[j] = w[tid * 10 + j];
+    w1[j] = w[(tid + 256) * 10 + j];
+  }
+  __syncthreads();
+  const int nf = min(GN_FB, T0 - f0);
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  for (int f = 0; f < nf; ++f) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const float xv = xs[f * 5 + j];
+      a0 = fmaf(w0[j], xv, a0);
+      a1 = fmaf(w1[j], xv, a1);
+    }
+    s0 += a0; q0 = fmaf(a0, a0, q0);
+    s1 += a1; q1 = fmaf(a1, a1, q1);
+  }
+  float* o = part + ((long)b * gridDim.x + blockIdx.x) * 1024;
+  o[tid] = s0; o[tid + 256] = s1; o[512 + tid] = q0; o[512 + tid + 256] = q1;
+}
+__global__ void conv0_gn_finalize_kernel(const float* __restrict__ part, int nchunk, int T0, float eps,
+                                         float* __restrict__ mean, float* __restrict__ rstd) {
+  const int b = blockIdx.x, c = threadIdx.x;  // 512 threads
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    const float* o = part + ((long)b * nchunk + k) * 1024;
+    s += (double)o[c];
+    q += (double)o[512 + c];
+  }
+  const double m = s / T0, v = q / T0 - m * m;
+  mean[b * 512 + c] = (float)m;
+  rstd[b * 512 + c] = (float)(1.0 / sqrt((v > 0.0 ? v : 0.0) + (double)eps));
+}
+template <class HT>
+__global__ __launch_bounds__(256) void conv0_gn_apply_kernel(const float* __restrict__ wave, int L, int T0,
+                                                             const float* __restrict__ w, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, typename HT::T* __restrict__ out) {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+  __shared__ float xs[C0_FB * 5 + 8];
+  const int b = blockIdx.y, f0 = blockIdx.x * C0_FB;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* x = wave + (long)b * L;
+  for (int i = tid; i < C0_FB * 5 + 5; i += 256) xs[i] = f0 * 5 + i < L ? x[f0 * 5 + i] : 0.f;
+  float wr[8][10], sc[8], sh[8];  // lane owns channels 8 lane .. 8 lane + 7; y = conv * sc + sh
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane * 8 + i;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) wr[i][j] = w[c * 10 + j];
+    const float r = rstd[b * 512 + c] * gamma[c];
+    sc[i] = r;
+    sh[i] = fmaf(-mean[b * 512 + c], r, beta[c]);
+  }
+  __syncthreads();
+  const int fend = min(C0_FB, T0 - f0);
+  for (int f = wv; f < fend; f += 4) {
+    float xv[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) xv[j] = xs[f * 5 + j];
+    V8 o;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        a0 = fmaf(wr[i][j], xv[j], a0);
+        a1 = fmaf(wr[i + 1][j], xv[j], a1);
+      }
+      const f32x2_t yin = f32x2_t{fmaf(a0, sc[i], sh[i]), fmaf(a1, sc[i + 1], sh[i + 1])};
+      const f32x2_t y = sizeof(T) == 4 ? gelu_erf2(yin) : gelu_poly2(yin);
+      o[i] = (T)y[0];
+      o[i + 1] = (T)y[1];
+    }
+    *(V8*)(out + ((long)b * T0 + f0 + f) * 512 + lane * 8) = o;
+  }
+}
+const char* launch_conv0_groupnorm(const float* wave, int B, int L, int T0, const float* w, const float* gamma,
+                                   const float* beta, float eps, float* stats /* B*(nchunk*1024 + 1024) floats */, void* out_h,
+                                   int dtype, hipStream_t s) {
+  if (B <= 0 || L < 10 || T0 != (L - 10) / 5 + 1 || B > 65535) return "conv0 (group norm): bad shape";
+  const int nchunk = (T0 + GN_FB - 1) / GN_FB;
+  float* part = stats;
+  float* mean = stats + (size_t)B * nchunk * 1024;
+  float* rstd = mean + (size_t)B * 512;
+  hipLaunchKernelGGL(conv0_gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, wave, L, T0, w, part);
+  hipLaunchKernelGGL(conv0_gn_finalize_kernel, dim3(B), dim3(512), 0, s, part, nchunk, T0, eps, mean, rstd);
+  dim3 grid((T0 + C0_FB - 1) / C0_FB, B);
+  AFX_DISPATCH_HT(dtype, hipLaunchKernelGGL(conv0_gn_apply_kernel<HT>, grid, dim3(256), 0, s, wave, L, T0, w, mean, rstd, gamma,
+                                            beta, (HT::T*)out_h));
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+size_t conv0_groupnorm_stats_floats(int B, int T0) { return (size_t)B * (((size_t)T0 + GN_FB - 1) / GN_FB * 1024 + 1024); }
+
 const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w, const float* bias,
                          const float* gamma, const float* beta, int pre_emph, float pre_coef, void* out_h,
                          int dtype, hipStream_t s) {

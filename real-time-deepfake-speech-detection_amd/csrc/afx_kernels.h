@@ -67,6 +67,11 @@ bool gemm_set_nodma(int v);     // timing-only knob (attribution build, -DAFX_AT
 const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w /*[512][10]*/,
                          const float* bias, const float* gamma, const float* beta, int pre_emph,
                          float pre_coef, void* out_h, int dtype, hipStream_t s);
+// the wav2vec2-base form of layer 0: bias-free conv -> GroupNorm(512,512) (per utterance and channel, over time) -> GELU;
+// stats: scratch of conv0_groupnorm_stats_floats(B, T0) floats
+const char* launch_conv0_groupnorm(const float* wave, int B, int L, int T0, const float* w, const float* gamma,
+                                   const float* beta, float eps, float* stats, void* out_h, int dtype, hipStream_t s);
+size_t conv0_groupnorm_stats_floats(int B, int T0);
 // ragged batch (packed, offs[B+1]) -> (B, duration): out[b][i] = x_b[(start_b + i) mod n_b]; starts may be null
 const char* launch_tile_crop(const float* x, const long long* offs, const long long* starts, int B, int duration,
                              float* out, hipStream_t s);

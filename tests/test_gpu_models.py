@@ -550,3 +550,31 @@ def test_ragged_ssl_features(afx_mod):
         alone = eng.ssl(c[None])[0]
         assert torch.equal(feats[b, : frames[b]], alone)
         assert bool((feats[b, frames[b]:] == 0).all())
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-3), ("fp32", 2e-5)])
+def test_group_norm_extractor_mode(afx_mod, dtype, tol):
+    """The wav2vec2-base feature extractor `north_star` names beside XLS-R's (fairseq extractor_mode="default":
+    bias-free convs, GroupNorm(512,512) = per-utterance-and-channel normalisation over time on layer 0 only, GELU;
+    SURVEY 8a row 1a) against the oracle's mode="default", after the conv stack and at the trunk's output."""
+    engine, synth = afx_mod
+    from oracle import ssl_trunk
+    sd = synth.ssl_state_dict(2, extractor_mode="group_norm")
+    assert "ssl_model.model.feature_extractor.conv_layers.0.2.weight" in sd
+    assert "ssl_model.model.feature_extractor.conv_layers.0.0.bias" not in sd
+    wave = synth.waveforms(3, 32000, batch_idx=61) + 0.02  # a DC offset: the group norm must remove per-channel means
+    taps = {}
+    ref = ssl_trunk.ssl_forward({k[len(synth.SSL_PREFIX):]: v for k, v in sd.items()}, wave, mode="default", taps=taps)
+    eng = engine.Engine("ssl", n_layers=2, dtype=dtype, extractor_mode="group_norm")
+    eng.load_state_dict(sd)
+    eng.enable_taps()
+    got = eng.ssl(wave.cuda()).cpu()
+
+    def rel(a, b):
+        return ((a.reshape(-1) - b.reshape(-1)).norm() / b.norm()).item()
+    assert rel(eng.tap("conv").cpu(), taps["conv"]) < tol
+    assert got.shape == ref.shape and rel(got, ref) < tol
+    with pytest.raises(Exception, match="group-norm|whole clip"):
+        eng.ssl_ragged([wave[0].cuda(), wave[1, :20000].cuda()])
+    with pytest.raises(Exception, match="missing weight"):
+        engine.Engine("ssl", n_layers=2, dtype=dtype, extractor_mode="group_norm").load_state_dict(synth.ssl_state_dict(2))
