@@ -16,6 +16,14 @@ constexpr int AAS_HP = 46;      // padded rows (43 conv1 rows + 1 top + slack)
 
 struct AasistWeights {
   bool ready = false;
+  // true (set by the engine before aasist_finalize for fp16 / bf16 engines): the dense products of the head run in
+  // the split-precision form on the fp16 matrix pipe (afx_aasist.hip, f32s_gemm_kernel: fp32 accuracy, ~5x the speed
+  // of the fp32 MFMA); false = exact mode, true-fp32 matrix instruction
+  bool split = false;
+  struct Split {
+    _Float16 *hi = nullptr, *lo = nullptr;
+  };
+  Split LLs, att_s0, att_s3;
   // pointers into engine-owned fp32 tensors / prepared buffers
   const float *LLw, *LLb;
   float bn0_scale, bn0_shift;  // first_bn (1 channel)
@@ -24,6 +32,7 @@ struct AasistWeights {
     float *w1, *w2, *wd;  // tap-major packed [cout][taps*cin]
     const float *b1, *b2, *bd;
     float *bn2_scale, *bn2_shift;
+    Split s1, s2, sd;
   } blk[6];
   float *bn1_scale, *bn1_shift;  // first_bn1 (64)
   float *att_w0, *att_w3;        // 1x1 convs as [128][64], [64][128]

@@ -29,6 +29,9 @@ struct F32GemmArgs {
   int nch, kc;         // K = nch chunks of kc contiguous elements (kc % 16 == 0)
   long chunk_stride;   // elements between chunks of one row
   const float* W;      // [N][nch*kc]
+  // split-precision form (f32s_gemm_kernel): the same weights as fp16 pairs, W = Wh + 2^-11 Wl (null: fp32 MFMA)
+  const _Float16* Wh;
+  const _Float16* Wl;
   int M, N;            // N = 16 * NT
   const float* bias;   // [N] or null
   const float* resid;  // indexed like out, or null
@@ -120,6 +123,119 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(F32GemmArgs p) {
   }
 }
 
+// ===================================================================================
+// The same product at fp32 ACCURACY on the fp16 matrix pipe (16x the rate of the fp32 MFMA).
+// Every fp32 operand is split into two fp16 halves, x = xh + 2^-11 xl with xh = fp16(x), xl = fp16((x - xh) 2^11):
+// the residue x - xh is exact in fp32, the scaling keeps xl a NORMAL fp16 number for every |x| > 6e-5 (unscaled, the
+// low half of anything below 0.125 would be subnormal) and xh + 2^-11 xl carries 22 mantissa bits.  Then
+//     a w  =  ah wh  +  2^-11 (ah wl + al wh)  +  O(2^-22 a w)
+// with each fp16 x fp16 product exact in the MFMA's fp32 accumulation.  Three v_mfma_f32_16x16x32_f16 (48 cycles per
+// 16 x 16 x 32 block) replace eight v_mfma_f32_16x16x4_f32 (256 cycles); the main and the correction terms keep their
+// own fp32 accumulators and meet once at the end.  Weights are split once at load time, activations in registers
+// (two cvt, a subtract and a multiply per element).  Relative error of a dot product ~3e-7: the same order as the
+// fp32 kernel's own summation-order noise against the CPU reference (both are "fp32" only up to that).
+// The engine's exact mode (dtype fp32) and the stand-alone module entry points keep the true-fp32 kernel above.
+// ===================================================================================
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+template <int NT>
+__global__ __launch_bounds__(256) void f32s_gemm_kernel(F32GemmArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const long m0 = ((long)blockIdx.x * 4 + wave) * 32;
+  if (m0 >= p.M) return;
+  const int n0 = blockIdx.y * NT * 16;
+  const long ldw = (long)p.nch * p.kc;
+  const float* arow[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    long m = m0 + mt * 16 + r;
+    m = m < p.M ? m : p.M - 1;
+    arow[mt] = p.A + m * p.lda + kq * 8;
+  }
+  const long woff = (long)(n0 + r) * ldw + kq * 8;
+  f32x4 acc[2][NT], cor[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = cor[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ch = 0; ch < p.nch; ++ch) {
+    const long ao = (long)ch * p.chunk_stride;
+    const long wo = (long)ch * p.kc;
+    for (int k0 = 0; k0 < p.kc; k0 += 32) {
+      f32x4 x[2][2];
+      h16x8 wh[NT], wl[NT];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        x[mt][0] = *(const f32x4*)(arow[mt] + ao + k0);
+        x[mt][1] = *(const f32x4*)(arow[mt] + ao + k0 + 4);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        wh[nt] = *(const h16x8*)(p.Wh + woff + (long)nt * 16 * ldw + wo + k0);
+        wl[nt] = *(const h16x8*)(p.Wl + woff + (long)nt * 16 * ldw + wo + k0);
+      }
+      h16x8 ah[2], al[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float v = x[mt][i >> 2][i & 3];
+          const _Float16 hi = (_Float16)v;
+          ah[mt][i] = hi;
+          al[mt][i] = (_Float16)((v - (float)hi) * 2048.0f);
+        }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+          cor[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], ah[mt], cor[mt][nt], 0, 0, 0);
+          cor[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], al[mt], cor[mt][nt], 0, 0, 0);
+        }
+    }
+  }
+  // operands swapped: lane holds out[m = .. + (lane&15)][n = n0 + 16nt + 4*(lane>>4) + 0..3]
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const long m = m0 + mt * 16 + r;
+    if (m >= p.M) continue;
+    bool valid = true;
+    if (p.img) {
+      const int pix = (int)(m % p.img);
+      valid = (pix / p.wp < p.hout) && (pix % p.wp < p.wd);
+    }
+    const long orow = (m + p.o_off) * p.ldo;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + nt * 16 + kq * 4;
+      f32x4 v = acc[mt][nt] + cor[mt][nt] * (1.0f / 2048.0f);
+      if (p.bias) v += *(const f32x4*)(p.bias + n);
+      if (p.resid) v += *(const f32x4*)(p.resid + orow + n);
+      if (p.post == 1) {
+        const f32x4 sc = *(const f32x4*)(p.bn_scale + n), sh = *(const f32x4*)(p.bn_shift + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = selu(fmaf(v[i], sc[i], sh[i]));
+      } else if (p.post == 2) {
+        const f32x4 sc = *(const f32x4*)(p.bn_scale + n), sh = *(const f32x4*)(p.bn_shift + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaf(selu(v[i]), sc[i], sh[i]);
+      }
+      if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)(p.out + orow + n) = v;
+    }
+  }
+}
+
+// fp32 weights -> (hi, 2^11-scaled lo) fp16 pair, once at load time
+__global__ void split_f16_kernel(const float* __restrict__ w, long n, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = w[i];
+    const _Float16 h = (_Float16)v;
+    hi[i] = h;
+    lo[i] = (_Float16)((v - (float)h) * 2048.0f);
+  }
+}
+
 static const char* launch_f32_gemm(const F32GemmArgs& p, hipStream_t s) {
   if (p.kc % 16 || p.M <= 0) return "aasist gemm: chunk length must be a multiple of 16";
   if (p.N != 32 && p.N != 64 && p.N != 128) return "aasist gemm: N must be 32, 64 or 128";
@@ -129,6 +245,20 @@ static const char* launch_f32_gemm(const F32GemmArgs& p, hipStream_t s) {
   int nt = p.N / 16;
   while (nt > 1 && row_waves * (p.N / (16 * nt)) < 1024) nt >>= 1;
   dim3 grid((unsigned)((p.M + 127) / 128), p.N / (16 * nt));
+  if (p.Wh && p.Wl) {  // split-precision form on the fp16 matrix pipe
+    if (p.kc % 32 || (p.lda % 4) || (p.chunk_stride % 4)) return "aasist gemm (split precision): K chunks of 32, 16-B aligned rows";
+    if (nt > 4) {  // 2 x NT x 2 accumulator tiles: keep the wave at 4 column tiles
+      nt = 4;
+      grid.y = p.N / 64;
+    }
+    switch (nt) {
+      case 1: hipLaunchKernelGGL(f32s_gemm_kernel<1>, grid, dim3(256), 0, s, p); break;
+      case 2: hipLaunchKernelGGL(f32s_gemm_kernel<2>, grid, dim3(256), 0, s, p); break;
+      default: hipLaunchKernelGGL(f32s_gemm_kernel<4>, grid, dim3(256), 0, s, p); break;
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+  }
   switch (nt) {
     case 1: hipLaunchKernelGGL(f32_gemm_kernel<1>, grid, dim3(256), 0, s, p); break;
     case 2: hipLaunchKernelGGL(f32_gemm_kernel<2>, grid, dim3(256), 0, s, p); break;
@@ -480,8 +610,18 @@ const char* aasist_finalize(AasistWeights& w, const GetF& get, const Alloc& allo
     if (src && dst) hipLaunchKernelGGL(pack_conv2d_kernel, dim3(64), dim3(256), 0, s, src, cout, cin, kh, kw, dst);
     return dst;
   };
+  // split-precision copies (hi, lo) of a packed fp32 weight for f32s_gemm_kernel; null pair in exact mode
+  auto split = [&](const float* src, size_t n, AasistWeights::Split* out) {
+    out->hi = out->lo = nullptr;
+    if (!w.split || !src) return;
+    out->hi = (_Float16*)alloc(n * 2);
+    out->lo = (_Float16*)alloc(n * 2);
+    if (out->hi && out->lo)
+      hipLaunchKernelGGL(split_f16_kernel, dim3(64), dim3(256), 0, s, src, (long)n, out->hi, out->lo);
+  };
   w.LLw = need("LL.weight");
   w.LLb = need("LL.bias");
+  split(w.LLw, (size_t)128 * 1024, &w.LLs);
   static const int filt[6][2] = {{1, 32}, {32, 32}, {32, 64}, {64, 64}, {64, 64}, {64, 64}};
   for (int i = 0; i < 6; ++i) {
     AasistWeights::Block& B = w.blk[i];
@@ -492,20 +632,25 @@ const char* aasist_finalize(AasistWeights& w, const GetF& get, const Alloc& allo
     B.b1 = need(p + "conv1.bias");
     B.w2 = pack(p + "conv2.weight", B.cout, B.cout, 2, 3);
     B.b2 = need(p + "conv2.bias");
+    if (B.cin > 1) split(B.w1, (size_t)B.cout * B.cin * 6, &B.s1);
+    split(B.w2, (size_t)B.cout * B.cout * 6, &B.s2);
     fold(p + "bn2.", B.cout, &B.bn2_scale, &B.bn2_shift);
     B.wd = nullptr;
     B.bd = nullptr;
     if (B.cin != B.cout) {
       B.wd = pack(p + "conv_downsample.weight", B.cout, B.cin, 1, 3);
       B.bd = need(p + "conv_downsample.bias");
+      if (B.cin > 1) split(B.wd, (size_t)B.cout * B.cin * 3, &B.sd);
     }
   }
   fold("first_bn1.", 64, &w.bn1_scale, &w.bn1_shift);
   w.att_w0 = pack("attention.0.weight", 128, 64, 1, 1);
   w.att_b0 = need("attention.0.bias");
+  split(w.att_w0, (size_t)128 * 64, &w.att_s0);
   fold("attention.2.", 128, &w.att_bn_scale, &w.att_bn_shift);
   w.att_w3 = pack("attention.3.weight", 64, 128, 1, 1);
   w.att_b3 = need("attention.3.bias");
+  split(w.att_w3, (size_t)64 * 128, &w.att_s3);
   w.pos_S = need("pos_S");
   w.master1 = need("master1");
   w.master2 = need("master2");
@@ -616,7 +761,7 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
   {
     F32GemmArgs g;
     memset(&g, 0, sizeof g);
-    g.A = feats; g.lda = 1024; g.nch = 1; g.kc = 1024; g.W = w.LLw; g.M = B * T; g.N = 128;
+    g.A = feats; g.lda = 1024; g.nch = 1; g.kc = 1024; g.W = w.LLw; g.Wh = w.LLs.hi; g.Wl = w.LLs.lo; g.M = B * T; g.N = 128;
     g.bias = w.LLb; g.out = ws.ll; g.ldo = 128;
     AOK(launch_f32_gemm(g, s));
   }
@@ -643,7 +788,7 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
     F32GemmArgs g;
     memset(&g, 0, sizeof g);
     g.A = Y + (long)wp * K.cout; g.lda = K.cout; g.nch = 2; g.kc = 3 * K.cout; g.chunk_stride = (long)wp * K.cout;
-    g.W = K.w2; g.M = M; g.N = K.cout; g.bias = K.b2; g.resid = D;
+    g.W = K.w2; g.Wh = K.s2.hi; g.Wl = K.s2.lo; g.M = M; g.N = K.cout; g.bias = K.b2; g.resid = D;
     g.img = img; g.wp = wp; g.hout = AAS_F; g.wd = wd; g.out = X; g.ldo = K.cout; g.o_off = wp + 1;
     AOK(launch_f32_gemm(g, s));
   }
@@ -656,13 +801,13 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
     F32GemmArgs g;
     memset(&g, 0, sizeof g);  // conv1 (pad (1,1)) on X -> bn2 -> selu -> Y, 43 rows
     g.A = X; g.lda = K.cin; g.nch = 2; g.kc = 3 * K.cin; g.chunk_stride = (long)wp * K.cin;
-    g.W = K.w1; g.M = M; g.N = K.cout; g.bias = K.b1; g.bn_scale = K.bn2_scale; g.bn_shift = K.bn2_shift; g.post = 1;
+    g.W = K.w1; g.Wh = K.s1.hi; g.Wl = K.s1.lo; g.M = M; g.N = K.cout; g.bias = K.b1; g.bn_scale = K.bn2_scale; g.bn_shift = K.bn2_shift; g.post = 1;
     g.img = img; g.wp = wp; g.hout = AAS_F + 1; g.wd = wd; g.out = Y; g.ldo = K.cout; g.o_off = wp + 1;
     AOK(launch_f32_gemm(g, s));
     const float* resid = X;
     if (K.wd) {  // (1,3) downsample conv of X -> D
       memset(&g, 0, sizeof g);
-      g.A = X + (long)wp * K.cin; g.lda = K.cin; g.nch = 1; g.kc = 3 * K.cin; g.W = K.wd; g.M = M; g.N = K.cout;
+      g.A = X + (long)wp * K.cin; g.lda = K.cin; g.nch = 1; g.kc = 3 * K.cin; g.W = K.wd; g.Wh = K.sd.hi; g.Wl = K.sd.lo; g.M = M; g.N = K.cout;
       g.bias = K.bd; g.img = img; g.wp = wp; g.hout = AAS_F; g.wd = wd; g.out = D; g.ldo = K.cout; g.o_off = wp + 1;
       AOK(launch_f32_gemm(g, s));
       resid = D;
@@ -674,7 +819,7 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
     // residual, by the same thread that then overwrites it)
     memset(&g, 0, sizeof g);
     g.A = Y + (long)wp * K.cout; g.lda = K.cout; g.nch = 2; g.kc = 3 * K.cout; g.chunk_stride = (long)wp * K.cout;
-    g.W = K.w2; g.M = M; g.N = K.cout; g.bias = K.b2; g.resid = resid;
+    g.W = K.w2; g.Wh = K.s2.hi; g.Wl = K.s2.lo; g.M = M; g.N = K.cout; g.bias = K.b2; g.resid = resid;
     if (i == 5) {  // first_bn1 + SELU close the encoder (models/xlsr_aasist.py:100-101)
       g.bn_scale = w.bn1_scale; g.bn_shift = w.bn1_shift; g.post = 1;
     }
@@ -685,11 +830,11 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
   {
     F32GemmArgs g;
     memset(&g, 0, sizeof g);
-    g.A = X; g.lda = 64; g.nch = 1; g.kc = 64; g.W = w.att_w0; g.M = M; g.N = 128; g.bias = w.att_b0;
+    g.A = X; g.lda = 64; g.nch = 1; g.kc = 64; g.W = w.att_w0; g.Wh = w.att_s0.hi; g.Wl = w.att_s0.lo; g.M = M; g.N = 128; g.bias = w.att_b0;
     g.bn_scale = w.att_bn_scale; g.bn_shift = w.att_bn_shift; g.post = 2; g.out = ws.wmap1; g.ldo = 128;
     AOK(launch_f32_gemm(g, s));
     memset(&g, 0, sizeof g);
-    g.A = ws.wmap1; g.lda = 128; g.nch = 1; g.kc = 128; g.W = w.att_w3; g.M = M; g.N = 64; g.bias = w.att_b3;
+    g.A = ws.wmap1; g.lda = 128; g.nch = 1; g.kc = 128; g.W = w.att_w3; g.Wh = w.att_s3.hi; g.Wl = w.att_s3.lo; g.M = M; g.N = 64; g.bias = w.att_b3;
     g.out = ws.wmap2; g.ldo = 64;
     AOK(launch_f32_gemm(g, s));
   }

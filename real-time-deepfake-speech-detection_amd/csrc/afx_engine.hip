@@ -495,6 +495,7 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
     h->conf_bn_scale = w / sqrtf(v + kBnEps);
     h->conf_bn_shift = b - m * h->conf_bn_scale;
   } else if (h->cfg.arch == AFX_ARCH_XLSR_AASIST) {
+    h->aw.split = h->dt != AFX_DT_FP32;  // exact mode keeps the true-fp32 matrix instruction
     if (const char* m = aasist_finalize(
             h->aw, [&](const std::string& k) { return h->F(k); }, [&](size_t bytes) { return h->dalloc(bytes); }, s))
       return fail("afx_finalize: %s", m);
