@@ -226,6 +226,165 @@ __global__ __launch_bounds__(256) void f32s_gemm_kernel(F32GemmArgs p) {
   }
 }
 
+// ===================================================================================
+// The (2,3) / (1,3) / 1x1 convs of the residual encoder, LDS-staged.  f32_gemm_kernel / f32s_gemm_kernel fetch every
+// operand fragment straight from L2 in 64-byte pieces (16 rows x 64 B per load instruction) and every wave re-reads
+// the whole weight matrix: 230 MB of L2 traffic in fragment-shaped loads per conv -- that, not the matrix pipe, is what
+// they run at (the split-precision form cut the MFMA work 5x and the time by 7 %).  Here a persistent workgroup keeps
+// the split weights (hi | lo fp16, rows padded by 16 B) in LDS for its whole life and stages, per 64 output pixels, the
+// 2 x 66 input pixels they read (channel-last, so a (kh,3) conv reads kh contiguous runs of pixels) with coalesced
+// 16-byte loads, the next tile's pixels travelling through registers under the current tile's MFMAs.  A fragments come
+// from LDS (pixel rows padded by 16 B: conflict-free across the 16 rows of a fragment), are split hi / lo in
+// registers, and feed the same three MFMAs per block as f32s_gemm_kernel.
+// ===================================================================================
+constexpr int ACV_TM = 64;  // output pixels per workgroup step (4 waves x 16)
+template <int NT>
+__global__ __launch_bounds__(256) void aas_conv_kernel(F32GemmArgs p, int C, int taps, int cpo, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char acv_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  constexpr int N = NT * 16;
+  const int K = p.nch * p.kc, Kp = K + 8;            // halfs per weight row in LDS
+  const int Cp = C + 4, SP = ACV_TM + taps - 1;      // floats per pixel in LDS; pixels per slab
+  _Float16* wh = (_Float16*)acv_lds;                 // [N][Kp]
+  _Float16* wl = wh + (long)N * Kp;                  // [N][Kp]
+  float* slab = (float*)(wl + (long)N * Kp);         // [nch][SP][Cp]
+  // ---- weights: once per workgroup ---------------------------------------------------
+  for (int i = tid; i < N * (K / 8); i += 256) {
+    const int n = i / (K / 8), c8 = i % (K / 8);
+    *(h16x8*)(wh + (long)n * Kp + c8 * 8) = *(const h16x8*)(p.Wh + (long)n * K + c8 * 8);
+    *(h16x8*)(wl + (long)n * Kp + c8 * 8) = *(const h16x8*)(p.Wl + (long)n * K + c8 * 8);
+  }
+  // ---- slab staging: float4 pieces, piece j of a tile = (chunk, pixel, 4 channels) ----
+  const int c4 = C / 4, npiece = p.nch * SP * c4;
+  constexpr int PMAX = 10;  // pieces per thread (2 x 66 x 16 / 256 = 8.25 for C = 64; launcher checks)
+  const long last_pix = (long)p.M - 1 + (long)cpo * (p.nch - 1) + taps - 1;  // last pixel any valid row reads
+  f32x4 stage[PMAX];
+  auto fetch = [&](int tile) {
+    const long m0 = (long)tile * ACV_TM;
+#pragma unroll
+    for (int u = 0; u < PMAX; ++u) {
+      const int j = tid + u * 256;
+      if (j < npiece) {
+        const int ch = j / (SP * c4), rem = j % (SP * c4), px = rem / c4, cc = rem % c4;
+        long pix = m0 + (long)ch * cpo + px;
+        pix = pix < last_pix ? pix : last_pix;
+        stage[u] = *(const f32x4*)(p.A + pix * C + cc * 4);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < PMAX; ++u) {
+      const int j = tid + u * 256;
+      if (j < npiece) {
+        const int ch = j / (SP * c4), rem = j % (SP * c4), px = rem / c4, cc = rem % c4;
+        *(f32x4*)(slab + ((long)ch * SP + px) * Cp + cc * 4) = stage[u];
+      }
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();  // every wave is done with the previous slab (and, first time round, nothing)
+    commit();
+    __syncthreads();  // slab (and, first time round, the weights) visible
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);  // the next tile's pixels ride under this tile's MFMAs
+    f32x4 acc[NT], cor[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = cor[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lr = wave * 16 + r;
+    for (int ch = 0; ch < p.nch; ++ch)
+      for (int tp = 0; tp < taps; ++tp) {
+        const float* arow = slab + ((long)ch * SP + lr + tp) * Cp + kq * 8;
+        const int kbase = ch * p.kc + tp * C;
+        for (int c0 = 0; c0 < C; c0 += 32) {
+          const f32x4 x0 = *(const f32x4*)(arow + c0), x1 = *(const f32x4*)(arow + c0 + 4);
+          h16x8 bh[NT], bl[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const long wo = (long)(nt * 16 + r) * Kp + kbase + c0 + kq * 8;
+            bh[nt] = *(const h16x8*)(wh + wo);
+            bl[nt] = *(const h16x8*)(wl + wo);
+          }
+          h16x8 ah, al;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float v = i < 4 ? x0[i & 3] : x1[i & 3];
+            const _Float16 hi = (_Float16)v;
+            ah[i] = hi;
+            al[i] = (_Float16)((v - (float)hi) * 2048.0f);
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[nt], ah, acc[nt], 0, 0, 0);
+            cor[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[nt], ah, cor[nt], 0, 0, 0);
+            cor[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[nt], al, cor[nt], 0, 0, 0);
+          }
+        }
+      }
+    // epilogue: lane holds out[m = m0 + 16 wave + (lane&15)][n = 16 nt + 4 (lane>>4) + 0..3]
+    const long m = (long)tile * ACV_TM + lr;
+    if (m < p.M) {
+      bool valid = true;
+      if (p.img) {
+        const int pix = (int)(m % p.img);
+        valid = (pix / p.wp < p.hout) && (pix % p.wp < p.wd);
+      }
+      const long orow = (m + p.o_off) * p.ldo;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + kq * 4;
+        f32x4 v = acc[nt] + cor[nt] * (1.0f / 2048.0f);
+        if (p.bias) v += *(const f32x4*)(p.bias + n);
+        if (p.resid) v += *(const f32x4*)(p.resid + orow + n);
+        if (p.post == 1) {
+          const f32x4 sc = *(const f32x4*)(p.bn_scale + n), sh = *(const f32x4*)(p.bn_shift + n);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = selu(fmaf(v[i], sc[i], sh[i]));
+        } else if (p.post == 2) {
+          const f32x4 sc = *(const f32x4*)(p.bn_scale + n), sh = *(const f32x4*)(p.bn_shift + n);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fmaf(selu(v[i]), sc[i], sh[i]);
+        }
+        if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(p.out + orow + n) = v;
+      }
+    }
+  }
+}
+
+// launch the LDS-staged form when the shape allows it; false = not applicable (caller falls back)
+static bool try_launch_aas_conv(const F32GemmArgs& p, hipStream_t s, hipError_t* err) {
+  *err = hipSuccess;
+  if (!p.Wh || !p.Wl || p.lda <= 0 || p.lda % 32 || p.kc % p.lda || p.chunk_stride % p.lda) return false;
+  const int C = (int)p.lda, taps = p.kc / C, cpo = (int)(p.chunk_stride / C), K = p.nch * p.kc;
+  const int SP = ACV_TM + taps - 1;
+  const long lds = 2L * p.N * (K + 8) * 2 + (long)p.nch * SP * (C + 4) * 4;
+  if (lds > 160 * 1024 || (long)p.nch * SP * (C / 4) > 10 * 256) return false;
+  const int ntiles = (int)((p.M + ACV_TM - 1) / ACV_TM);
+  static int n_cu_of[kMaxDevices] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { *err = hipErrorInvalidDevice; return true; }
+  if (!n_cu_of[dev] && hipDeviceGetAttribute(&n_cu_of[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { *err = hipErrorUnknown; return true; }
+  const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
+  const int slots = n_cu_of[dev] * (per_cu < 1 ? 1 : per_cu);
+  dim3 grid(ntiles < slots ? ntiles : slots);
+  static LdsLimit lim[3];
+#define AFX_ACV(IDX, NTv)                                                                                 \
+  do {                                                                                                    \
+    *err = lim[IDX].ensure((const void*)aas_conv_kernel<NTv>, (int)lds);                                  \
+    if (*err == hipSuccess) hipLaunchKernelGGL(aas_conv_kernel<NTv>, grid, dim3(256), (size_t)lds, s, p, C, taps, cpo, ntiles); \
+  } while (0)
+  if (p.N == 32) AFX_ACV(0, 2);
+  else if (p.N == 64) AFX_ACV(1, 4);
+  else if (p.N == 128) AFX_ACV(2, 8);
+  else return false;
+#undef AFX_ACV
+  if (*err == hipSuccess) *err = hipGetLastError();
+  return true;
+}
+
 // fp32 weights -> (hi, 2^11-scaled lo) fp16 pair, once at load time
 __global__ void split_f16_kernel(const float* __restrict__ w, long n, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -246,6 +405,8 @@ static const char* launch_f32_gemm(const F32GemmArgs& p, hipStream_t s) {
   while (nt > 1 && row_waves * (p.N / (16 * nt)) < 1024) nt >>= 1;
   dim3 grid((unsigned)((p.M + 127) / 128), p.N / (16 * nt));
   if (p.Wh && p.Wl) {  // split-precision form on the fp16 matrix pipe
+    hipError_t ce;
+    if (try_launch_aas_conv(p, s, &ce)) return ce == hipSuccess ? nullptr : hipGetErrorString(ce);  // LDS-staged convs
     if (p.kc % 32 || (p.lda % 4) || (p.chunk_stride % 4)) return "aasist gemm (split precision): K chunks of 32, 16-B aligned rows";
     if (nt > 4) {  // 2 x NT x 2 accumulator tiles: keep the wave at 4 column tiles
       nt = 4;
