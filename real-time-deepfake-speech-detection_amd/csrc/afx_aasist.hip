@@ -237,93 +237,116 @@ __global__ __launch_bounds__(256) void f32s_gemm_kernel(F32GemmArgs p) {
 // from LDS (pixel rows padded by 16 B: conflict-free across the 16 rows of a fragment), are split hi / lo in
 // registers, and feed the same three MFMAs per block as f32s_gemm_kernel.
 // ===================================================================================
-constexpr int ACV_TM = 64;  // output pixels per workgroup step (4 waves x 16)
+constexpr int ACV_TM = 64;  // output pixels per workgroup step
+// 8 waves: wave w owns output pixels 16 (w & 3) .. +15 and the column half (w >> 2) of the N outputs, so every SIMD
+// holds two waves (one workgroup per CU: the weights of the 64 -> 64 (2,3) conv are 100 KB of LDS).  The staged pixels
+// are split into their fp16 hi / lo halves ONCE, while they are written to LDS (each is then read by kh x 3 taps and
+// two column waves): the inner loop is LDS fragment reads and MFMAs only.
 template <int NT>
-__global__ __launch_bounds__(256) void aas_conv_kernel(F32GemmArgs p, int C, int taps, int cpo, int ntiles) {
+__global__ __launch_bounds__(512) void aas_conv_kernel(F32GemmArgs p, int C, int taps, int cpo, int ntiles) {
+  static_assert(NT % 2 == 0, "two column halves");
+  constexpr int NTW = NT / 2;  // 16-column tiles per wave
   extern __shared__ __attribute__((aligned(16))) char acv_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
   constexpr int N = NT * 16;
-  const int K = p.nch * p.kc, Kp = K + 8;            // halfs per weight row in LDS
-  const int Cp = C + 4, SP = ACV_TM + taps - 1;      // floats per pixel in LDS; pixels per slab
+  const int K = p.nch * p.kc, Kp = K + 8;            // halfs per weight row in LDS (16 B of padding)
+  const int Cp = C + 8, SP = ACV_TM + taps - 1;      // halfs per pixel in LDS (16 B of padding); pixels per slab
   _Float16* wh = (_Float16*)acv_lds;                 // [N][Kp]
   _Float16* wl = wh + (long)N * Kp;                  // [N][Kp]
-  float* slab = (float*)(wl + (long)N * Kp);         // [nch][SP][Cp]
+  _Float16* sh = wl + (long)N * Kp;                  // [nch][SP][Cp]  hi halves of the staged pixels
+  _Float16* sl = sh + (long)p.nch * SP * Cp;         // [nch][SP][Cp]  lo halves (scaled by 2^11)
   // ---- weights: once per workgroup ---------------------------------------------------
-  for (int i = tid; i < N * (K / 8); i += 256) {
+  for (int i = tid; i < N * (K / 8); i += 512) {
     const int n = i / (K / 8), c8 = i % (K / 8);
     *(h16x8*)(wh + (long)n * Kp + c8 * 8) = *(const h16x8*)(p.Wh + (long)n * K + c8 * 8);
     *(h16x8*)(wl + (long)n * Kp + c8 * 8) = *(const h16x8*)(p.Wl + (long)n * K + c8 * 8);
   }
-  // ---- slab staging: float4 pieces, piece j of a tile = (chunk, pixel, 4 channels) ----
+  // ---- staging plan: piece j = (chunk, pixel, 4 channels); the plan does not depend on the tile ----
   const int c4 = C / 4, npiece = p.nch * SP * c4;
-  constexpr int PMAX = 10;  // pieces per thread (2 x 66 x 16 / 256 = 8.25 for C = 64; launcher checks)
+  constexpr int PMAX = 5;  // pieces per thread (2 x 66 x 16 / 512 = 4.1 for C = 64; the launcher checks)
+  int src_rel[PMAX], dst_off[PMAX];  // source: float offset relative to pixel m0; destination: half offset in sh / sl
+  long lim_rel[PMAX];
   const long last_pix = (long)p.M - 1 + (long)cpo * (p.nch - 1) + taps - 1;  // last pixel any valid row reads
+#pragma unroll
+  for (int u = 0; u < PMAX; ++u) {
+    const int j = tid + u * 512;
+    const int jj = j < npiece ? j : 0;
+    const int ch = jj / (SP * c4), rem = jj % (SP * c4), px = rem / c4, cc = rem % c4;
+    src_rel[u] = ch * cpo + px;  // pixels past m0
+    lim_rel[u] = cc * 4;
+    dst_off[u] = j < npiece ? (ch * SP + px) * Cp + cc * 4 : -1;
+  }
   f32x4 stage[PMAX];
   auto fetch = [&](int tile) {
     const long m0 = (long)tile * ACV_TM;
 #pragma unroll
-    for (int u = 0; u < PMAX; ++u) {
-      const int j = tid + u * 256;
-      if (j < npiece) {
-        const int ch = j / (SP * c4), rem = j % (SP * c4), px = rem / c4, cc = rem % c4;
-        long pix = m0 + (long)ch * cpo + px;
+    for (int u = 0; u < PMAX; ++u)
+      if (dst_off[u] >= 0) {
+        long pix = m0 + src_rel[u];
         pix = pix < last_pix ? pix : last_pix;
-        stage[u] = *(const f32x4*)(p.A + pix * C + cc * 4);
+        stage[u] = *(const f32x4*)(p.A + pix * C + lim_rel[u]);
       }
-    }
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int u = 0; u < PMAX; ++u) {
-      const int j = tid + u * 256;
-      if (j < npiece) {
-        const int ch = j / (SP * c4), rem = j % (SP * c4), px = rem / c4, cc = rem % c4;
-        *(f32x4*)(slab + ((long)ch * SP + px) * Cp + cc * 4) = stage[u];
+    for (int u = 0; u < PMAX; ++u)
+      if (dst_off[u] >= 0) {
+        typedef __attribute__((ext_vector_type(4))) _Float16 h16x4;
+        h16x4 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = stage[u][i];
+          hi[i] = (_Float16)v;
+          lo[i] = (_Float16)((v - (float)hi[i]) * 2048.0f);
+        }
+        *(h16x4*)(sh + dst_off[u]) = hi;
+        *(h16x4*)(sl + dst_off[u]) = lo;
       }
-    }
   };
+  // per-column vectors of this lane's outputs (n = 16 (col half, nt) + 4 kq + 0..3): loaded once
+  const int nbase = (wave >> 2) * NTW * 16;
+  f32x4 vb[NTW], vsc[NTW], vsh[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int n = nbase + nt * 16 + kq * 4;
+    vb[nt] = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    vsc[nt] = p.post ? *(const f32x4*)(p.bn_scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+    vsh[nt] = p.post ? *(const f32x4*)(p.bn_shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   int tile = blockIdx.x;
   if (tile < ntiles) fetch(tile);
+  const int lr = (wave & 3) * 16 + r;
   for (; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();  // every wave is done with the previous slab (and, first time round, nothing)
+    __syncthreads();  // every wave is done with the previous slab
     commit();
     __syncthreads();  // slab (and, first time round, the weights) visible
     if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);  // the next tile's pixels ride under this tile's MFMAs
-    f32x4 acc[NT], cor[NT];
+    f32x4 acc[NTW], cor[NTW];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = cor[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int lr = wave * 16 + r;
+    for (int nt = 0; nt < NTW; ++nt) acc[nt] = cor[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int ch = 0; ch < p.nch; ++ch)
       for (int tp = 0; tp < taps; ++tp) {
-        const float* arow = slab + ((long)ch * SP + lr + tp) * Cp + kq * 8;
+        const long ao = ((long)ch * SP + lr + tp) * Cp + kq * 8;
         const int kbase = ch * p.kc + tp * C;
         for (int c0 = 0; c0 < C; c0 += 32) {
-          const f32x4 x0 = *(const f32x4*)(arow + c0), x1 = *(const f32x4*)(arow + c0 + 4);
-          h16x8 bh[NT], bl[NT];
+          const h16x8 ah = *(const h16x8*)(sh + ao + c0), al = *(const h16x8*)(sl + ao + c0);
+          h16x8 bh[NTW], bl[NTW];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const long wo = (long)(nt * 16 + r) * Kp + kbase + c0 + kq * 8;
+          for (int nt = 0; nt < NTW; ++nt) {
+            const long wo = (long)(nbase + nt * 16 + r) * Kp + kbase + c0 + kq * 8;
             bh[nt] = *(const h16x8*)(wh + wo);
             bl[nt] = *(const h16x8*)(wl + wo);
           }
-          h16x8 ah, al;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float v = i < 4 ? x0[i & 3] : x1[i & 3];
-            const _Float16 hi = (_Float16)v;
-            ah[i] = hi;
-            al[i] = (_Float16)((v - (float)hi) * 2048.0f);
-          }
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
+          for (int nt = 0; nt < NTW; ++nt) {
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[nt], ah, acc[nt], 0, 0, 0);
             cor[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[nt], ah, cor[nt], 0, 0, 0);
             cor[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[nt], al, cor[nt], 0, 0, 0);
           }
         }
       }
-    // epilogue: lane holds out[m = m0 + 16 wave + (lane&15)][n = 16 nt + 4 (lane>>4) + 0..3]
+    // epilogue: lane holds out[m = m0 + 16 (wave & 3) + (lane&15)][n = nbase + 16 nt + 4 (lane>>4) + 0..3]
     const long m = (long)tile * ACV_TM + lr;
     if (m < p.M) {
       bool valid = true;
@@ -332,20 +355,22 @@ __global__ __launch_bounds__(256) void aas_conv_kernel(F32GemmArgs p, int C, int
         valid = (pix / p.wp < p.hout) && (pix % p.wp < p.wd);
       }
       const long orow = (m + p.o_off) * p.ldo;
+      f32x4 res[NTW];
+      if (p.resid) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int n = nt * 16 + kq * 4;
-        f32x4 v = acc[nt] + cor[nt] * (1.0f / 2048.0f);
-        if (p.bias) v += *(const f32x4*)(p.bias + n);
-        if (p.resid) v += *(const f32x4*)(p.resid + orow + n);
+        for (int nt = 0; nt < NTW; ++nt) res[nt] = *(const f32x4*)(p.resid + orow + nbase + nt * 16 + kq * 4);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int n = nbase + nt * 16 + kq * 4;
+        f32x4 v = acc[nt] + cor[nt] * (1.0f / 2048.0f) + vb[nt];
+        if (p.resid) v += res[nt];
         if (p.post == 1) {
-          const f32x4 sc = *(const f32x4*)(p.bn_scale + n), sh = *(const f32x4*)(p.bn_shift + n);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = selu(fmaf(v[i], sc[i], sh[i]));
+          for (int i = 0; i < 4; ++i) v[i] = selu(fmaf(v[i], vsc[nt][i], vsh[nt][i]));
         } else if (p.post == 2) {
-          const f32x4 sc = *(const f32x4*)(p.bn_scale + n), sh = *(const f32x4*)(p.bn_shift + n);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = fmaf(selu(v[i]), sc[i], sh[i]);
+          for (int i = 0; i < 4; ++i) v[i] = fmaf(selu(v[i]), vsc[nt][i], vsh[nt][i]);
         }
         if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
         *(f32x4*)(p.out + orow + n) = v;
@@ -360,21 +385,21 @@ static bool try_launch_aas_conv(const F32GemmArgs& p, hipStream_t s, hipError_t*
   if (!p.Wh || !p.Wl || p.lda <= 0 || p.lda % 32 || p.kc % p.lda || p.chunk_stride % p.lda) return false;
   const int C = (int)p.lda, taps = p.kc / C, cpo = (int)(p.chunk_stride / C), K = p.nch * p.kc;
   const int SP = ACV_TM + taps - 1;
-  const long lds = 2L * p.N * (K + 8) * 2 + (long)p.nch * SP * (C + 4) * 4;
-  if (lds > 160 * 1024 || (long)p.nch * SP * (C / 4) > 10 * 256) return false;
+  const long lds = 2L * p.N * (K + 8) * 2 + 2L * p.nch * SP * (C + 8) * 2;
+  if (lds > 160 * 1024 || (long)p.nch * SP * (C / 4) > 5 * 512) return false;
   const int ntiles = (int)((p.M + ACV_TM - 1) / ACV_TM);
   static int n_cu_of[kMaxDevices] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { *err = hipErrorInvalidDevice; return true; }
   if (!n_cu_of[dev] && hipDeviceGetAttribute(&n_cu_of[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { *err = hipErrorUnknown; return true; }
-  const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
+  const int per_cu = (int)((160 * 1024) / lds) > 2 ? 2 : (int)((160 * 1024) / lds);  // 512-thread workgroups
   const int slots = n_cu_of[dev] * (per_cu < 1 ? 1 : per_cu);
   dim3 grid(ntiles < slots ? ntiles : slots);
   static LdsLimit lim[3];
 #define AFX_ACV(IDX, NTv)                                                                                 \
   do {                                                                                                    \
     *err = lim[IDX].ensure((const void*)aas_conv_kernel<NTv>, (int)lds);                                  \
-    if (*err == hipSuccess) hipLaunchKernelGGL(aas_conv_kernel<NTv>, grid, dim3(256), (size_t)lds, s, p, C, taps, cpo, ntiles); \
+    if (*err == hipSuccess) hipLaunchKernelGGL(aas_conv_kernel<NTv>, grid, dim3(512), (size_t)lds, s, p, C, taps, cpo, ntiles); \
   } while (0)
   if (p.N == 32) AFX_ACV(0, 2);
   else if (p.N == 64) AFX_ACV(1, 4);
