@@ -256,11 +256,29 @@ __global__ __launch_bounds__(512) void aas_conv_kernel(F32GemmArgs p, int C, int
   _Float16* wl = wh + (long)N * Kp;                  // [N][Kp]
   _Float16* sh = wl + (long)N * Kp;                  // [nch][SP][Cp]  hi halves of the staged pixels
   _Float16* sl = sh + (long)p.nch * SP * Cp;         // [nch][SP][Cp]  lo halves (scaled by 2^11)
-  // ---- weights: once per workgroup ---------------------------------------------------
-  for (int i = tid; i < N * (K / 8); i += 512) {
-    const int n = i / (K / 8), c8 = i % (K / 8);
-    *(h16x8*)(wh + (long)n * Kp + c8 * 8) = *(const h16x8*)(p.Wh + (long)n * K + c8 * 8);
-    *(h16x8*)(wl + (long)n * Kp + c8 * 8) = *(const h16x8*)(p.Wl + (long)n * K + c8 * 8);
+  // ---- weights: once per workgroup; ALL of a thread's loads go out before its first LDS write (left as a plain
+  // loop the copy was six dependent L2 round trips: a third of the kernel's time at three tiles per workgroup) -------
+  {
+    constexpr int WPMAX = 6;  // 16-byte pieces per thread and array (64 x 384 / 8 / 512 = 6; the launcher checks)
+    h16x8 th[WPMAX], tl[WPMAX];
+    const int npw = N * (K / 8);
+#pragma unroll
+    for (int u = 0; u < WPMAX; ++u) {
+      const int i = tid + u * 512;
+      if (i < npw) {
+        th[u] = *(const h16x8*)(p.Wh + (long)i * 8);
+        tl[u] = *(const h16x8*)(p.Wl + (long)i * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < WPMAX; ++u) {
+      const int i = tid + u * 512;
+      if (i < npw) {
+        const int n = i / (K / 8), c8 = i % (K / 8);
+        *(h16x8*)(wh + (long)n * Kp + c8 * 8) = th[u];
+        *(h16x8*)(wl + (long)n * Kp + c8 * 8) = tl[u];
+      }
+    }
   }
   // ---- staging plan: piece j = (chunk, pixel, 4 channels); the plan does not depend on the tile ----
   const int c4 = C / 4, npiece = p.nch * SP * c4;
@@ -321,7 +339,15 @@ __global__ __launch_bounds__(512) void aas_conv_kernel(F32GemmArgs p, int C, int
     __syncthreads();  // every wave is done with the previous slab
     commit();
     __syncthreads();  // slab (and, first time round, the weights) visible
-    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);  // the next tile's pixels ride under this tile's MFMAs
+    // this tile's residual rows and the next tile's pixels are requested now and ride under this tile's MFMAs
+    const long m = (long)tile * ACV_TM + lr;
+    const long orow = ((m < p.M ? m : (long)p.M - 1) + p.o_off) * p.ldo;
+    f32x4 res[NTW];
+    if (p.resid) {
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) res[nt] = *(const f32x4*)(p.resid + orow + nbase + nt * 16 + kq * 4);
+    }
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
     f32x4 acc[NTW], cor[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) acc[nt] = cor[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -347,18 +373,11 @@ __global__ __launch_bounds__(512) void aas_conv_kernel(F32GemmArgs p, int C, int
         }
       }
     // epilogue: lane holds out[m = m0 + 16 (wave & 3) + (lane&15)][n = nbase + 16 nt + 4 (lane>>4) + 0..3]
-    const long m = (long)tile * ACV_TM + lr;
     if (m < p.M) {
       bool valid = true;
       if (p.img) {
         const int pix = (int)(m % p.img);
         valid = (pix / p.wp < p.hout) && (pix % p.wp < p.wd);
-      }
-      const long orow = (m + p.o_off) * p.ldo;
-      f32x4 res[NTW];
-      if (p.resid) {
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) res[nt] = *(const f32x4*)(p.resid + orow + nbase + nt * 16 + kq * 4);
       }
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
@@ -386,7 +405,7 @@ static bool try_launch_aas_conv(const F32GemmArgs& p, hipStream_t s, hipError_t*
   const int C = (int)p.lda, taps = p.kc / C, cpo = (int)(p.chunk_stride / C), K = p.nch * p.kc;
   const int SP = ACV_TM + taps - 1;
   const long lds = 2L * p.N * (K + 8) * 2 + 2L * p.nch * SP * (C + 8) * 2;
-  if (lds > 160 * 1024 || (long)p.nch * SP * (C / 4) > 5 * 512) return false;
+  if (lds > 160 * 1024 || (long)p.nch * SP * (C / 4) > 5 * 512 || (long)p.N * (K / 8) > 6 * 512) return false;
   const int ntiles = (int)((p.M + ACV_TM - 1) / ACV_TM);
   static int n_cu_of[kMaxDevices] = {0};
   int dev = 0;
