@@ -480,17 +480,45 @@ static const char* launch_f32_gemm(const F32GemmArgs& p, hipStream_t s) {
 // models/xlsr_aasist.py:92-96: (B,T,128) -> transpose -> max_pool2d(3,3) -> BN2d(1) -> SELU,
 // written as a 1-channel padded image.
 __global__ void pool_bn_selu_kernel(const float* __restrict__ ll, int T, int wd, int wp, int img, float sc, float sh,
-                                    float* __restrict__ out) {
+                                    float* __restrict__ out, int B, int tail, float* __restrict__ za, float* __restrict__ zb,
+                                    float* __restrict__ zc, int head) {
+  // Writes EVERY pixel of the 1-channel padded image (zeros on the border), so nothing has to be cleared first; the
+  // extra grid row y == B zeroes the slack behind the last image and the heads of the three multi-channel images.
   const int b = blockIdx.y;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= AAS_F * wd) return;
-  const int fi = idx / wd, ti = idx % wd;
-  float m = -INFINITY;
+  if (b == B) {
+    const int step = gridDim.x * blockDim.x;
+    for (int i = idx; i < tail; i += step) out[(long)B * img + i] = 0.f;
+    for (int i = idx; i < head; i += step) {
+      za[i] = 0.f;
+      zb[i] = 0.f;
+      zc[i] = 0.f;
+    }
+    return;
+  }
+  if (idx >= img) return;
+  const int h = idx / wp, wq = idx % wp;
+  float v = 0.f;
+  if (h >= 1 && h <= AAS_F && wq >= 1 && wq <= wd) {
+    const int fi = h - 1, ti = wq - 1;
+    float m = -INFINITY;
 #pragma unroll
-  for (int dt = 0; dt < 3; ++dt)
+    for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
-    for (int df = 0; df < 3; ++df) m = fmaxf(m, ll[((long)b * T + ti * 3 + dt) * 128 + fi * 3 + df]);
-  out[(long)b * img + (fi + 1) * wp + ti + 1] = selu(fmaf(m, sc, sh));
+      for (int df = 0; df < 3; ++df) m = fmaxf(m, ll[((long)b * T + ti * 3 + dt) * 128 + fi * 3 + df]);
+    v = selu(fmaf(m, sc, sh));
+  }
+  out[(long)b * img + idx] = v;
+}
+
+// zero the first `n` floats of three buffers in one launch (image heads when the channel-last layout widens)
+__global__ void zero3_kernel(float* __restrict__ a, float* __restrict__ b, float* __restrict__ c, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    a[i] = 0.f;
+    b[i] = 0.f;
+    c[i] = 0.f;
+  }
 }
 
 // first residual block (Cin = 1): conv1 (2,3) pad (1,1) -> bn2 -> selu into Y (43 rows) and
@@ -961,7 +989,6 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
   if (wd < 2) return "aasist: clip too short (need at least 6 SSL frames)";
   if (wd > 630) return "aasist: clip too long for the graph kernels (about 37 s: T <= 1890 frames)";
   const int M = B * img;
-  const size_t pixbytes = ((size_t)M + 3 * (size_t)wp + 16) * 4;
   // ---- LL: (B*T,1024) x [128][1024] on the fp32 matrix cores ------------------------
   {
     F32GemmArgs g;
@@ -976,14 +1003,10 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
   // where they fall in the padding -- that re-creates the border), so of each image just the first padded row + 1
   // pixel; rows past M+wp+1 are read by invalid (masked-by-assignment) outputs only.  (Round 1 cleared 3 x 12.8 MB
   // per forward here.)
-  const size_t head_bytes = (size_t)(wp + 1) * 64 * 4;  // first padded row + 1 pixel, 64 channels
-  HOK(hipMemsetAsync(ws.imgA, 0, head_bytes, s));
-  HOK(hipMemsetAsync(ws.imgB, 0, head_bytes, s));
-  HOK(hipMemsetAsync(ws.imgC, 0, head_bytes, s));
+  const int head = (wp + 1) * 64;  // first padded row + 1 pixel, 64 channels (floats)
   float* x1 = ws.wmap2;  // 1-channel image borrowed from a later buffer
-  HOK(hipMemsetAsync(x1, 0, pixbytes, s));
-  hipLaunchKernelGGL(pool_bn_selu_kernel, dim3((AAS_F * wd + 255) / 256, B), dim3(256), 0, s, ws.ll, T, wd, wp, img,
-                     w.bn0_scale, w.bn0_shift, x1);
+  hipLaunchKernelGGL(pool_bn_selu_kernel, dim3((img + 255) / 256, B + 1), dim3(256), 0, s, ws.ll, T, wd, wp, img,
+                     w.bn0_scale, w.bn0_shift, x1, B, 3 * wp + 16, ws.imgA, ws.imgB, ws.imgC, head);
   // ---- residual encoder ----------------------------------------------------------------
   {  // block 0 (Cin = 1): conv1+bn2+selu -> Y, downsample -> D, conv2(Y) + D -> X
     const AasistWeights::Block& K = w.blk[0];
@@ -999,10 +1022,6 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
   }
   for (int i = 1; i < 6; ++i) {
     const AasistWeights::Block& K = w.blk[i];
-    if (K.cin != K.cout) {  // Y and D switch to the wider channel-last layout: re-zero their borders
-      HOK(hipMemsetAsync(Y, 0, head_bytes, s));
-      HOK(hipMemsetAsync(D, 0, head_bytes, s));
-    }
     F32GemmArgs g;
     memset(&g, 0, sizeof g);  // conv1 (pad (1,1)) on X -> bn2 -> selu -> Y, 43 rows
     g.A = X; g.lda = K.cin; g.nch = 2; g.kc = 3 * K.cin; g.chunk_stride = (long)wp * K.cin;
@@ -1016,9 +1035,10 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
       g.bias = K.bd; g.img = img; g.wp = wp; g.hout = AAS_F; g.wd = wd; g.out = D; g.ldo = K.cout; g.o_off = wp + 1;
       AOK(launch_f32_gemm(g, s));
       resid = D;
-      // X is about to be re-used with cout channels per pixel: its first padded row + 1
-      // pixel are never touched by the shifted store and still hold cin-channel data
-      HOK(hipMemsetAsync(X, 0, head_bytes, s));
+      // X, Y and D switch to cout channels per pixel: the first padded row + 1 pixel of each is never touched by the
+      // shifted stores (conv1 -> Y and the downsample -> D above wrote from pixel wp+1 on) and still holds cin-channel
+      // data; X's may go only now that both convs have read it
+      if (K.cin != K.cout) hipLaunchKernelGGL(zero3_kernel, dim3((head + 255) / 256), dim3(256), 0, s, X, Y, D, head);
     }
     // conv2 (pad (0,1)) on Y + residual, written over X (each element is read, as the
     // residual, by the same thread that then overwrites it)

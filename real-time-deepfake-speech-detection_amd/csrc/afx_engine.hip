@@ -1306,6 +1306,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
     gemm_set_split(value);
     return 0;
   }
+  if (!strcmp(key, "gemm_fit")) {
+    gemm_set_fit(value);
+    return 0;
+  }
   if (!strcmp(key, "mhsa_force_long")) {
     mhsa_set_force_long(value);
     return 0;

@@ -528,7 +528,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 //        were retired before the reading phase's first barrier (B0: ph1 reads are issued
 //        first and retired by lgkmcnt(8) there -> staged in ph2).
 // =======================================================================================
-template <class HT, int BM, int BN, bool ROWLN>
+// MF (256x256 instance only) = 16-row fragments a wave row actually computes, 5..8: the tile then covers 32*MF rows
+// (160 / 192 / 224 / 256) of the SAME LDS layout -- half-tile slots stay 64 rows per wave row, the first
+// MF0 = ceil(MF/2) / MF1 = MF - MF0 fragments of them are live, the other slots receive clamped duplicate rows nobody
+// reads.  The launcher picks the height whose tile count fills ONE round of the CUs (M = 64 x 199 rows, N = 1024:
+// 228 tiles of 224 rows instead of 200 of 256; M = 16 x 199, N = 3072: 240 tiles of 160 rows instead of 156), so a
+// sub-round product pays 7/8 or 5/8 of the K-loop instead of idling a fifth to a third of the chip.  Per-row results
+// do not depend on the height (same K order).
+template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32>
 __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
@@ -550,6 +557,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   constexpr int BUF = 2 * (RA + RB) * 128;
   static_assert((WIDE ? MTH : NTH) * KSN == 4 && (WIDE ? NTH : MTH) * KSN == 8, "resident operand: 4 reads per half, flowing: 8");
   static_assert(2 * (WIDE ? DA : DB) + (WIDE ? DB : DA) == 6, "vmcnt(6) leaves R0, F0, R1 of tile t+2 in flight");
+  static_assert(MF == BM / 32 || (!WIDE && !ROWLN && MF >= 5 && MF < 8), "short tiles: the 256x256 instance only");
+  constexpr int MF0 = WIDE ? MTH : (MF + 1) / 2, MF1 = WIDE ? MTH : MF - MF0;  // live fragments of A half 0 / 1
+  constexpr int BMC = (MF0 + MF1) * 32;                                       // rows the tile covers
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -558,7 +568,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   const int g = blockIdx.z;
   const T* Ag = (const T*)p.A + (long)g * p.g_a;
   const T* Wg = (const T*)p.W + (long)g * p.g_w;
-  const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
+  const int nN = (p.N + BN - 1) / BN, nM = (p.M + BMC - 1) / BMC;
   const int nwg = nM * nN;
   const int nk = p.K >> 6;
 
@@ -590,7 +600,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
       pm = L / nN;
       pn = L % nN;
     }
-    m0 = pm * BM;
+    m0 = pm * BMC;
     n0 = pn * BN;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
       for (int i = 0; i < DA; ++i) {
         const int r = (i * 8 + wave) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        int m = m0 + (r / (RA / 2)) * (BM / 2) + h * (RA / 2) + r % (RA / 2);
+        int m = m0 + (r / (RA / 2)) * (BMC / 2) + h * (MF0 * FR) + r % (RA / 2);
         m = m < p.M ? m : p.M - 1;
         srcA[h][i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
       }
@@ -637,16 +647,18 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   const char* aR = smem + (wr * (RA / 2) + frow) * 128;
   const char* bR = smem + (wc * (RB / 4) + frow) * 128;
 
-  f32x4 acc[2 * MTH][2 * NTH];
+  f32x4 acc[MF0 + MF1][2 * NTH];
   // the resident operand keeps both halves in registers, the flowing one a single half
   V8 af[WIDE ? 2 : 1][MTH][KSN], wf[WIDE ? 1 : 2][NTH][KSN];
 
   auto readA = [&](int buf, int h) {
 #pragma unroll
     for (int mi = 0; mi < MTH; ++mi)
+      if (mi < (h ? MF1 : MF0)) {
 #pragma unroll
-      for (int ks = 0; ks < KSN; ++ks)
-        af[WIDE ? h : 0][mi][ks] = *(const V8*)(aR + buf * BUF + (h ? OFF_A1 : OFF_A0) + mi * (FR * 128) + slot[ks]);
+        for (int ks = 0; ks < KSN; ++ks)
+          af[WIDE ? h : 0][mi][ks] = *(const V8*)(aR + buf * BUF + (h ? OFF_A1 : OFF_A0) + mi * (FR * 128) + slot[ks]);
+      }
   };
   auto readB = [&](int buf, int h) {
 #pragma unroll
@@ -661,10 +673,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     for (int ks = 0; ks < KSN; ++ks)
 #pragma unroll
       for (int mi = 0; mi < MTH; ++mi)
+        if (mi < (ah ? MF1 : MF0)) {
 #pragma unroll
-        for (int nj = 0; nj < NTH; ++nj) {
-          acc[ah * MTH + mi][bh * NTH + nj] =
-              HT::mfma(wf[WIDE ? 0 : bh][nj][ks], af[WIDE ? ah : 0][mi][ks], acc[ah * MTH + mi][bh * NTH + nj]);
+          for (int nj = 0; nj < NTH; ++nj) {
+            acc[ah * MF0 + mi][bh * NTH + nj] =
+                HT::mfma(wf[WIDE ? 0 : bh][nj][ks], af[WIDE ? ah : 0][mi][ks], acc[ah * MF0 + mi][bh * NTH + nj]);
+          }
         }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -705,7 +719,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     readF(b, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (more1) stageF(1, b ^ 1, t + 1);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the R0 reads (issued first) are done: R0 may be re-staged next phase
+    // the R0 reads (issued first) are done -- all but the F0 reads behind them: R0 may be re-staged next phase
+    if constexpr ((WIDE ? NTH : MF0) * KSN == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    else if constexpr ((WIDE ? NTH : MF0) * KSN == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     AFX_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     quadFR(0, 0);
@@ -752,7 +769,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     AFX_BAR();
     if (wr == 1) AFX_BAR();  // the second wave row runs one barrier behind the first
 #pragma unroll
-    for (int i = 0; i < 2 * MTH; ++i)
+    for (int i = 0; i < MF0 + MF1; ++i)
 #pragma unroll
       for (int j = 0; j < 2 * NTH; ++j) acc[i][j] = 0.f;
     for (int t = 0; t < nk; t += 2) {
@@ -771,13 +788,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     }
     if (AFX_DBG(p, 64)) {  // timing only: no epilogue at all
 #pragma unroll
-      for (int i = 0; i < 2 * MTH; ++i)
+      for (int i = 0; i < MF0 + MF1; ++i)
 #pragma unroll
         for (int j = 0; j < 2 * NTH; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) asm volatile("" :: "v"(acc[i][j][r]));
     } else {
-      gemm_epilogue<HT, BM, BN, 2, 4, ROWLN, true>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
+      gemm_epilogue<HT, BMC, BN, 2, 4, ROWLN, true>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
     }
     if (vn >= nwg) break;
     v = vn;
@@ -785,12 +802,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 #undef AFX_BAR
 }
 
-template <class HT, int BM, int BN, bool ROWLN>
+template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32>
 static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static_assert(lds <= 160 * 1024, "two K-tile buffers must fit the 160 KB LDS");
   static LdsLimit lim;
-  if (hipError_t e = lim.ensure((const void*)gemm8_kernel<HT, BM, BN, ROWLN>, lds); e != hipSuccess) return e;
+  if (hipError_t e = lim.ensure((const void*)gemm8_kernel<HT, BM, BN, ROWLN, MF>, lds); e != hipSuccess) return e;
   static int n_cu_of[kMaxDevices] = {0};  // (benign if two threads fill the same slot: same value)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
@@ -801,9 +818,9 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
     n_cu_of[dev] = cus < 8 ? 8 : cus;
   }
   const int n_cu = n_cu_of[dev];
-  const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+  const int tiles = ((p.N + BN - 1) / BN) * ((p.M + MF * 32 - 1) / (MF * 32));
   dim3 grid(tiles < n_cu ? tiles : n_cu, 1, groups);  // persistent: at most one workgroup per CU
-  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN>), grid, dim3(512), lds, s, p);
+  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN, MF>), grid, dim3(512), lds, s, p);
   return hipGetLastError();
 }
 
@@ -878,6 +895,28 @@ static int gemm_split_rows(const GemmArgs& p, int groups) {
   return (int)(nM1 * 256);
 }
 
+// Height of the 8-phase 256-wide tile for a product that is NOT round-split: fragments per wave row (8 = 256 rows).
+// Cost model: rounds x (MF + 2) -- a round's K-loop scales with MF, prologue + epilogue are about two fragments' worth.
+static int g_fit = 1;  // A/B knob: 0 = always 256 rows, 1 = fitted, 5..8 = forced
+void gemm_set_fit(int v) { g_fit = v; }
+static int gemm8_fit_mf(const GemmArgs& p) {
+  constexpr long kCUs = 256;
+  if (!g_fit) return 8;
+  if (g_fit >= 5 && g_fit <= 8) return g_fit;
+  const long nN = (p.N + 255) / 256;
+  int best = 8;
+  long best_cost = 0;
+  for (int mf = 8; mf >= 5; --mf) {
+    const long tiles = nN * ((p.M + mf * 32 - 1) / (mf * 32));
+    const long cost = ((tiles + kCUs - 1) / kCUs) * (mf + 2);
+    if (mf == 8 || cost < best_cost) {
+      best = mf;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
 int gemm_tile_of(const GemmArgs& p, int groups) {
   if (p.ln_gamma) return g_deep != 0 && p.kchunk == p.K ? 8 : 3;
   if (gemm_is_narrow(p.N)) return 1;
@@ -907,6 +946,9 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
     case 7: return launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
+    case 75: return launch_gemm8_t<HT, 256, 256, false, 5>(p, groups, s);
+    case 76: return launch_gemm8_t<HT, 256, 256, false, 6>(p, groups, s);
+    case 77: return launch_gemm8_t<HT, 256, 256, false, 7>(p, groups, s);
     case 8: return launch_gemm8_t<HT, 128, 512, true>(p, groups, s);
     default: return lean ? launch_gemm_t<HT, 128, 128, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
   }
@@ -935,6 +977,10 @@ const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t
     hipError_t err = dtype == DT_BF16 ? dispatch<BF16>(a, 7, groups, s) : dispatch<FP16>(a, 7, groups, s);
     if (err == hipSuccess) err = dtype == DT_BF16 ? dispatch<BF16>(b, 0, groups, s) : dispatch<FP16>(b, 0, groups, s);
     return err == hipSuccess ? nullptr : hipGetErrorString(err);
+  }
+  if (tile == 7) {
+    const int mf = gemm8_fit_mf(p);
+    if (mf < 8) tile = 70 + mf;
   }
   const hipError_t err = dtype == DT_BF16 ? dispatch<BF16>(p, tile, groups, s) : dispatch<FP16>(p, tile, groups, s);
   return err == hipSuccess ? nullptr : hipGetErrorString(err);

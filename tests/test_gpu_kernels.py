@@ -101,6 +101,32 @@ def test_gemm_8phase_kernel_is_bit_identical_to_the_2stage_kernel(K, M, N, K_):
         check(lib().afx_debug_set(b"gemm_tile", -1))
 
 
+@pytest.mark.parametrize("M,N,K_", [(12736, 1024, 1024), (3184, 3072, 1024), (3184, 4096, 1024), (1000, 768, 64), (447, 512, 192)])
+def test_gemm_8phase_short_tiles_are_bit_identical(K, M, N, K_):
+    """Tile heights 160 / 192 / 224 / 256 of the 8-phase kernel (the launcher fits the height to one round of the
+    CUs): same LDS layout, fewer live fragments per wave row -- every height, forced and fitted, must reproduce the
+    2-stage kernel bit for bit (fp32 and fp16 outputs, residual, ragged last tile), over repeated launches."""
+    from afx._lib import check, lib
+    g = torch.Generator().manual_seed(K_ + M + N)
+    A = torch.randn(M, K_, generator=g).half().cuda()
+    W = (torch.randn(N, K_, generator=g) / math.sqrt(K_)).half().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).cuda()
+    try:
+        check(lib().afx_debug_set(b"gemm_tile", 0))
+        want_f, want_h = K.gemm("fp16", A, W, bias=bias, resid=R, out_f=True, out_h=True)
+        _close(want_f, A.float().cpu() @ W.float().cpu().t() + bias.cpu() + R.cpu(), 1e-4, 2e-4)
+        check(lib().afx_debug_set(b"gemm_tile", 3))
+        for fit in (5, 6, 7, 8, 1):
+            check(lib().afx_debug_set(b"gemm_fit", fit))
+            for _ in range(4):
+                got_f, got_h = K.gemm("fp16", A, W, bias=bias, resid=R, out_f=True, out_h=True)
+                assert torch.equal(got_f, want_f) and torch.equal(got_h, want_h), fit
+    finally:
+        check(lib().afx_debug_set(b"gemm_tile", -1))
+        check(lib().afx_debug_set(b"gemm_fit", 1))
+
+
 @pytest.mark.parametrize("M,N,K_,resid", [(12736, 3072, 1024, False), (12736, 4096, 1024, False), (6500, 2048, 512, True)])
 def test_gemm_round_split_matches_the_single_kernel(K, M, N, K_, resid):
     """Default dispatch of a multi-round plain GEMM: whole rounds on the 8-phase kernel, remaining rows on the

@@ -14,7 +14,9 @@ from afx._lib import check, lib  # noqa: E402
 
 M = int(os.environ.get("BENCH_M", 3184))
 SHAPES = [("qkv", 3072, 1024, False), ("out", 1024, 1024, True), ("fc1", 4096, 1024, False), ("fc2", 1024, 4096, True)]
-TILES = [("auto", -1), ("128x128/4w", 0), ("128x64/4w", 5), ("8ph 256x256", 3)]
+# (name, gemm_tile, gemm_fit): the 8-phase kernel at forced heights 256 / 224 / 192 / 160 rows and fitted
+TILES = [("auto", -1, 1), ("auto nofit", -1, 0), ("128x128/4w", 0, 1), ("128x64/4w", 5, 1), ("8ph 256", 3, 8), ("8ph 224", 3, 7),
+         ("8ph 192", 3, 6), ("8ph 160", 3, 5)]
 
 
 def timeit(fn, reps=20):
@@ -38,9 +40,10 @@ def main():
         ga = torch.ones(N, device="cuda")
         flops = 2.0 * M * N * Kk
         variants = {}
-        for tn, tv in TILES:
-            def f(tv=tv):
+        for tn, tv, fit in TILES:
+            def f(tv=tv, fit=fit):
                 check(lib().afx_debug_set(b"gemm_tile", tv))
+                check(lib().afx_debug_set(b"gemm_fit", fit))
                 if resid:
                     K.gemm("fp16", a, w, bias=bias, resid=x, out_f=True, out_h=False)
                 else:
@@ -53,6 +56,7 @@ def main():
             for k, f in variants.items():
                 times[k].append(timeit(f))
         check(lib().afx_debug_set(b"gemm_tile", -1))
+        check(lib().afx_debug_set(b"gemm_fit", 1))
         print(f"{name} M={M} N={N} K={Kk}: " + "  ".join(
             f"{k}: {statistics.median(t):6.1f} us" + (f" ({flops / statistics.median(t) / 1e6:5.0f} TF)" if "LN" not in k else "")
             for k, t in times.items()), flush=True)
