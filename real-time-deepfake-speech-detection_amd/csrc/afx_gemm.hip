@@ -557,8 +557,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   constexpr int BUF = 2 * (RA + RB) * 128;
   static_assert((WIDE ? MTH : NTH) * KSN == 4 && (WIDE ? NTH : MTH) * KSN == 8, "resident operand: 4 reads per half, flowing: 8");
   static_assert(2 * (WIDE ? DA : DB) + (WIDE ? DB : DA) == 6, "vmcnt(6) leaves R0, F0, R1 of tile t+2 in flight");
-  static_assert(MF == BM / 32 || (!WIDE && !ROWLN && MF >= 5 && MF < 8), "short tiles: the 256x256 instance only");
-  constexpr int MF0 = WIDE ? MTH : (MF + 1) / 2, MF1 = WIDE ? MTH : MF - MF0;  // live fragments of A half 0 / 1
+  static_assert(MF == BM / 32 || (!WIDE && MF >= 5 && MF < 8) || (WIDE && MF >= 2 && MF < 4), "short tiles: 160..224 of 256 rows, 64 / 96 of 128");
+  constexpr int MF0 = (MF + 1) / 2, MF1 = MF - MF0;  // live fragments of A half 0 / 1
   constexpr int BMC = (MF0 + MF1) * 32;                                       // rows the tile covers
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -917,6 +917,26 @@ static int gemm8_fit_mf(const GemmArgs& p) {
   return best;
 }
 
+// The same for the row-complete 128x512 tile (4 fragments per wave row = 128 rows; 3 = 96, 2 = 64): the conv layers of
+// a small batch (B = 16: 200 / 100 / 50 / 25 / 13 / 7 tiles of 128 rows on 256 CUs) spread over more CUs.  The weight
+// panel flows at 64 KB per K-tile whatever the height, so a tile's time shrinks less than its rows: cost MF + 4.
+static int gemm8_fit_rowln(const GemmArgs& p) {
+  constexpr long kCUs = 256;
+  if (!g_fit) return 4;
+  if (g_fit >= 12 && g_fit <= 14) return g_fit - 10;  // forced (A/B): 12, 13, 14
+  int best = 4;
+  long best_cost = 0;
+  for (int mf = 4; mf >= 2; --mf) {
+    const long tiles = (p.M + mf * 32 - 1) / (mf * 32);
+    const long cost = ((tiles + kCUs - 1) / kCUs) * (mf + 4);
+    if (mf == 4 || cost < best_cost) {
+      best = mf;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
 int gemm_tile_of(const GemmArgs& p, int groups) {
   if (p.ln_gamma) return g_deep != 0 && p.kchunk == p.K ? 8 : 3;
   if (gemm_is_narrow(p.N)) return 1;
@@ -950,6 +970,8 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 76: return launch_gemm8_t<HT, 256, 256, false, 6>(p, groups, s);
     case 77: return launch_gemm8_t<HT, 256, 256, false, 7>(p, groups, s);
     case 8: return launch_gemm8_t<HT, 128, 512, true>(p, groups, s);
+    case 82: return launch_gemm8_t<HT, 128, 512, true, 2>(p, groups, s);
+    case 83: return launch_gemm8_t<HT, 128, 512, true, 3>(p, groups, s);
     default: return lean ? launch_gemm_t<HT, 128, 128, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
   }
 }
@@ -981,6 +1003,9 @@ const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t
   if (tile == 7) {
     const int mf = gemm8_fit_mf(p);
     if (mf < 8) tile = 70 + mf;
+  } else if (tile == 8) {
+    const int mf = gemm8_fit_rowln(p);
+    if (mf < 4) tile = 80 + mf;
   }
   const hipError_t err = dtype == DT_BF16 ? dispatch<BF16>(p, tile, groups, s) : dispatch<FP16>(p, tile, groups, s);
   return err == hipSuccess ? nullptr : hipGetErrorString(err);

@@ -241,11 +241,14 @@ def test_conv_layernorm_8phase_tile_is_bit_identical_to_the_2stage_tile(K):
             check(lib().afx_debug_set(b"gemm_deep", 0))  # the 2-stage tile
             want, _ = K.conv_ln_act("fp16", x, wp, k, 2, bias, ga, be, out_f=True, out_h=False)
             check(lib().afx_debug_set(b"gemm_deep", 2))
-            for _ in range(8):
-                got, _ = K.conv_ln_act("fp16", x, wp, k, 2, bias, ga, be, out_f=True, out_h=False)
-                assert torch.equal(got, want)
+            for fit in (14, 13, 12, 1):  # tile heights 128 / 96 / 64 rows, then the fitted choice: same rows, bit for bit
+                check(lib().afx_debug_set(b"gemm_fit", fit))
+                for _ in range(4):
+                    got, _ = K.conv_ln_act("fp16", x, wp, k, 2, bias, ga, be, out_f=True, out_h=False)
+                    assert torch.equal(got, want), fit
         finally:
             check(lib().afx_debug_set(b"gemm_deep", -1))
+            check(lib().afx_debug_set(b"gemm_fit", 1))
 
 
 @pytest.mark.parametrize("dtype", DT)

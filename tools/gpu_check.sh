@@ -39,10 +39,21 @@ python3 - "$OUT" <<'PYEOF'
 import csv, glob, sys, collections
 out = sys.argv[1]
 agg = collections.defaultdict(list)
+spans = []
 for f in glob.glob(out + "/prof/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[(n, r["Grid_Size_X"], r["Grid_Size_Z"], r["Workgroup_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        spans.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+# idle time between consecutive kernels of the stream (gaps under 100 us: back-to-back launches, not host pauses)
+spans.sort()
+gaps = [b[0] - a[1] for a, b in zip(spans, spans[1:]) if 0 <= b[0] - a[1] < 100000]
+if gaps:
+    gaps.sort()
+    busy = sum(e - s for s, e in spans)
+    with open(out + "/summary.txt", "a") as fh:
+        fh.write(f"== inter-kernel gaps: {len(gaps)} gaps, median {gaps[len(gaps)//2]/1e3:.2f} us, mean {sum(gaps)/len(gaps)/1e3:.2f} us, "
+                 f"sum {sum(gaps)/1e6:.2f} ms beside {busy/1e6:.2f} ms of kernel time ({sum(gaps)/(sum(gaps)+busy)*100:.1f} % idle)\n")
 with open(out + "/kernel_by_shape.csv", "w") as fh:
     fh.write("kernel,grid_x_threads,grid_z,wg_size,calls,avg_us,total_ms\n")
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
