@@ -1306,6 +1306,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
     gemm_set_split(value);
     return 0;
   }
+  if (!strcmp(key, "gemm_ph4")) {
+    gemm_set_ph4(value);
+    return 0;
+  }
   if (!strcmp(key, "gemm_fit")) {
     gemm_set_fit(value);
     return 0;

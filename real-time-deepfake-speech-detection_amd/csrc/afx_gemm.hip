@@ -24,7 +24,8 @@
 #include <type_traits>
 
 // Timing-only switches of the epilogue (GemmArgs::dbg_nodma: 8 no activation, 16 narrow stores, 32 no stores,
-// 64 no epilogue -- WRONG results) exist only in the attribution build (make attr -> lib/libafx_attr.so,
+// 64 no epilogue; 8-phase K-loop: 128 / 256 / 512 / 1024 one half-tile's operand DMA off, 2048 no MFMAs, 4096 no LDS
+// fragment reads -- WRONG results) exist only in the attribution build (make attr -> lib/libafx_attr.so,
 // -DAFX_ATTR, loaded through AFX_LIB by tools/bench_convln_attr.py / bench_gemm_k.py); the product library
 // compiles them out, so no environment variable or debug key can switch results off.
 #ifdef AFX_ATTR
@@ -535,7 +536,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // 228 tiles of 224 rows instead of 200 of 256; M = 16 x 199, N = 3072: 240 tiles of 160 rows instead of 156), so a
 // sub-round product pays 7/8 or 5/8 of the K-loop instead of idling a fifth to a third of the chip.  Per-row results
 // do not depend on the height (same K order).
-template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32>
+template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, bool PH2 = true>
 __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
@@ -668,6 +669,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
         wf[WIDE ? 0 : h][nj][ks] = *(const V8*)(bR + buf * BUF + (h ? OFF_B1 : OFF_B0) + nj * (FR * 128) + slot[ks]);
   };
   auto quadrant = [&](int ah, int bh) {  // 16 MFMAs: (A half ah) x (B half bh) x K = 64
+    if (AFX_DBG(p, 2048)) return;  // timing only: K-loop without its MFMAs
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < KSN; ++ks)
@@ -683,8 +685,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     __builtin_amdgcn_s_setprio(0);
   };
   // R / F views of the two operands
-  auto readR = [&](int buf, int h) { if constexpr (WIDE) readA(buf, h); else readB(buf, h); };
-  auto readF = [&](int buf, int h) { if constexpr (WIDE) readB(buf, h); else readA(buf, h); };
+  // (AFX_DBG 4096, timing only: K-loop without its LDS fragment reads)
+  auto readR = [&](int buf, int h) { if (AFX_DBG(p, 4096)) return; if constexpr (WIDE) readA(buf, h); else readB(buf, h); };
+  auto readF = [&](int buf, int h) { if (AFX_DBG(p, 4096)) return; if constexpr (WIDE) readB(buf, h); else readA(buf, h); };
   auto stageR = [&](int h, int buf, int kt) { if constexpr (WIDE) stageA(h, buf, kt); else stageB(h, buf, kt); };
   auto stageF = [&](int h, int buf, int kt) { if constexpr (WIDE) stageB(h, buf, kt); else stageA(h, buf, kt); };
   auto quadFR = [&](int fh, int rh) { if constexpr (WIDE) quadrant(rh, fh); else quadrant(fh, rh); };
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     readF(b, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (more1) stageF(1, b ^ 1, t + 1);
+    if (more1 && !(AFX_DBG(p, 128))) stageF(1, b ^ 1, t + 1);  // (AFX_DBG 128 / 256 / 512 / 1024, timing only: one operand half-tile's DMA off)
     // the R0 reads (issued first) are done -- all but the F0 reads behind them: R0 may be re-staged next phase
     if constexpr ((WIDE ? NTH : MF0) * KSN == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
     else if constexpr ((WIDE ? NTH : MF0) * KSN == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     // ---- phase 2
     readR(b, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (more2) stageR(0, b, t + 2);
+    if (more2 && !(AFX_DBG(p, 256))) stageR(0, b, t + 2);
     AFX_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     quadFR(0, 1);
@@ -738,14 +741,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     // ---- phase 3
     readF(b, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (more2) stageF(0, b, t + 2);
+    if (more2 && !(AFX_DBG(p, 512))) stageF(0, b, t + 2);
     AFX_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     quadFR(1, 1);
     AFX_BAR();
     // ---- phase 4
     if (more2) {
-      stageR(1, b, t + 2);
+      if (!(AFX_DBG(p, 1024))) stageR(1, b, t + 2);
       wait_vmcnt<6>();  // tile t+1 has landed; R0/F0/R1 of tile t+2 stay in flight
     } else {
       wait_vmcnt<0>();
@@ -754,17 +757,86 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     quadFR(1, 0);
     AFX_BAR();
   };
+  // ---- the K-tile as TWO phases of 32 MFMAs (PH2) ---------------------------------------------------------------
+  // Measured with everything but the MFMAs and the barriers switched off (tools/bench_kloop_attr.py), the 4-phase
+  // loop still takes 1.31 us per K-tile against 0.98 us of matrix-pipe time: every hand-over of the pipe from one
+  // wave row to the other (s_barrier release, first issue) costs ~90 cycles, and a 16-MFMA segment is only 256.
+  // Two phases per K-tile halve the hand-overs:
+  //     phase A: read R0, R1, F0 (16 ds_read_b128)   stage F1(t+1)          MFMA (F0,R0) (F0,R1)
+  //     phase B: read F1 (8)                         stage R0 R1 F0 (t+2)   MFMA (F1,R1) (F1,R0)
+  // each phase = { reads ; LDS-DMA ; vmcnt ; lgkmcnt(0) ; s_barrier ; 32 MFMA ; s_barrier }; same registers as before
+  // (both R halves were resident already).  Hazards, in barrier intervals of wave row 0 (row 1 one interval later):
+  //   WAR  every read is RETIRED (lgkmcnt(0)) before its phase's first barrier, so a slot is free two intervals after
+  //        row 0 read it: R0 R1 F0 of tile t (read in A_t) are re-staged from B_t on, F1 (read in B_t) from A_t+1 on.
+  //   RAW  a wave waits for its own DMA at the END of a read interval, one full interval before the earliest reader
+  //        of the other row needs it: end of B_t-1 -> R0 R1 F0 of tile t (read from A_t), end of A_t -> F1 of tile t
+  //        (read from B_t).  In issue order the queue then holds [F1(t+1) 2] [R0R1F0(t+2) 6] behind what is needed:
+  //        vmcnt(8) in steady state; every transfer has a whole K-tile of time to land.
+  auto ktile2 = [&](auto bufc, int t) {
+    constexpr int b = decltype(bufc)::value;
+    constexpr int NF1 = WIDE ? DB : DA, NRRF = 2 * (WIDE ? DA : DB) + (WIDE ? DB : DA);  // DMAs per wave: F1; R0+R1+F0
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+    // ---- phase A
+    readR(b, 0);
+    readR(b, 1);
+    readF(b, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more1 && !(AFX_DBG(p, 128))) stageF(1, b ^ 1, t + 1);
+    if (more1) wait_vmcnt<NF1 + NRRF>();  // F1(t) has landed; R0R1F0(t+1), F1(t+1) stay in flight
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    AFX_BAR();
+    quadFR(0, 0);
+    quadFR(0, 1);
+    AFX_BAR();
+    // ---- phase B
+    readF(b, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) {
+      if (!(AFX_DBG(p, 256))) stageR(0, b, t + 2);
+      if (!(AFX_DBG(p, 1024))) stageR(1, b, t + 2);
+      if (!(AFX_DBG(p, 512))) stageF(0, b, t + 2);
+      wait_vmcnt<NF1 + NRRF>();  // R0R1F0(t+1) have landed; F1(t+1), R0R1F0(t+2) stay in flight
+    } else if (more1) {
+      wait_vmcnt<NF1>();  // F1(t+1) may stay in flight
+    } else {
+      wait_vmcnt<0>();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    AFX_BAR();
+    quadFR(1, 1);
+    quadFR(1, 0);
+    AFX_BAR();
+  };
+  auto issue_prologue2 = [&] {
+    stageR(0, 0, 0);
+    stageR(1, 0, 0);
+    stageF(0, 0, 0);
+    stageF(1, 0, 0);
+    if (nk > 1) {
+      stageR(0, 1, 1);
+      stageR(1, 1, 1);
+      stageF(0, 1, 1);
+    }
+  };
   int v = blockIdx.x;
   setup(v);
-  issue_prologue();
+  if constexpr (PH2) issue_prologue2(); else issue_prologue();
   bool first = true;
   for (;;) {
     // K-tile 0 has landed.  For the first output tile that is the counted wait of the template;
     // for later ones the epilogue stores of the previous tile were issued BEHIND these DMAs and
     // vmcnt retires in order, so the wait is vmcnt(0) (the stores were issued all through the
     // epilogue and are mostly acknowledged by now).
-    if (first && nk > 1) wait_vmcnt<6>();
-    else wait_vmcnt<0>();
+    if constexpr (PH2) {
+      constexpr int NF1 = WIDE ? DB : DA, NRRF = 2 * (WIDE ? DA : DB) + (WIDE ? DB : DA);
+      if (first && nk > 1) wait_vmcnt<NF1 + NRRF>();  // R0 R1 F0 of K-tile 0 have landed
+      else if (first) wait_vmcnt<NF1>();
+      else wait_vmcnt<0>();
+    } else {
+      if (first && nk > 1) wait_vmcnt<6>();
+      else wait_vmcnt<0>();
+    }
     first = false;
     AFX_BAR();
     if (wr == 1) AFX_BAR();  // the second wave row runs one barrier behind the first
@@ -772,9 +844,21 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     for (int i = 0; i < MF0 + MF1; ++i)
 #pragma unroll
       for (int j = 0; j < 2 * NTH; ++j) acc[i][j] = 0.f;
+    // A wait the COMPILER can see: its waitcnt pass does not model the inline-asm waits above, so at the K-loop header
+    // it still believed the loads of the previous output tile's epilogue (residual rows, a spill reload) outstanding
+    // and protected the loop's first register writes with an s_waitcnt vmcnt(0) of its own -- at the header, i.e.
+    // in EVERY iteration, draining the operand DMA queue every second K-tile.  Those loads are long complete here
+    // (vmcnt retires in order and the asm waits above covered them); this tells the pass so.  Hardware cost: the first
+    // output tile of a workgroup waits for all of its prologue instead of the first K-tile only.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only (gfx9 encoding: expcnt / lgkmcnt fields at their maximum)
     for (int t = 0; t < nk; t += 2) {
-      ktile(std::integral_constant<int, 0>{}, t);
-      if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
+      if constexpr (PH2) {
+        ktile2(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nk) ktile2(std::integral_constant<int, 1>{}, t + 1);
+      } else {
+        ktile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
+      }
     }
     if (wr == 0) AFX_BAR();  // both wave rows are done with every LDS read of this output tile
     // The operand DMA of the NEXT output tile goes out before this tile's epilogue: its latency
@@ -784,7 +868,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     const int vn = v + gridDim.x;
     if (vn < nwg) {
       setup(vn);
-      issue_prologue();
+      if constexpr (PH2) issue_prologue2(); else issue_prologue();
     }
     if (AFX_DBG(p, 64)) {  // timing only: no epilogue at all
 #pragma unroll
@@ -802,12 +886,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 #undef AFX_BAR
 }
 
-template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32>
+template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, bool PH2 = true>
 static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static_assert(lds <= 160 * 1024, "two K-tile buffers must fit the 160 KB LDS");
   static LdsLimit lim;
-  if (hipError_t e = lim.ensure((const void*)gemm8_kernel<HT, BM, BN, ROWLN, MF>, lds); e != hipSuccess) return e;
+  if (hipError_t e = lim.ensure((const void*)gemm8_kernel<HT, BM, BN, ROWLN, MF, PH2>, lds); e != hipSuccess) return e;
   static int n_cu_of[kMaxDevices] = {0};  // (benign if two threads fill the same slot: same value)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
@@ -820,7 +904,7 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   const int n_cu = n_cu_of[dev];
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + MF * 32 - 1) / (MF * 32));
   dim3 grid(tiles < n_cu ? tiles : n_cu, 1, groups);  // persistent: at most one workgroup per CU
-  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN, MF>), grid, dim3(512), lds, s, p);
+  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN, MF, PH2>), grid, dim3(512), lds, s, p);
   return hipGetLastError();
 }
 
@@ -897,6 +981,8 @@ static int gemm_split_rows(const GemmArgs& p, int groups) {
 
 // Height of the 8-phase 256-wide tile for a product that is NOT round-split: fragments per wave row (8 = 256 rows).
 // Cost model: rounds x (MF + 2) -- a round's K-loop scales with MF, prologue + epilogue are about two fragments' worth.
+static int g_ph4 = 0;  // A/B knob: 1 = the 4-phase K-tile (16-MFMA segments) on the full-height tiles
+void gemm_set_ph4(int v) { g_ph4 = v; }
 static int g_fit = 1;  // A/B knob: 0 = always 256 rows, 1 = fitted, 5..8 = forced
 void gemm_set_fit(int v) { g_fit = v; }
 static int gemm8_fit_mf(const GemmArgs& p) {
@@ -965,11 +1051,11 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 1: return lean ? launch_gemm_t<HT, 128, 64, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 64, 2, 2>(p, groups, s);
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
-    case 7: return launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
+    case 7: return g_ph4 ? launch_gemm8_t<HT, 256, 256, false, 8, false>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
     case 75: return launch_gemm8_t<HT, 256, 256, false, 5>(p, groups, s);
     case 76: return launch_gemm8_t<HT, 256, 256, false, 6>(p, groups, s);
     case 77: return launch_gemm8_t<HT, 256, 256, false, 7>(p, groups, s);
-    case 8: return launch_gemm8_t<HT, 128, 512, true>(p, groups, s);
+    case 8: return g_ph4 ? launch_gemm8_t<HT, 128, 512, true, 4, false>(p, groups, s) : launch_gemm8_t<HT, 128, 512, true>(p, groups, s);
     case 82: return launch_gemm8_t<HT, 128, 512, true, 2>(p, groups, s);
     case 83: return launch_gemm8_t<HT, 128, 512, true, 3>(p, groups, s);
     default: return lean ? launch_gemm_t<HT, 128, 128, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);

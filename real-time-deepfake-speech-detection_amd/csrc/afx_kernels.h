@@ -55,6 +55,7 @@ int gemm_tile_of(const GemmArgs& p, int groups);  // tile instance id (afx_gemm.
 void gemm_set_map_mode(int m);  // A/B knob: -1 default, else force map_mode
 void gemm_set_tile(int t);      // A/B knob: -1 default, 0: 128x128 tile, 1: 256x256 tile
 void gemm_set_a_nt(int v);      // A/B knob: -1 auto, 0/1 non-temporal A-panel loads
+void gemm_set_ph4(int v);       // A/B knob: 1 = 4-phase K-tile of the 8-wave kernels (default 0: two phases of 32 MFMAs)
 void gemm_set_fit(int v);       // A/B knob: 1 (default) = 8-phase tile height fitted to one round of the CUs (160..256 rows)
 void gemm_set_split(int v);     // A/B knob: 1 (default) = whole rounds on the 8-phase kernel + 128x128 remainder rows
 void mhsa_set_force_long(int v);   // test knob: the blocked any-length trunk attention kernel at every length

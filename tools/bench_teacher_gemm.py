@@ -15,7 +15,8 @@ from afx._lib import check, lib  # noqa: E402
 M = int(os.environ.get("BENCH_M", 3184))
 SHAPES = [("qkv", 3072, 1024, False), ("out", 1024, 1024, True), ("fc1", 4096, 1024, False), ("fc2", 1024, 4096, True)]
 # (name, gemm_tile, gemm_fit): the 8-phase kernel at forced heights 256 / 224 / 192 / 160 rows and fitted
-TILES = [("auto", -1, 1), ("auto nofit", -1, 0), ("128x128/4w", 0, 1), ("128x64/4w", 5, 1), ("8ph 256", 3, 8), ("8ph 224", 3, 7),
+# gemm_fit + 100 = the same on the 4-phase K-tile (full-height tiles only)
+TILES = [("auto", -1, 1), ("auto 4ph", -1, 101), ("auto nofit", -1, 0), ("128x128/4w", 0, 1), ("128x64/4w", 5, 1), ("8ph 256", 3, 8), ("8ph 256 4ph", 3, 108), ("8ph 224", 3, 7),
          ("8ph 192", 3, 6), ("8ph 160", 3, 5)]
 
 
@@ -43,7 +44,8 @@ def main():
         for tn, tv, fit in TILES:
             def f(tv=tv, fit=fit):
                 check(lib().afx_debug_set(b"gemm_tile", tv))
-                check(lib().afx_debug_set(b"gemm_fit", fit))
+                check(lib().afx_debug_set(b"gemm_fit", fit % 100))
+                check(lib().afx_debug_set(b"gemm_ph4", fit // 100))
                 if resid:
                     K.gemm("fp16", a, w, bias=bias, resid=x, out_f=True, out_h=False)
                 else:
@@ -57,6 +59,7 @@ def main():
                 times[k].append(timeit(f))
         check(lib().afx_debug_set(b"gemm_tile", -1))
         check(lib().afx_debug_set(b"gemm_fit", 1))
+        check(lib().afx_debug_set(b"gemm_ph4", 0))
         print(f"{name} M={M} N={N} K={Kk}: " + "  ".join(
             f"{k}: {statistics.median(t):6.1f} us" + (f" ({flops / statistics.median(t) / 1e6:5.0f} TF)" if "LN" not in k else "")
             for k, t in times.items()), flush=True)
