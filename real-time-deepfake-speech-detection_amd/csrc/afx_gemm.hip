@@ -536,7 +536,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // 228 tiles of 224 rows instead of 200 of 256; M = 16 x 199, N = 3072: 240 tiles of 160 rows instead of 156), so a
 // sub-round product pays 7/8 or 5/8 of the K-loop instead of idling a fifth to a third of the chip.  Per-row results
 // do not depend on the height (same K order).
-template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, bool PH2 = true>
+template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, int PH = 1>
 __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
@@ -821,14 +821,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   };
   int v = blockIdx.x;
   setup(v);
-  if constexpr (PH2) issue_prologue2(); else issue_prologue();
+  if constexpr (PH != 0) issue_prologue2(); else issue_prologue();
   bool first = true;
   for (;;) {
     // K-tile 0 has landed.  For the first output tile that is the counted wait of the template;
     // for later ones the epilogue stores of the previous tile were issued BEHIND these DMAs and
     // vmcnt retires in order, so the wait is vmcnt(0) (the stores were issued all through the
     // epilogue and are mostly acknowledged by now).
-    if constexpr (PH2) {
+    if constexpr (PH != 0) {
       constexpr int NF1 = WIDE ? DB : DA, NRRF = 2 * (WIDE ? DA : DB) + (WIDE ? DB : DA);
       if (first && nk > 1) wait_vmcnt<NF1 + NRRF>();  // R0 R1 F0 of K-tile 0 have landed
       else if (first) wait_vmcnt<NF1>();
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     // output tile of a workgroup waits for all of its prologue instead of the first K-tile only.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only (gfx9 encoding: expcnt / lgkmcnt fields at their maximum)
     for (int t = 0; t < nk; t += 2) {
-      if constexpr (PH2) {
+      if constexpr (PH == 1) {
         ktile2(std::integral_constant<int, 0>{}, t);
         if (t + 1 < nk) ktile2(std::integral_constant<int, 1>{}, t + 1);
       } else {
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     const int vn = v + gridDim.x;
     if (vn < nwg) {
       setup(vn);
-      if constexpr (PH2) issue_prologue2(); else issue_prologue();
+      if constexpr (PH != 0) issue_prologue2(); else issue_prologue();
     }
     if (AFX_DBG(p, 64)) {  // timing only: no epilogue at all
 #pragma unroll
@@ -886,12 +886,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 #undef AFX_BAR
 }
 
-template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, bool PH2 = true>
+template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, int PH = 1>
 static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static_assert(lds <= 160 * 1024, "two K-tile buffers must fit the 160 KB LDS");
   static LdsLimit lim;
-  if (hipError_t e = lim.ensure((const void*)gemm8_kernel<HT, BM, BN, ROWLN, MF, PH2>, lds); e != hipSuccess) return e;
+  if (hipError_t e = lim.ensure((const void*)gemm8_kernel<HT, BM, BN, ROWLN, MF, PH>, lds); e != hipSuccess) return e;
   static int n_cu_of[kMaxDevices] = {0};  // (benign if two threads fill the same slot: same value)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
@@ -904,7 +904,7 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   const int n_cu = n_cu_of[dev];
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + MF * 32 - 1) / (MF * 32));
   dim3 grid(tiles < n_cu ? tiles : n_cu, 1, groups);  // persistent: at most one workgroup per CU
-  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN, MF, PH2>), grid, dim3(512), lds, s, p);
+  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN, MF, PH>), grid, dim3(512), lds, s, p);
   return hipGetLastError();
 }
 
@@ -980,32 +980,30 @@ static int gemm_split_rows(const GemmArgs& p, int groups) {
 }
 
 // Height of the 8-phase 256-wide tile for a product that is NOT round-split: fragments per wave row (8 = 256 rows).
-// Cost model: rounds x (MF + 2) -- a round's K-loop scales with MF, prologue + epilogue are about two fragments' worth.
-static int g_ph4 = 0;  // A/B knob: 1 = the 4-phase K-tile (16-MFMA segments) on the full-height tiles
+// Cost model: rounds x (MF + 5) -- fitted to tools/bench_teacher_gemm.py (M = 12736, N = 4096: 33.4 / 30.3 / 27.3 / 25.6 us
+// per round at 8 / 7 / 6 / 5 fragments): the operand DMA of a K-tile does not shrink with the height, only the MFMAs do.
+static int g_ph4 = 0;  // A/B knob (full-height tiles): 1 = the 4-phase K-tile (16-MFMA segments)
 void gemm_set_ph4(int v) { g_ph4 = v; }
 static int g_fit = 1;  // A/B knob: 0 = always 256 rows, 1 = fitted, 5..8 = forced
 void gemm_set_fit(int v) { g_fit = v; }
-static int gemm8_fit_mf(const GemmArgs& p) {
+static int gemm8_fit_mf(const GemmArgs& p, long* cost_out = nullptr) {
   constexpr long kCUs = 256;
-  if (!g_fit) return 8;
-  if (g_fit >= 5 && g_fit <= 8) return g_fit;
   const long nN = (p.N + 255) / 256;
+  auto cost_of = [&](int mf) { return ((nN * ((p.M + mf * 32 - 1) / (mf * 32)) + kCUs - 1) / kCUs) * (mf + 5); };
   int best = 8;
-  long best_cost = 0;
-  for (int mf = 8; mf >= 5; --mf) {
-    const long tiles = nN * ((p.M + mf * 32 - 1) / (mf * 32));
-    const long cost = ((tiles + kCUs - 1) / kCUs) * (mf + 2);
-    if (mf == 8 || cost < best_cost) {
-      best = mf;
-      best_cost = cost;
-    }
+  if (g_fit >= 5 && g_fit <= 8) {
+    best = g_fit;
+  } else if (g_fit) {
+    for (int mf = 7; mf >= 5; --mf)
+      if (cost_of(mf) < cost_of(best)) best = mf;
   }
+  if (cost_out) *cost_out = cost_of(best);
   return best;
 }
 
 // The same for the row-complete 128x512 tile (4 fragments per wave row = 128 rows; 3 = 96, 2 = 64): the conv layers of
 // a small batch (B = 16: 200 / 100 / 50 / 25 / 13 / 7 tiles of 128 rows on 256 CUs) spread over more CUs.  The weight
-// panel flows at 64 KB per K-tile whatever the height, so a tile's time shrinks less than its rows: cost MF + 4.
+// panel flows at 64 KB per K-tile whatever the height, so a tile's time shrinks less than its rows: cost MF + 6 (41.9 / 37.2 / 33.5 us at 128 / 96 / 64 rows, one round each).
 static int gemm8_fit_rowln(const GemmArgs& p) {
   constexpr long kCUs = 256;
   if (!g_fit) return 4;
@@ -1014,7 +1012,7 @@ static int gemm8_fit_rowln(const GemmArgs& p) {
   long best_cost = 0;
   for (int mf = 4; mf >= 2; --mf) {
     const long tiles = (p.M + mf * 32 - 1) / (mf * 32);
-    const long cost = ((tiles + kCUs - 1) / kCUs) * (mf + 4);
+    const long cost = ((tiles + kCUs - 1) / kCUs) * (mf + 6);
     if (mf == 4 || cost < best_cost) {
       best = mf;
       best_cost = cost;
@@ -1051,11 +1049,11 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 1: return lean ? launch_gemm_t<HT, 128, 64, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 64, 2, 2>(p, groups, s);
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
-    case 7: return g_ph4 ? launch_gemm8_t<HT, 256, 256, false, 8, false>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
+    case 7: return g_ph4 ? launch_gemm8_t<HT, 256, 256, false, 8, 0>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
     case 75: return launch_gemm8_t<HT, 256, 256, false, 5>(p, groups, s);
     case 76: return launch_gemm8_t<HT, 256, 256, false, 6>(p, groups, s);
     case 77: return launch_gemm8_t<HT, 256, 256, false, 7>(p, groups, s);
-    case 8: return g_ph4 ? launch_gemm8_t<HT, 128, 512, true, 4, false>(p, groups, s) : launch_gemm8_t<HT, 128, 512, true>(p, groups, s);
+    case 8: return g_ph4 ? launch_gemm8_t<HT, 128, 512, true, 4, 0>(p, groups, s) : launch_gemm8_t<HT, 128, 512, true>(p, groups, s);
     case 82: return launch_gemm8_t<HT, 128, 512, true, 2>(p, groups, s);
     case 83: return launch_gemm8_t<HT, 128, 512, true, 3>(p, groups, s);
     default: return lean ? launch_gemm_t<HT, 128, 128, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
@@ -1072,7 +1070,16 @@ const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t
     tile = tile == 7 ? 0 : 3;  // the 8-phase kernels carry the lean epilogue: everything else stays on the 2-stage tiles
   p.a_nt = g_ant_override >= 0 ? g_ant_override : (tile == 3 ? 1 : 0);
   p.dbg_nodma = g_nodma;
-  const int m1 = tile == 7 && g_tile_override < 0 ? gemm_split_rows(p, groups) : 0;
+  int m1 = tile == 7 && g_tile_override < 0 ? gemm_split_rows(p, groups) : 0;
+  if (m1 > 0) {
+    // round split against a fitted height on the whole problem, in the same units: whole rounds at full height plus
+    // the remainder kernel (~10: measured 84.9 us split against 82.2 us as 3 rounds of 224-row tiles for QKV at M = 12736,
+    // 123.7 against 121.1 as 4 rounds for FC1 -- profiles/r02_gemm_dma_spread_ab.txt)
+    long fitted = 0;
+    gemm8_fit_mf(p, &fitted);
+    const long split = ((long)(m1 / 256) * ((p.N + 255) / 256) / 256) * 13 + 10;
+    if (g_fit == 1 && fitted <= split) m1 = 0;
+  }
   if (m1 > 0) {  // rows [0, m1) on the 8-phase kernel, rows [m1, M) on the 128x128 kernel
     const size_t hs = 2;
     GemmArgs a = p, b = p;
