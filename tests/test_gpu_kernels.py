@@ -129,8 +129,9 @@ def test_gemm_8phase_short_tiles_are_bit_identical(K, M, N, K_):
 
 @pytest.mark.parametrize("M,N,K_,resid", [(12736, 3072, 1024, False), (12736, 4096, 1024, False), (6500, 2048, 512, True)])
 def test_gemm_round_split_matches_the_single_kernel(K, M, N, K_, resid):
-    """Default dispatch of a multi-round plain GEMM: whole rounds on the 8-phase kernel, remaining rows on the
-    128x128 kernel.  Same k order per element in both, so the result must equal the single-kernel one bit for bit."""
+    """Dispatch of a multi-round plain GEMM: either a fitted tile height on the whole problem (default where the cost
+    model prefers it) or whole rounds on the 8-wave kernel + the remaining rows on the 128x128 kernel (gemm_fit 0 forces
+    this form).  Same k order per element everywhere, so every form must equal the single-kernel result bit for bit."""
     from afx._lib import check, lib
     g = torch.Generator().manual_seed(N + K_)
     A = torch.randn(M, K_, generator=g).half().cuda()
@@ -141,14 +142,17 @@ def test_gemm_round_split_matches_the_single_kernel(K, M, N, K_, resid):
         check(lib().afx_debug_set(b"gemm_tile", 0))
         want_f, want_h = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
         check(lib().afx_debug_set(b"gemm_tile", -1))
-        got_f, got_h = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
-        assert torch.equal(got_f, want_f) and torch.equal(got_h, want_h)
+        for fit in (1, 0):  # default dispatch, then the round split
+            check(lib().afx_debug_set(b"gemm_fit", fit))
+            got_f, got_h = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
+            assert torch.equal(got_f, want_f) and torch.equal(got_h, want_h), fit
         check(lib().afx_debug_set(b"gemm_split", 0))
         got_f, _ = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
         assert torch.equal(got_f, want_f)
     finally:
         check(lib().afx_debug_set(b"gemm_tile", -1))
         check(lib().afx_debug_set(b"gemm_split", 1))
+        check(lib().afx_debug_set(b"gemm_fit", 1))
 
 
 @pytest.mark.parametrize("dtype", DT)
