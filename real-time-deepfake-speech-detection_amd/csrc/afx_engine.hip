@@ -112,6 +112,7 @@ struct afx_engine {
 
   // trunk, packed operand-type weights
   void* convw[7] = {nullptr};
+  void* conv0pack = nullptr;  // layer 0 as the split-precision fp16 MFMA operand (layer_norm mode, half-precision engines)
   void* projw = nullptr;
   void* posw = nullptr;
   float* pos_norm = nullptr;
@@ -430,6 +431,11 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
                           "self_attn_layer_norm.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias",
                           "final_layer_norm.weight", "final_layer_norm.bias"})
       if (need(h, L + k)) return 1;
+  }
+  if (!gn && h->dt != AFX_DT_FP32) {  // conv layer 0 as the split-precision fp16 matrix-core operand
+    if (!h->conv0pack && !(h->conv0pack = h->dalloc(conv0_pack_bytes()))) return fail("afx_finalize: device allocation failed");
+    KOK(launch_conv0_pack(h->F("ssl.feature_extractor.conv_layers.0.0.weight"), h->F("ssl.feature_extractor.conv_layers.0.0.bias"),
+                          h->conv0pack, s));
   }
   // positional conv: weight-norm (dim=2) folded into the packed operand
   const float* pv = h->F("ssl.encoder.pos_conv.0.weight_v");
@@ -777,7 +783,7 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
         return launch_conv0_groupnorm(wave, B, L, T[0], cf(0, ".0.weight"), cf(0, ".2.weight"), cf(0, ".2.bias"), kLnEps,
                                       w.gn_stats, w.bufA, dt, s);
       return launch_conv0(wave, B, L, T[0], cf(0, ".0.weight"), cf(0, ".0.bias"), cf(0, ".2.1.weight"),
-                          cf(0, ".2.1.bias"), e->cfg.pre_emphasis, e->cfg.pre_emphasis_coef, w.bufA, dt, s);
+                          cf(0, ".2.1.bias"), e->cfg.pre_emphasis, e->cfg.pre_emphasis_coef, w.bufA, dt, s, e->conv0pack);
     }));
   // layers 1..6: conv-as-GEMM on a row-complete tile, LayerNorm(512) + GELU fused into the
   // epilogue (the pre-norm fp32 activations never leave the registers)
@@ -1289,8 +1295,23 @@ extern "C" int afx_k_pack_conv(int dtype, const float* w, int N, int Cin, int k,
 extern "C" int afx_k_conv0(int dtype, const float* wave, int B, int L, const float* w, const float* bias,
                            const float* gamma, const float* beta, int pre_emph, float coef, void* out_h,
                            void* stream) {
-  KRET(launch_conv0(wave, B, L, (L - 10) / 5 + 1, w, bias, gamma, beta, pre_emph, coef, out_h, dtype,
-                    (hipStream_t)stream));
+  // (test hook: the packed operand the engine prepares once per checkpoint is built here per call)
+  void* pack = nullptr;
+  if (dtype != DT_FP32) {
+    if (hipMalloc(&pack, conv0_pack_bytes()) != hipSuccess) return fail("afx_k_conv0: device allocation failed");
+    if (const char* m = launch_conv0_pack(w, bias, pack, (hipStream_t)stream)) {
+      (void)hipFree(pack);
+      return fail("%s", m);
+    }
+  }
+  const char* m = launch_conv0(wave, B, L, (L - 10) / 5 + 1, w, bias, gamma, beta, pre_emph, coef, out_h, dtype,
+                               (hipStream_t)stream, pack);
+  if (pack) {
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(pack);
+  }
+  if (m) return fail("%s", m);
+  return 0;
 }
 extern "C" int afx_debug_set(const char* key, int value) {
   if (!key) return fail("afx_debug_set: null key");

@@ -18,7 +18,7 @@ namespace afx {
 // (data/preprocess.py:16-29) is applied while the waveform window is staged in LDS.
 // ---------------------------------------------------------------------------------
 constexpr int C0_FB = 64;  // frames per workgroup
-static int g_conv0_mfma = 1;  // A/B knob: matrix-core form of conv layer 0 (0: the VALU form below)
+static int g_conv0_mfma = 1;  // A/B knob: 1 = matrix-core forms of conv layer 0 (split-precision fp16 with a packed operand, else fp32 MFMA), 2 = fp32 MFMA always, 0 = the VALU form below
 
 template <class HT>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wave, int L, int T0,
@@ -200,6 +200,195 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------
+// conv layer 0 at fp32 accuracy on the fp16 matrix pipe (the half-precision engines' form): the 10 taps, their
+// split-precision corrections and the bias are ONE v_mfma_f32_16x16x32_f16 per 16 channels x 16 frames instead of
+// three v_mfma_f32_16x16x4_f32 (16 against 96 matrix-pipe cycles):
+//     k  0.. 9  xh[tap] * wh[tap]          x = xh + xl, w = wh + wl (fp16 hi + fp16 lo of the remainder)
+//     k 10..19  xl[tap] * wh[tap]
+//     k 20..29  xh[tap] * wl[tap]          (xl * wl, 2^-22 relative, is dropped)
+//     k 30, 31  (G / cb) * (cb bias)_hi, (G / cb) * (cb bias)_lo      (cb: power of two, largest |bias| into [1, 2))
+// Each frame is scaled by a power of two S_f that brings its largest sample into [1, 2) and the weights by one power of
+// two c for the layer (largest |w| into [1, 2)), so that the lo parts sit in fp16's normal range whatever the recording
+// level; G = S_f * c multiplies the whole pre-norm row and the LayerNorm that follows divides it out again
+// (eps -> G^2 eps).  S_f depends on the frame's own 10 samples only: a frame's result does not depend on its
+// neighbours, the batch or the launch (the streaming scorer relies on that).
+// The packed weight operand (conv0_pack_kernel, once per checkpoint): [32 channel tiles][64 lanes][8 halfs] in MFMA
+// A-operand order, followed by the exponents of c and cb.
+// ---------------------------------------------------------------------------------
+constexpr int C0P_HALFS = 32 * 64 * 8;
+__global__ __launch_bounds__(256) void conv0_pack_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                         _Float16* __restrict__ pack) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  auto norm_exp = [&](const float* v, int n) {  // e with max|v| * 2^e in [1, 2), clamped to +-12
+    float m = 0.f;
+    for (int i = tid; i < n; i += 256) m = fmaxf(m, fabsf(v[i]));
+    __syncthreads();
+    red[tid] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (tid < st) red[tid] = fmaxf(red[tid], red[tid + st]);
+      __syncthreads();
+    }
+    const float mx = red[0];
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) e = 127 - (int)((__float_as_uint(mx) >> 23) & 0xff);
+    return e < -12 ? -12 : (e > 12 ? 12 : e);
+  };
+  const int cexp = norm_exp(w, 512 * 10), bexp = norm_exp(bias, 512);
+  const float c = ldexpf(1.0f, cexp), cb = ldexpf(1.0f, bexp);
+  for (int i = tid; i < 32 * 64; i += 256) {
+    const int ct = i >> 6, l = i & 63, ch = ct * 16 + (l & 15), kg = l >> 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kg * 8 + j;
+      float v;
+      if (k < 30) {
+        const float wv = w[ch * 10 + (k < 10 ? k : (k < 20 ? k - 10 : k - 20))] * c;
+        const float hi = (float)(_Float16)wv;
+        v = k < 20 ? hi : wv - hi;
+      } else {
+        const float bv = bias[ch] * cb;
+        const float hi = (float)(_Float16)bv;
+        v = k == 30 ? hi : bv - hi;
+      }
+      pack[i * 8 + j] = (_Float16)v;
+    }
+  }
+  if (tid == 0) {
+    ((int*)(pack + C0P_HALFS))[0] = cexp;
+    ((int*)(pack + C0P_HALFS))[1] = bexp;
+  }
+}
+
+template <class HT>
+__global__ __launch_bounds__(256, 2) void conv0_split_kernel(const float* __restrict__ wave, int L, int T0,
+                                                          const _Float16* __restrict__ pack, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int pre_emph, float pre_coef,
+                                                          typename HT::T* __restrict__ out) {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+  __shared__ float xs[C0M_FB * 5 + 16];
+  __shared__ __attribute__((aligned(16))) _Float16 xop[C0M_FB * 32];  // per frame: the 32 k-values of its B operand
+  __shared__ float Gs[C0M_FB];
+  __shared__ __attribute__((aligned(16))) _Float16 wsh[C0P_HALFS];
+  __shared__ float pv[2 * 512];  // gamma | beta
+  const int b = blockIdx.y, f0 = blockIdx.x * C0M_FB;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* x = wave + (long)b * L;
+  const int s0 = f0 * 5;
+  for (int i = tid; i < C0M_FB * 5 + 16; i += 256) {
+    const int gidx = s0 + i;
+    float v = 0.f;
+    if (gidx < L) {
+      v = x[gidx];
+      if (pre_emph) {
+        const int gp = gidx > 0 ? gidx - 1 : 1;  // reflect pad of one sample on the left
+        v -= pre_coef * x[gp];
+      }
+    }
+    xs[i] = v;
+  }
+  for (int i = tid; i < C0P_HALFS / 8; i += 256) ((uint4*)wsh)[i] = ((const uint4*)pack)[i];
+  const int cexp = ((const int*)(pack + C0P_HALFS))[0], bexp = ((const int*)(pack + C0P_HALFS))[1];
+  for (int i = tid; i < 512; i += 256) {
+    pv[i] = gamma[i];
+    pv[512 + i] = beta[i];
+  }
+  __syncthreads();
+  {  // thread = frame: scale, split, lay out the 32 k-values
+    float xv[10], m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      xv[j] = xs[tid * 5 + j];
+      m = fmaxf(m, fabsf(xv[j]));
+    }
+    const int eb = (int)((__float_as_uint(m) >> 23) & 0xff);
+    int ge = (eb > 0 && eb < 255 ? 127 - eb : 0) + cexp;  // exponent of G = S_f * c; S_f * m in [1, 2)
+    int qe = ge - bexp;                                   // G / cb is an fp16 operand (k = 30, 31): keep it normal
+    qe = qe < -14 ? -14 : (qe > 15 ? 15 : qe);
+    ge = qe + bexp;
+    const float S = ldexpf(1.0f, ge - cexp), G = ldexpf(1.0f, ge);
+    _Float16 h[32];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const float v = xv[j] * S;
+      const _Float16 hi = (_Float16)v;
+      h[j] = hi;
+      h[10 + j] = (_Float16)(v - (float)hi);
+      h[20 + j] = hi;
+    }
+    h[30] = h[31] = (_Float16)ldexpf(1.0f, qe);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f16x8 t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = h[q * 8 + j];
+      *(f16x8*)(xop + tid * 32 + q * 8) = t;
+    }
+    Gs[tid] = G;
+  }
+  __syncthreads();
+  const int fr = lane & 15, kq = lane >> 4;
+  for (int grp = 0; grp < 4; ++grp) {
+    const int fl = (wv * 4 + grp) * 16;  // first frame of this group inside the workgroup
+    if (f0 + fl >= T0) break;
+    const f16x8 bx = *(const f16x8*)(xop + (fl + fr) * 32 + kq * 8);
+    const float G = Gs[fl + fr];
+    f32x4 acc[32];
+#pragma unroll
+    for (int ct = 0; ct < 32; ++ct)
+      acc[ct] = FP16::mfma(*(const f16x8*)(wsh + (ct * 64 + lane) * 8), bx, f32x4{0.f, 0.f, 0.f, 0.f});
+    float sum = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 32; ++ct) sum += (acc[ct][0] + acc[ct][1]) + (acc[ct][2] + acc[ct][3]);
+    const float mean = rows_sum(sum) * (1.0f / 512.0f);
+    float sq = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 32; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[ct][r] -= mean;
+        sq = fmaf(acc[ct][r], acc[ct][r], sq);
+      }
+    const float rstd = 1.0f / sqrtf(rows_sum(sq) * (1.0f / 512.0f) + (G * G) * 1e-5f);
+    const int f = f0 + fl + fr;
+    T* orow = out + ((long)b * T0 + (f < T0 ? f : T0 - 1)) * 512;
+    const int cb = (kq & 1) * 16 + (kq >> 1) * 8;
+#pragma unroll
+    for (int cp = 0; cp < 16; ++cp) {  // channel-tile pairs -> 8 consecutive channels per lane
+      f32x4 va, vb;
+      {
+        const f32x4 g0 = *(const f32x4*)(pv + cp * 32 + kq * 4), b0 = *(const f32x4*)(pv + 512 + cp * 32 + kq * 4);
+        const f32x4 g1 = *(const f32x4*)(pv + cp * 32 + 16 + kq * 4), b1 = *(const f32x4*)(pv + 512 + cp * 32 + 16 + kq * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          va[r] = fmaf(acc[2 * cp][r] * rstd, g0[r], b0[r]);
+          vb[r] = fmaf(acc[2 * cp + 1][r] * rstd, g1[r], b1[r]);
+        }
+        gelu_poly8(va, vb);
+      }
+      V8 h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va[r]), __float_as_uint(vb[r]), false, false);
+        h[r] = (T)__uint_as_float(sw[0]);
+        h[4 + r] = (T)__uint_as_float(sw[1]);
+      }
+      if (f < T0) *(V8*)(orow + cp * 32 + cb) = h;
+    }
+  }
+}
+
+size_t conv0_pack_bytes() { return (size_t)C0P_HALFS * 2 + 16; }
+const char* launch_conv0_pack(const float* w, const float* bias, void* pack, hipStream_t s) {
+  if (!w || !bias || !pack) return "conv0_pack: null argument";
+  hipLaunchKernelGGL(conv0_pack_kernel, dim3(1), dim3(256), 0, s, w, bias, (_Float16*)pack);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------
 // conv layer 0 of the wav2vec2-*base* feature extractor (fairseq extractor_mode="default"; SURVEY 8a row 1a, the
 // "GroupNorm/GELU" `north_star` names): bias-free Conv1d(1 -> 512, k=10, s=5) -> GroupNorm(512 groups of one channel
 // = per (utterance, channel) normalisation over TIME, affine) -> erf-GELU.  The statistics span the whole clip, so
@@ -315,8 +504,19 @@ size_t conv0_groupnorm_stats_floats(int B, int T0) { return (size_t)B * (((size_
 
 const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w, const float* bias,
                          const float* gamma, const float* beta, int pre_emph, float pre_coef, void* out_h,
-                         int dtype, hipStream_t s) {
+                         int dtype, hipStream_t s, const void* wpack) {
   if (B <= 0 || L < 10 || T0 != (L - 10) / 5 + 1) return "conv0: bad shape";
+  if (dtype != DT_FP32 && g_conv0_mfma == 1 && wpack) {  // split precision on the fp16 matrix pipe (packed operand given)
+    dim3 grid((T0 + C0M_FB - 1) / C0M_FB, B);
+    if (dtype == DT_BF16)
+      hipLaunchKernelGGL(conv0_split_kernel<BF16>, grid, dim3(256), 0, s, wave, L, T0, (const _Float16*)wpack, gamma, beta,
+                         pre_emph, pre_coef, (__bf16*)out_h);
+    else
+      hipLaunchKernelGGL(conv0_split_kernel<FP16>, grid, dim3(256), 0, s, wave, L, T0, (const _Float16*)wpack, gamma, beta,
+                         pre_emph, pre_coef, (_Float16*)out_h);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+  }
   if (dtype != DT_FP32 && g_conv0_mfma) {
     dim3 grid((T0 + C0M_FB - 1) / C0M_FB, B);
     if (dtype == DT_BF16)
@@ -334,7 +534,7 @@ const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
-void conv0_set_mfma(int v) { g_conv0_mfma = v != 0; }
+void conv0_set_mfma(int v) { g_conv0_mfma = v; }
 
 // ---------------------------------------------------------------------------------
 // Stand-alone pre-emphasis (data/preprocess.py:16-29) for callers that apply it as a

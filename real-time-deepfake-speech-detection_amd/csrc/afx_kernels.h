@@ -68,7 +68,11 @@ bool gemm_set_nodma(int v);     // timing-only knob (attribution build, -DAFX_AT
 // conv layer 0 (Cin=1,k=10,s=5) + LayerNorm(512) + erf-GELU; optional pre-emphasis.
 const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w /*[512][10]*/,
                          const float* bias, const float* gamma, const float* beta, int pre_emph,
-                         float pre_coef, void* out_h, int dtype, hipStream_t s);
+                         float pre_coef, void* out_h, int dtype, hipStream_t s, const void* wpack = nullptr);
+// wpack: the layer's weights + bias as the split-precision fp16 MFMA operand (conv0_pack_bytes() bytes, built once per
+// checkpoint by launch_conv0_pack); with it the half-precision engines run the layer on the fp16 matrix pipe at fp32 accuracy
+size_t conv0_pack_bytes();
+const char* launch_conv0_pack(const float* w /*[512][10]*/, const float* bias, void* pack, hipStream_t s);
 // the wav2vec2-base form of layer 0: bias-free conv -> GroupNorm(512,512) (per utterance and channel, over time) -> GELU;
 // stats: scratch of conv0_groupnorm_stats_floats(B, T0) floats
 const char* launch_conv0_groupnorm(const float* wave, int B, int L, int T0, const float* w, const float* gamma,
@@ -77,7 +81,7 @@ size_t conv0_groupnorm_stats_floats(int B, int T0);
 // ragged batch (packed, offs[B+1]) -> (B, duration): out[b][i] = x_b[(start_b + i) mod n_b]; starts may be null
 const char* launch_tile_crop(const float* x, const long long* offs, const long long* starts, int B, int duration,
                              float* out, hipStream_t s);
-void conv0_set_mfma(int v);  // A/B knob: 1 (default) = fp32 matrix-core form, 0 = VALU form
+void conv0_set_mfma(int v);  // A/B knob: 1 (default) = matrix-core forms (split-precision fp16 when packed), 2 = fp32 MFMA form, 0 = VALU form
 // y[t] = x[t] - coef * x[t-1] with a reflect pad on the left; (B,L) fp32 -> (B,L) fp32
 const char* launch_pre_emphasis(const float* x, int B, int L, float coef, float* y, hipStream_t s);
 // rows x C fp32 -> LayerNorm (optional activation) -> fp32 and/or operand-type outputs.

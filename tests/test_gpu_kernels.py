@@ -273,6 +273,38 @@ def test_conv0_layernorm_gelu(K, dtype, pre):
     _close(got, ref, _eps(dtype), 2e-3 if dtype == "fp16" else 1e-2)
 
 
+@pytest.mark.parametrize("amp,wscale", [(0.1, 1.0), (1e-4, 1.0), (30.0, 1.0), (0.05, 0.01), (3e-7, 20.0)])
+def test_conv0_split_precision_form_is_fp32_accurate_at_any_level(K, amp, wscale):
+    """The half-precision engines run conv layer 0 as ONE fp16 MFMA per tile (hi/lo split of samples and weights, per-frame
+    and per-layer power-of-two scaling folded into the LayerNorm).  Against the true-fp32 matrix-core form of the same
+    layer (conv0_mfma = 2) the fp16 outputs may differ only where a value sits on a rounding boundary -- whatever the
+    recording level and the weight scale, silence between loud frames included."""
+    from afx._lib import check, lib
+    g = torch.Generator().manual_seed(int(amp * 1e7) % 1000 + 3)
+    wave = torch.randn(2, 8000 + 3, generator=g) * amp
+    wave[0, 1000:1400] *= 1e-3      # a quiet stretch inside a loud clip: the scale is per frame
+    wave[1, 3000:3050] = 0.0        # digital silence: the bias decides
+    w = torch.randn(512, 1, 10, generator=g) * math.sqrt(0.2) * wscale
+    b = torch.randn(512, generator=g) * 0.02
+    ga = 1 + 0.1 * torch.randn(512, generator=g)
+    be = 0.1 * torch.randn(512, generator=g)
+    args = (wave.cuda(), w.cuda(), b.cuda(), ga.cuda(), be.cuda())
+    try:
+        check(lib().afx_debug_set(b"conv0_mfma", 2))
+        want = K.conv0("fp16", *args).float()
+        check(lib().afx_debug_set(b"conv0_mfma", 1))
+        got = K.conv0("fp16", *args).float()
+    finally:
+        check(lib().afx_debug_set(b"conv0_mfma", 1))
+    ref = F.gelu(F.layer_norm(F.conv1d(wave.double().unsqueeze(1), w.double(), b.double(), stride=5).transpose(1, 2), (512,),
+                              ga.double(), be.double(), 1e-5)).float()
+    ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14)) * 2.0 ** -10
+    assert ((got.cpu() - ref).abs() <= 1.01 * ulp + 4e-6).all(), float(((got.cpu() - ref).abs() / ulp).max())
+    differ = (got != want).float().mean().item()
+    assert differ < 2e-3, differ  # one-ulp disagreements on rounding boundaries only
+    assert ((got - want).abs().cpu() <= 2.02 * ulp + 4e-6).all()  # each within one ulp of the exact value
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("C,act", [(512, "gelu"), (1024, None), (144, None)])
 def test_row_layernorm(K, dtype, C, act):
