@@ -24,8 +24,11 @@ namespace afx {
 constexpr int ATT_KEYS = 224;       // padded key capacity (7 k-steps of 32)
 constexpr int ATT_VT_STRIDE = 232;  // halfs per V^T row: 464 B, conflict-free ds_read_b64
 
-template <class HT, int KS>  // KS = number of 32-key steps actually computed
-__global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __restrict__ qkv,
+// NW waves per workgroup: the 16-query tiles of a head are dealt to the waves round-robin, so the compute phase is
+// ceil(tiles / NW) tiles long -- 13 tiles (T = 199): 4 with four waves, 2 with seven (and 1 when the tiles are split over
+// two workgroups, B x H < 512); the staging loop is spread over all threads.
+template <class HT, int KS, int NW>  // KS = number of 32-key steps actually computed
+__global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typename HT::T* __restrict__ qkv,
                                                    typename HT::T* __restrict__ out, int T, int H, float scale,
                                                    const int* __restrict__ lens) {
   typedef typename HT::T Tt;
@@ -52,13 +55,14 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
   // all global loads of the thread first, then the LDS writes: issued one (load, wait, write) step at a
   // time the staging was 7 dependent L2 round trips and most of this kernel's time
   {
-    constexpr int IT = KEYS * 8 / 256;
-    static_assert(KEYS * 8 % 256 == 0, "staging loop shape");
+    constexpr int NT = 64 * NW;
+    constexpr int IT = KEYS * 8 / NT;
+    static_assert(KEYS * 8 % NT == 0, "staging loop shape");
     u32x4 kreg[IT];
     V8 vreg[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const int idx = tid + it * 256, key = idx >> 3, c = idx & 7;
+      const int idx = tid + it * NT, key = idx >> 3, c = idx & 7;
       kreg[it] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
       for (int i = 0; i < 8; ++i) vreg[it][i] = (Tt)0.f;
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const int idx = tid + it * 256, key = idx >> 3, c = idx & 7;
+      const int idx = tid + it * NT, key = idx >> 3, c = idx & 7;
       *(u32x4*)(k_lds + key * 128 + ((c ^ ((key >> 1) & 7)) * 16)) = kreg[it];
       if (!(MHSA_DBG & 4)) {
 #pragma unroll
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
       }
     }
   }
-  if (tid < KEYS) mask_lds[tid] = tid < T ? 0.f : -1e30f;
+  for (int i = tid; i < KEYS; i += 64 * NW) mask_lds[i] = i < T ? 0.f : -1e30f;
   __syncthreads();
   if (MHSA_DBG & 2) return;
 
@@ -96,10 +100,10 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const typename HT::T* __re
   };
   V8 qnext[2];
   if (qt_first + wave < nqt) load_q(qt_first + wave, qnext);
-  for (int qt = qt_first + wave; qt < nqt; qt += 4) {
+  for (int qt = qt_first + wave; qt < nqt; qt += NW) {
     const int q0 = qt * 16;
     V8 qf[2] = {qnext[0], qnext[1]};
-    if (qt + 4 < nqt) load_q(qt + 4, qnext);  // the next tile's Q rows are in flight under this tile's work
+    if (qt + NW < nqt) load_q(qt + NW, qnext);  // the next tile's Q rows are in flight under this tile's work
 
     // S^T tiles: s[kt][r] = S[q0+ql][16kt + 4g + r].  Two key tiles at a time (4 fragment reads in
     // flight, then 4 MFMAs on two accumulators): the sched_barriers stop hipcc from hoisting all 28
@@ -392,6 +396,8 @@ __global__ __launch_bounds__(256, 2) void mhsa_long_kernel(const typename HT::T*
 
 static int g_mhsa_force_long = 0;  // test knob: the blocked kernel at any length
 void mhsa_set_force_long(int v) { g_mhsa_force_long = v != 0; }
+static int g_mhsa_waves = 7;  // A/B knob: waves per workgroup of the one-pass kernel beyond 128 frames (4 or 7)
+void mhsa_set_waves(int v) { g_mhsa_waves = v == 4 ? 4 : 7; }
 
 template <class HT>
 static void launch_mhsa_t(const void* qkv, void* out, int B, int T, int H, float scale, const int* lens, hipStream_t s) {
@@ -401,11 +407,13 @@ static void launch_mhsa_t(const void* qkv, void* out, int B, int T, int H, float
   if (T > ATT_KEYS || g_mhsa_force_long)
     hipLaunchKernelGGL((mhsa_long_kernel<HT>), dim3(H, B, (T + 63) / 64), blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
   else if (T <= 64)
-    hipLaunchKernelGGL((mhsa_kernel<HT, 2>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
+    hipLaunchKernelGGL((mhsa_kernel<HT, 2, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
   else if (T <= 128)
-    hipLaunchKernelGGL((mhsa_kernel<HT, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
+    hipLaunchKernelGGL((mhsa_kernel<HT, 4, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
+  else if (g_mhsa_waves == 4)
+    hipLaunchKernelGGL((mhsa_kernel<HT, 7, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
   else
-    hipLaunchKernelGGL((mhsa_kernel<HT, 7>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
+    hipLaunchKernelGGL((mhsa_kernel<HT, 7, 7>), grid, dim3(448), 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
 }
 
 const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t s, const int* lens) {

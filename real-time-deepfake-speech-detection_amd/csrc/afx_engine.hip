@@ -1335,6 +1335,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
     gemm_set_fit(value);
     return 0;
   }
+  if (!strcmp(key, "mhsa_waves")) {
+    mhsa_set_waves(value);
+    return 0;
+  }
   if (!strcmp(key, "mhsa_force_long")) {
     mhsa_set_force_long(value);
     return 0;
