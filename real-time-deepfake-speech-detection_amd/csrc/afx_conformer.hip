@@ -209,8 +209,11 @@ const char* launch_conf_attn(const float* q, long ldq, const float* kv, long ldk
 // ---------------------------------------------------------------------------------
 constexpr int CA_KEYS = 224, CA_VT_STRIDE = 232, CA_RS = 228, CA_NKT = 14, CA_KS = 7;
 
-template <class HT, int DH>
-__global__ __launch_bounds__(256) void conf_attn_mfma_kernel(const float* __restrict__ q, long ldq,
+// NW waves per workgroup (4 or 7): the 13 query tiles of a 200-token head are dealt round-robin, 2 per wave with seven
+// waves instead of 4 with four; 152 KB of LDS (a 14.6-KB skew tile per wave) -- one workgroup per CU either way, and at
+// batch 64 there are exactly B x H = 256 of them.
+template <class HT, int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void conf_attn_mfma_kernel(const float* __restrict__ q, long ldq,
                                                              const float* __restrict__ kv, long ldkv,
                                                              const typename HT::T* __restrict__ rel_h, int max_pos,
                                                              int N, int H, typename HT::T* __restrict__ out, long ldo,
@@ -226,20 +229,21 @@ __global__ __launch_bounds__(256) void conf_attn_mfma_kernel(const float* __rest
   char* sm = (char*)sm_f;
   char* k_lds = sm;                                        // [224][128 B]
   Tt* vt_lds = (Tt*)(sm + CA_KEYS * 128);                  // [16 DT][232]
-  float* r_lds = (float*)(sm + CA_KEYS * 128 + 16 * DT * CA_VT_STRIDE * 2);  // [4 waves][16][228]
+  float* r_lds = (float*)(sm + CA_KEYS * 128 + 16 * DT * CA_VT_STRIDE * 2);  // [NW waves][16][228]
+  constexpr int NT = 64 * NW;
 
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int inner = H * DH;
   // ---- stage K (fp16, swizzled, zero padded) and V^T ---------------------------------
-  for (int i = tid; i < (CA_KEYS * 128 + 16 * DT * CA_VT_STRIDE * 2) / 16; i += 256) ((u32x4*)sm)[i] = u32x4{0u, 0u, 0u, 0u};
+  for (int i = tid; i < (CA_KEYS * 128 + 16 * DT * CA_VT_STRIDE * 2) / 16; i += NT) ((u32x4*)sm)[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
   {  // all of the thread's global loads first, then the LDS writes (one dependent L2 round trip, not eight)
-    constexpr int IT = (209 * (DH / 4) + 255) / 256;
+    constexpr int IT = (209 * (DH / 4) + NT - 1) / NT;
     f32x4 kreg[IT], vreg[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const int idx = tid + it * 256;
+      const int idx = tid + it * NT;
       if (idx < N * (DH / 4)) {
         const int key = idx / (DH / 4), q4 = idx % (DH / 4);
         const float* row = kv + ((long)b * Nrow + key) * ldkv + h * DH + q4 * 4;
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256) void conf_attn_mfma_kernel(const float* __rest
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const int idx = tid + it * 256;
+      const int idx = tid + it * NT;
       if (idx < N * (DH / 4)) {
         const int key = idx / (DH / 4), q4 = idx % (DH / 4);
         V4 kh;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256) void conf_attn_mfma_kernel(const float* __rest
   const float scale = 1.0f / sqrtf((float)DH);
   float* rw = r_lds + wave * 16 * CA_RS;
   const int nqt = (N + 15) >> 4;
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += NW) {
     const int q0 = qt * 16;
     int qrow = q0 + ql;
     qrow = qrow < N ? qrow : N - 1;
@@ -591,6 +595,8 @@ __global__ __launch_bounds__(256, 2) void conf_attn_mfma_long_kernel(const float
 
 static int g_conf_attn_force_long = 0;  // test knob: the blocked kernel at every length
 void conf_attn_mfma_set_force_long(int v) { g_conf_attn_force_long = v != 0; }
+static int g_conf_attn_waves = 7;  // A/B knob: waves per workgroup of the one-pass kernel (4 or 7)
+void conf_attn_mfma_set_waves(int v) { g_conf_attn_waves = v == 4 ? 4 : 7; }
 
 const char* launch_conf_attn_mfma(const float* q, long ldq, const float* kv, long ldkv, const void* rel_h, int max_pos,
                                   int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s,
@@ -619,20 +625,23 @@ const char* launch_conf_attn_mfma(const float* q, long ldq, const float* kv, lon
     if (el == hipSuccess) el = hipGetLastError();
     return el == hipSuccess ? nullptr : hipGetErrorString(el);
   }
-  const int lds = CA_KEYS * 128 + 16 * DT * CA_VT_STRIDE * 2 + 4 * 16 * CA_RS * 4;
+  const int nw = N > 64 && g_conf_attn_waves != 4 ? 7 : 4;  // more than 4 query tiles: seven waves
+  const int lds = CA_KEYS * 128 + 16 * DT * CA_VT_STRIDE * 2 + nw * 16 * CA_RS * 4;
   hipError_t e = hipSuccess;
-  static LdsLimit lim[2];
+  static LdsLimit lim[4];
+#define AFX_CAM(HTv, NWv, slot, Tv)                                                                                      \
+  do {                                                                                                                   \
+    e = lim[slot].ensure((const void*)conf_attn_mfma_kernel<HTv, 36, NWv>, lds);                                         \
+    if (e == hipSuccess)                                                                                                 \
+      hipLaunchKernelGGL((conf_attn_mfma_kernel<HTv, 36, NWv>), dim3(H, B), dim3(64 * NWv), lds, s, q, ldq, kv, ldkv,    \
+                         (const Tv*)rel_h, max_pos, N, H, (Tv*)out_h, ldo, lens, len_add);                               \
+  } while (0)
   if (dtype == DT_BF16) {
-    e = lim[0].ensure((const void*)conf_attn_mfma_kernel<BF16, 36>, lds);
-    if (e == hipSuccess)
-      hipLaunchKernelGGL((conf_attn_mfma_kernel<BF16, 36>), dim3(H, B), dim3(256), lds, s, q, ldq, kv, ldkv, (const __bf16*)rel_h,
-                         max_pos, N, H, (__bf16*)out_h, ldo, lens, len_add);
+    if (nw == 7) AFX_CAM(BF16, 7, 0, __bf16); else AFX_CAM(BF16, 4, 1, __bf16);
   } else {
-    e = lim[1].ensure((const void*)conf_attn_mfma_kernel<FP16, 36>, lds);
-    if (e == hipSuccess)
-      hipLaunchKernelGGL((conf_attn_mfma_kernel<FP16, 36>), dim3(H, B), dim3(256), lds, s, q, ldq, kv, ldkv, (const _Float16*)rel_h,
-                         max_pos, N, H, (_Float16*)out_h, ldo, lens, len_add);
+    if (nw == 7) AFX_CAM(FP16, 7, 2, _Float16); else AFX_CAM(FP16, 4, 3, _Float16);
   }
+#undef AFX_CAM
   if (e == hipSuccess) e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -1335,6 +1335,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
     gemm_set_fit(value);
     return 0;
   }
+  if (!strcmp(key, "conf_attn_waves")) {
+    conf_attn_mfma_set_waves(value);
+    return 0;
+  }
   if (!strcmp(key, "mhsa_waves")) {
     mhsa_set_waves(value);
     return 0;

@@ -60,6 +60,7 @@ void gemm_set_fit(int v);       // A/B knob: 1 (default) = 8-phase tile height f
 void gemm_set_split(int v);     // A/B knob: 1 (default) = whole rounds on the 8-phase kernel + 128x128 remainder rows
 void mhsa_set_waves(int v);        // A/B knob: 4 or 7 (default) waves per workgroup of the one-pass trunk attention
 void mhsa_set_force_long(int v);   // test knob: the blocked any-length trunk attention kernel at every length
+void conf_attn_mfma_set_waves(int v);       // A/B knob: 4 or 7 (default) waves per workgroup of the one-pass Shaw attention
 void conf_attn_mfma_set_force_long(int v);  // test knob: the blocked matrix-core Shaw attention at every length
 void conf_attn_set_block(int v);   // test knob: keys per LDS block of the fp32 attention (0 = automatic)
 void gemm_set_deep(int v);      // A/B knob, conv tile: 0 = 2-stage kernel, -1/2 = 8-phase kernel (default)
