@@ -164,7 +164,7 @@ def main():
         # the QKV and FC1 products run as the 8-phase kernel on the rows that fill whole rounds of CUs plus a
         # 128x128-tile kernel on the remaining rows; the pair is ONE timed launch here, two rows in rocprofv3's
         # kernel stats: avg_launch_us = avg(8-phase) + (remainder launches / 8-phase launches) x avg(remainder)
-        "launch_note": "one launch = one GEMM of the path; round-split GEMMs (8-phase kernel + 128x128 remainder kernel) are timed as one",
+        "launch_note": "one launch = one GEMM of the path (all tile heights of the class; a round-split GEMM = 8-wave kernel + 128x128 remainder kernel is timed as one)",
     }
     breakdown = {k: round(v["ms"] / args.steps, 4) for k, v in prof.items() if v["launches"]}
     # HBM traffic of that kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: FETCH_SIZE x 2
@@ -172,10 +172,12 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", PMC_FILES[args.workload])
     if os.path.exists(pmc_path) and B == (64 if args.workload == "conformer_student" else 16) and args.dtype != "fp32":
         kern = dom.split("<")[0] + "<afx::" + args.dtype.upper() + ", " + dom.split("<")[1].rstrip(">").split(",")[0].replace("x", ", ")
-        for name, rec in json.load(open(pmc_path))["kernels"].items():
-            if name.startswith("afx::" + kern):
-                roofline["traffic"] = round(rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"])
-                roofline["traffic_unit"] = f"HBM bytes per launch (rocprofv3 PMC, profiles/{PMC_FILES[args.workload]})"
+        # every height of the tile (160..256 rows) is one instance of the class: launch-weighted mean over them
+        recs = [r for name, r in json.load(open(pmc_path))["kernels"].items() if name.startswith("afx::" + kern)]
+        n = sum(r["launches_sampled"] for r in recs)
+        if n:
+            roofline["traffic"] = round(sum((r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches_sampled"] for r in recs) / n)
+            roofline["traffic_unit"] = f"HBM bytes per launch (rocprofv3 PMC, profiles/{PMC_FILES[args.workload]})"
 
     result = {
         "metric": "utterances/sec (4 s @ 16 kHz)" if args.seconds == 4.0 else f"utterances/sec ({args.seconds:g} s @ 16 kHz)", "value": round(value, 2), "unit": "utterances/s",
