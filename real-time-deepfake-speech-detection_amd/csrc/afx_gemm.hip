@@ -1077,7 +1077,7 @@ const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t
     // 123.7 against 121.1 as 4 rounds for FC1 -- profiles/r02_gemm_dma_spread_ab.txt)
     long fitted = 0;
     gemm8_fit_mf(p, &fitted);
-    const long split = ((long)(m1 / 256) * ((p.N + 255) / 256) / 256) * 13 + 10;
+    const long split = (((long)(m1 / 256) * ((p.N + 255) / 256) + 255) / 256) * 13 + 10;
     if (g_fit == 1 && fitted <= split) m1 = 0;
   }
   if (m1 > 0) {  // rows [0, m1) on the 8-phase kernel, rows [m1, M) on the 128x128 kernel
