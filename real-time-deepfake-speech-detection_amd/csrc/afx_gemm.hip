@@ -25,7 +25,7 @@
 
 // Timing-only switches of the epilogue (GemmArgs::dbg_nodma: 8 no activation, 16 narrow stores, 32 no stores,
 // 64 no epilogue; 8-phase K-loop: 128 / 256 / 512 / 1024 one half-tile's operand DMA off, 2048 no MFMAs, 4096 no LDS
-// fragment reads -- WRONG results) exist only in the attribution build (make attr -> lib/libafx_attr.so,
+// fragment reads; 8192 the clock-stamping instance (stamps overwrite the head of out_h) -- WRONG results) exist only in the attribution build (make attr -> lib/libafx_attr.so,
 // -DAFX_ATTR, loaded through AFX_LIB by tools/bench_convln_attr.py / bench_gemm_k.py); the product library
 // compiles them out, so no environment variable or debug key can switch results off.
 #ifdef AFX_ATTR
@@ -536,7 +536,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // 228 tiles of 224 rows instead of 200 of 256; M = 16 x 199, N = 3072: 240 tiles of 160 rows instead of 156), so a
 // sub-round product pays 7/8 or 5/8 of the K-loop instead of idling a fifth to a third of the chip.  Per-row results
 // do not depend on the height (same K order).
-template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, int PH = 1>
+// TS (attribution build only): every wave stamps the shader clock at five points of each phase of the FIRST output tile
+// (start of the read part / DMA landed + reads retired / first barrier passed / MFMAs issued / second barrier passed) into
+// 16 KB of LDS behind the operand buffers; workgroup 0 dumps them over the head of out_h at the end (tools/kloop_timeline.py).
+template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, int PH = 1, bool TS = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
@@ -772,11 +775,22 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   //        of the other row needs it: end of B_t-1 -> R0 R1 F0 of tile t (read from A_t), end of A_t -> F1 of tile t
   //        (read from B_t).  In issue order the queue then holds [F1(t+1) 2] [R0R1F0(t+2) 6] behind what is needed:
   //        vmcnt(8) in steady state; every transfer has a whole K-tile of time to land.
+  unsigned long long* ts_lds = (unsigned long long*)(smem + 2 * BUF);  // [8 waves][16 K-tiles][16 stamps]
+  bool ts_on = TS;
+  auto stamp = [&](int t, int slot) {
+    if constexpr (TS) {
+      if (ts_on && t < 16) {
+        const unsigned long long c = __builtin_readcyclecounter();
+        if (lane == 0) ts_lds[(wave * 16 + t) * 16 + slot] = c;
+      }
+    }
+  };
   auto ktile2 = [&](auto bufc, int t) {
     constexpr int b = decltype(bufc)::value;
     constexpr int NF1 = WIDE ? DB : DA, NRRF = 2 * (WIDE ? DA : DB) + (WIDE ? DB : DA);  // DMAs per wave: F1; R0+R1+F0
     const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
     // ---- phase A
+    stamp(t, 0);
     readR(b, 0);
     readR(b, 1);
     readF(b, 0);
@@ -785,10 +799,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     if (more1) wait_vmcnt<NF1 + NRRF>();  // F1(t) has landed; R0R1F0(t+1), F1(t+1) stay in flight
     else wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stamp(t, 1);
     AFX_BAR();
+    stamp(t, 2);
     quadFR(0, 0);
     quadFR(0, 1);
+    stamp(t, 3);
     AFX_BAR();
+    stamp(t, 4);
     // ---- phase B
     readF(b, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -803,10 +821,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
       wait_vmcnt<0>();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stamp(t, 5);
     AFX_BAR();
+    stamp(t, 6);
     quadFR(1, 1);
     quadFR(1, 0);
+    stamp(t, 7);
     AFX_BAR();
+    stamp(t, 8);
   };
   auto issue_prologue2 = [&] {
     stageR(0, 0, 0);
@@ -880,18 +902,24 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     } else {
       gemm_epilogue<HT, BMC, BN, 2, 4, ROWLN, true>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
     }
+    ts_on = false;
     if (vn >= nwg) break;
     v = vn;
+  }
+  if constexpr (TS) {
+    __syncthreads();
+    if (blockIdx.x == 0 && p.out_h)
+      for (int i = tid; i < 8 * 16 * 16; i += 512) ((unsigned long long*)p.out_h)[i] = ts_lds[i];
   }
 #undef AFX_BAR
 }
 
-template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, int PH = 1>
+template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, int PH = 1, bool TS = false>
 static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
-  constexpr int lds = 2 * (BM + BN) * 128;
+  constexpr int lds = 2 * (BM + BN) * 128 + (TS ? 16384 : 0);
   static_assert(lds <= 160 * 1024, "two K-tile buffers must fit the 160 KB LDS");
   static LdsLimit lim;
-  if (hipError_t e = lim.ensure((const void*)gemm8_kernel<HT, BM, BN, ROWLN, MF, PH>, lds); e != hipSuccess) return e;
+  if (hipError_t e = lim.ensure((const void*)gemm8_kernel<HT, BM, BN, ROWLN, MF, PH, TS>, lds); e != hipSuccess) return e;
   static int n_cu_of[kMaxDevices] = {0};  // (benign if two threads fill the same slot: same value)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
@@ -904,7 +932,7 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   const int n_cu = n_cu_of[dev];
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + MF * 32 - 1) / (MF * 32));
   dim3 grid(tiles < n_cu ? tiles : n_cu, 1, groups);  // persistent: at most one workgroup per CU
-  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN, MF, PH>), grid, dim3(512), lds, s, p);
+  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN, MF, PH, TS>), grid, dim3(512), lds, s, p);
   return hipGetLastError();
 }
 
@@ -1049,7 +1077,11 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 1: return lean ? launch_gemm_t<HT, 128, 64, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 64, 2, 2>(p, groups, s);
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
-    case 7: return g_ph4 ? launch_gemm8_t<HT, 256, 256, false, 8, 0>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
+    case 7:
+#ifdef AFX_ATTR
+      if (p.dbg_nodma & 8192) return launch_gemm8_t<HT, 256, 256, false, 8, 1, true>(p, groups, s);  // clock stamps (TS)
+#endif
+      return g_ph4 ? launch_gemm8_t<HT, 256, 256, false, 8, 0>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
     case 75: return launch_gemm8_t<HT, 256, 256, false, 5>(p, groups, s);
     case 76: return launch_gemm8_t<HT, 256, 256, false, 6>(p, groups, s);
     case 77: return launch_gemm8_t<HT, 256, 256, false, 7>(p, groups, s);
