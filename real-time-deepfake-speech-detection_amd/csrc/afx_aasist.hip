@@ -607,10 +607,22 @@ __global__ void att_pool_kernel(const float* __restrict__ x, const float* __rest
   }
 }
 
+// Several independent small problems of one shape class in ONE launch (blockIdx.z picks the problem): the graph stage is
+// a chain of launches a few microseconds long, and its two HS-GAL branches, the spectral / temporal graphs and the two
+// node types of a layer are independent of each other -- 21 launches per forward become 8.
+struct RowlinArgs {
+  const float* x; long ldx; int rows, K; const float *W, *bias; int N; float* y; long ldy; int rpb, o_batch_rows, o_row_off;
+};
+struct RowlinMulti { RowlinArgs q[4]; };
 // y[r][o] = b[o] + W[o] . x[r]   (rows of <= 64 features; wave per row, lane per output)
-__global__ void rowlin_kernel(const float* __restrict__ x, long ldx, int rows, int K, const float* __restrict__ W,
-                              const float* __restrict__ bias, int N, float* __restrict__ y, long ldy, int rpb,
-                              int o_batch_rows, int o_row_off) {
+__global__ void rowlin_kernel(RowlinMulti mm) {
+  const RowlinArgs& q = mm.q[blockIdx.z];
+  const float* __restrict__ x = q.x;
+  const float* __restrict__ W = q.W;
+  const float* __restrict__ bias = q.bias;
+  float* __restrict__ y = q.y;
+  const long ldx = q.ldx, ldy = q.ldy;
+  const int rows = q.rows, K = q.K, N = q.N, rpb = q.rpb, o_batch_rows = q.o_batch_rows, o_row_off = q.o_row_off;
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows || lane >= N) return;
@@ -648,13 +660,16 @@ struct GatArgs {
   float* master_out;  // (B, DOUT)
 };
 
+struct GatMulti { GatArgs a[2]; };
 template <int DIN, int DOUT>
-__global__ __launch_bounds__(256) void gat_kernel(GatArgs p) {
+__global__ __launch_bounds__(256) void gat_kernel(GatMulti pp) {
   constexpr int JPW = 64 / DOUT;  // nodes handled at once by one wave
-  // dynamic LDS, sized by the launcher for this graph: node features, attention row, aggregate
+  // dynamic LDS, sized by the launcher for the larger graph: node features, attention row, aggregate
   extern __shared__ __attribute__((aligned(16))) float gat_lds[];
+  const GatArgs& p = pp.a[blockIdx.z];
   const int b = blockIdx.y, i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = p.N;
+  if (i > N || (i == N && !p.master)) return;  // the grid covers the larger of the two graphs (+ its master node)
   float* xs = gat_lds;                     // [N][DIN]
   float* agg = xs + (long)N * DIN;         // [64]
   float* att = agg + 64;                   // [N]
@@ -731,18 +746,23 @@ __global__ __launch_bounds__(256) void gat_kernel(GatArgs p) {
   }
 }
 
-static const char* launch_gat(const GatArgs& a, int B, int din, int dout, hipStream_t s) {
+// one or two graphs of the same layer dims in one launch (a1 may be null)
+static const char* launch_gat(const GatArgs& a, int B, int din, int dout, hipStream_t s, const GatArgs* a1 = nullptr) {
   // one workgroup per node keeps the whole graph's features in LDS: 4-s clips have <= 66 nodes (17 KB); the
   // 160 KB of a CU hold 630 nodes = clips of about 37 s (test_duration_sec is a free config value)
-  const int lds = (int)(((long)a.N * din + 64 + a.N + 8) * sizeof(float));
-  if (a.N < 1 || lds > 160 * 1024) return "aasist: graph has too many nodes for the LDS slab (clip longer than ~37 s)";
-  dim3 grid(a.N + (a.master ? 1 : 0), B);
+  const int nmax = a1 && a1->N > a.N ? a1->N : a.N;
+  const int lds = (int)(((long)nmax * din + 64 + nmax + 8) * sizeof(float));
+  if (a.N < 1 || (a1 && a1->N < 1) || lds > 160 * 1024) return "aasist: graph has too many nodes for the LDS slab (clip longer than ~37 s)";
+  GatMulti mm;
+  mm.a[0] = a;
+  mm.a[1] = a1 ? *a1 : a;
+  dim3 grid(nmax + ((a.master || (a1 && a1->master)) ? 1 : 0), B, a1 ? 2 : 1);
   hipError_t e = hipSuccess;
   static LdsLimit lim[3];
 #define AFX_GAT(IDX, DI, DO)                                                                                          \
   do {                                                                                                                \
     if (lds > 48 * 1024) e = lim[IDX].ensure((const void*)gat_kernel<DI, DO>, lds);                                   \
-    if (e == hipSuccess) hipLaunchKernelGGL((gat_kernel<DI, DO>), grid, dim3(256), lds, s, a);                        \
+    if (e == hipSuccess) hipLaunchKernelGGL((gat_kernel<DI, DO>), grid, dim3(256), lds, s, mm);                       \
   } while (0)
   if (din == 64 && dout == 64)
     AFX_GAT(0, 64, 64);
@@ -759,9 +779,16 @@ static const char* launch_gat(const GatArgs& a, int B, int din, int dout, hipStr
 
 // GraphPool (models/aasist_modules.py:296-338): s = sigmoid(w.h + b); keep the top
 // max(int(N*k),1) nodes in DESCENDING score order; out = h * s.  One block per utterance.
-__global__ void graph_pool_kernel(const float* __restrict__ h, int N, int D, int keep, const float* __restrict__ w,
-                                  const float* __restrict__ bias, float* __restrict__ out) {
-  extern __shared__ float sc[];  // [N]; one thread per node (block = N rounded up to a wave)
+struct PoolArgs { const float* h; int N, D, keep; const float *w, *bias; float* out; };
+struct PoolMulti { PoolArgs q[4]; };
+__global__ void graph_pool_kernel(PoolMulti mm) {
+  const PoolArgs& a = mm.q[blockIdx.z];
+  const float* __restrict__ h = a.h;
+  const float* __restrict__ w = a.w;
+  const float* __restrict__ bias = a.bias;
+  float* __restrict__ out = a.out;
+  const int N = a.N, D = a.D, keep = a.keep;
+  extern __shared__ float sc[];  // [N]; one thread per node (block = the largest N rounded up to a wave)
   const int b = blockIdx.x, j = threadIdx.x;
   const float* hb = h + (long)b * N * D;
   if (j < N) {
@@ -777,6 +804,25 @@ __global__ void graph_pool_kernel(const float* __restrict__ h, int N, int D, int
     if (rank < keep)
       for (int d = 0; d < D; ++d) out[((long)b * keep + rank) * D + d] = hb[j * D + d] * s;
   }
+}
+
+static void launch_pools(const PoolArgs* q, int n, int B, hipStream_t s) {
+  PoolMulti mm;
+  int nmax = 1;
+  for (int i = 0; i < 4; ++i) {
+    mm.q[i] = q[i < n ? i : 0];
+    if (i < n && q[i].N > nmax) nmax = q[i].N;
+  }
+  hipLaunchKernelGGL(graph_pool_kernel, dim3(B, 1, n), dim3((nmax + 63) & ~63), (nmax + 8) * sizeof(float), s, mm);
+}
+static void launch_rowlins(const RowlinArgs* q, int n, hipStream_t s) {
+  RowlinMulti mm;
+  int rmax = 1;
+  for (int i = 0; i < 4; ++i) {
+    mm.q[i] = q[i < n ? i : 0];
+    if (i < n && q[i].rows > rmax) rmax = q[i].rows;
+  }
+  hipLaunchKernelGGL(rowlin_kernel, dim3((rmax + 3) / 4, 1, n), dim3(256), 0, s, mm);
 }
 
 // models/xlsr_aasist.py:137-175: residual adds (incl. the literal "+ 1", Q1), branch max,
@@ -1068,21 +1114,23 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
   // ---- graph layers ---------------------------------------------------------------------
   const int nS = AAS_F / 2, nT = wd / 2 > 0 ? wd / 2 : 1;        // after pool_S / pool_T
   const int nS1 = nS / 2 > 0 ? nS / 2 : 1, nT1 = nT / 2 > 0 ? nT / 2 : 1;  // after pool_h*
-  auto run_gat = [&](const AasistWeights::Gat& G, const float* x, int N, float* y) -> const char* {
+  auto gat_args = [&](const AasistWeights::Gat& G, const float* x, int N, float* y) {
     GatArgs a;
     memset(&a, 0, sizeof a);
     a.x = x; a.N = N; a.n1 = N; a.att_w = G.att_w; a.att_b = G.att_b; a.v11 = a.v22 = a.v12 = G.att_vec;
     a.w1 = G.w1; a.b1 = G.b1; a.w2 = G.w2; a.b2 = G.b2; a.bn_scale = G.bn_scale; a.bn_shift = G.bn_shift;
     a.temp = 2.0f; a.y1 = y; a.y2 = y;
-    return launch_gat(a, B, 64, 64, s);
+    return a;
   };
-  auto run_pool = [&](const AasistWeights::Pool& P, const float* h, int N, int Dm, int keep, float* out) {
-    hipLaunchKernelGGL(graph_pool_kernel, dim3(B), dim3((N + 63) & ~63), (N + 8) * sizeof(float), s, h, N, Dm, keep, P.w, P.b, out);
+  auto pool_args = [&](const AasistWeights::Pool& P, const float* h, int N, int Dm, int keep, float* out) {
+    return PoolArgs{h, N, Dm, keep, P.w, P.b, out};
   };
-  AOK(run_gat(w.gatS, ws.eS, AAS_F, ws.gS));
-  run_pool(w.pS, ws.gS, AAS_F, 64, nS, ws.oS);
-  AOK(run_gat(w.gatT, ws.eT, wd, ws.gT));
-  run_pool(w.pT, ws.gT, wd, 64, nT, ws.oT);
+  {  // the spectral and the temporal graph in one launch each: GAT, then GraphPool
+    const GatArgs gS = gat_args(w.gatS, ws.eS, AAS_F, ws.gS), gT = gat_args(w.gatT, ws.eT, wd, ws.gT);
+    AOK(launch_gat(gS, B, 64, 64, s, &gT));
+    const PoolArgs pp[2] = {pool_args(w.pS, ws.gS, AAS_F, 64, nS, ws.oS), pool_args(w.pT, ws.gT, wd, 64, nT, ws.oT)};
+    launch_pools(pp, 2, B, s);
+  }
   // branch scratch carve
   float* p = ws.br;
   auto take = [&](size_t n) { float* r = p; p += (n + 63) / 64 * 64; return r; };
@@ -1099,34 +1147,52 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
     br[k].Sa = take((size_t)B * nS1 * 32);
     br[k].ma = take((size_t)B * 32);
   }
-  auto run_hgat = [&](const AasistWeights::HGat& G, const float* x1, int n1, const float* x2, int n2, float* xp,
-                      const float* master, long mstride, float* y1, float* y2, float* mout) -> const char* {
-    const int N = n1 + n2;
-    hipLaunchKernelGGL(rowlin_kernel, dim3((B * n1 + 3) / 4), dim3(256), 0, s, x1, (long)G.din, B * n1, G.din, G.t1w,
-                       G.t1b, G.din, xp, (long)G.din, n1, N, 0);
-    hipLaunchKernelGGL(rowlin_kernel, dim3((B * n2 + 3) / 4), dim3(256), 0, s, x2, (long)G.din, B * n2, G.din, G.t2w,
-                       G.t2b, G.din, xp, (long)G.din, n2, N, n1);
+  // one heterogeneous layer of BOTH branches: type projections (4 problems, one launch), then the two graphs (one launch)
+  auto hgat_args = [&](const AasistWeights::HGat& G, int n1, int n2, float* xp, const float* master, long mstride, float* y1,
+                       float* y2, float* mout) {
     GatArgs a;
     memset(&a, 0, sizeof a);
-    a.x = xp; a.N = N; a.n1 = n1; a.att_w = G.att_w; a.att_b = G.att_b; a.v11 = G.v11; a.v22 = G.v22; a.v12 = G.v12;
+    a.x = xp; a.N = n1 + n2; a.n1 = n1; a.att_w = G.att_w; a.att_b = G.att_b; a.v11 = G.v11; a.v22 = G.v22; a.v12 = G.v12;
     a.w1 = G.w1; a.b1 = G.b1; a.w2 = G.w2; a.b2 = G.b2; a.bn_scale = G.bn_scale; a.bn_shift = G.bn_shift;
     a.temp = 100.0f; a.y1 = y1; a.y2 = y2;
     a.master = master; a.master_bstride = mstride; a.attM_w = G.attM_w; a.attM_b = G.attM_b; a.vM = G.vM;
     a.w1M = G.w1M; a.b1M = G.b1M; a.w2M = G.w2M; a.b2M = G.b2M; a.master_out = mout;
-    return launch_gat(a, B, G.din, G.dout, s);
+    return a;
+  };
+  auto proj_args = [&](const AasistWeights::HGat& G, bool second, const float* x, int n, int N, int off, float* xp) {
+    return RowlinArgs{x, (long)G.din, B * n, G.din, second ? G.t2w : G.t1w, second ? G.t2b : G.t1b, G.din, xp, (long)G.din, n, N, off};
   };
   const AasistWeights::HGat* H1[2] = {&w.h11, &w.h21};
   const AasistWeights::HGat* H2[2] = {&w.h12, &w.h22};
   const AasistWeights::Pool* PS[2] = {&w.phS1, &w.phS2};
   const AasistWeights::Pool* PT[2] = {&w.phT1, &w.phT2};
   const float* M0[2] = {w.master1, w.master2};
-  for (int k = 0; k < 2; ++k) {
-    // x1 = temporal nodes, x2 = spectral nodes (models/xlsr_aasist.py:129-130); the raw
-    // (1,1,64) parameter is the master of the first layer (Q3)
-    AOK(run_hgat(*H1[k], ws.oT, nT, ws.oS, nS, br[k].xp, M0[k], 0, br[k].T1, br[k].S1, br[k].m1));
-    run_pool(*PS[k], br[k].S1, nS, 32, nS1, br[k].S1p);
-    run_pool(*PT[k], br[k].T1, nT, 32, nT1, br[k].T1p);
-    AOK(run_hgat(*H2[k], br[k].T1p, nT1, br[k].S1p, nS1, br[k].xp2, br[k].m1, 32, br[k].Ta, br[k].Sa, br[k].ma));
+  {
+    // layer 1: x1 = temporal nodes, x2 = spectral nodes (models/xlsr_aasist.py:129-130); the raw (1,1,64) parameter is
+    // the master of the first layer (Q3)
+    RowlinArgs pr[4];
+    GatArgs ga[2];
+    for (int k = 0; k < 2; ++k) {
+      pr[2 * k] = proj_args(*H1[k], false, ws.oT, nT, nT + nS, 0, br[k].xp);
+      pr[2 * k + 1] = proj_args(*H1[k], true, ws.oS, nS, nT + nS, nT, br[k].xp);
+      ga[k] = hgat_args(*H1[k], nT, nS, br[k].xp, M0[k], 0, br[k].T1, br[k].S1, br[k].m1);
+    }
+    launch_rowlins(pr, 4, s);
+    AOK(launch_gat(ga[0], B, H1[0]->din, H1[0]->dout, s, &ga[1]));
+    PoolArgs pp[4];
+    for (int k = 0; k < 2; ++k) {
+      pp[2 * k] = pool_args(*PS[k], br[k].S1, nS, 32, nS1, br[k].S1p);
+      pp[2 * k + 1] = pool_args(*PT[k], br[k].T1, nT, 32, nT1, br[k].T1p);
+    }
+    launch_pools(pp, 4, B, s);
+    // layer 2 on the pooled graphs; master = the first layer's master output
+    for (int k = 0; k < 2; ++k) {
+      pr[2 * k] = proj_args(*H2[k], false, br[k].T1p, nT1, nT1 + nS1, 0, br[k].xp2);
+      pr[2 * k + 1] = proj_args(*H2[k], true, br[k].S1p, nS1, nT1 + nS1, nT1, br[k].xp2);
+      ga[k] = hgat_args(*H2[k], nT1, nS1, br[k].xp2, br[k].m1, 32, br[k].Ta, br[k].Sa, br[k].ma);
+    }
+    launch_rowlins(pr, 4, s);
+    AOK(launch_gat(ga[0], B, H2[0]->din, H2[0]->dout, s, &ga[1]));
   }
   {  // debug views for afx_tap
     int n = 0;
@@ -1184,10 +1250,9 @@ extern "C" int afx_k_hgat(const float* x1, int n1, const float* x2, int n2, int 
   // wts: t1w t1b t2w t2b att_w att_b attM_w attM_b v11 v22 v12 vM w1 b1 w2 b2 w1M b1M w2M b2M bn_scale bn_shift
   hipStream_t s = (hipStream_t)stream;
   const int N = n1 + n2;
-  hipLaunchKernelGGL(rowlin_kernel, dim3((B * n1 + 3) / 4), dim3(256), 0, s, x1, (long)din, B * n1, din, wts[0], wts[1],
-                     din, xp_scratch, (long)din, n1, N, 0);
-  hipLaunchKernelGGL(rowlin_kernel, dim3((B * n2 + 3) / 4), dim3(256), 0, s, x2, (long)din, B * n2, din, wts[2], wts[3],
-                     din, xp_scratch, (long)din, n2, N, n1);
+  const RowlinArgs pr[2] = {{x1, (long)din, B * n1, din, wts[0], wts[1], din, xp_scratch, (long)din, n1, N, 0},
+                            {x2, (long)din, B * n2, din, wts[2], wts[3], din, xp_scratch, (long)din, n2, N, n1}};
+  launch_rowlins(pr, 2, s);
   if (!master) {  // models/aasist_modules.py:167-168: mean of the projected nodes
     float* mean = xp_scratch + (long)B * N * din;
     hipLaunchKernelGGL(node_mean_kernel, dim3(B), dim3(64), 0, s, xp_scratch, N, din, mean);
@@ -1302,7 +1367,8 @@ extern "C" int afx_k_graph_pool(const float* h, int B, int N, int D, int keep, c
     aasist_last = "graph_pool: need 1 <= keep <= N <= 1024";
     return 1;
   }
-  hipLaunchKernelGGL(graph_pool_kernel, dim3(B), dim3((N + 63) & ~63), (N + 8) * sizeof(float), (hipStream_t)stream, h, N, D, keep, w, b, out);
+  const PoolArgs pq = {h, N, D, keep, w, b, out};
+  launch_pools(&pq, 1, B, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   aasist_last = e == hipSuccess ? nullptr : hipGetErrorString(e);
   return aasist_last ? 1 : 0;
