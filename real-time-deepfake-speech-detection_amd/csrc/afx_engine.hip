@@ -1327,6 +1327,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
     gemm_set_split(value);
     return 0;
   }
+  if (!strcmp(key, "gemm_conv_split")) {
+    gemm_set_conv_split(value);
+    return 0;
+  }
   if (!strcmp(key, "gemm_ph4")) {
     gemm_set_ph4(value);
     return 0;

@@ -572,7 +572,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   const int g = blockIdx.z;
   const T* Ag = (const T*)p.A + (long)g * p.g_a;
   const T* Wg = (const T*)p.W + (long)g * p.g_w;
-  const int nN = (p.N + BN - 1) / BN, nM = (p.M + BMC - 1) / BMC;
+  const int nN = (p.N + BN - 1) / BN, nM = (p.M - p.m_lo + BMC - 1) / BMC;  // the launch covers rows [m_lo, M)
   const int nwg = nM * nN;
   const int nk = p.K >> 6;
 
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
       pm = L / nN;
       pn = L % nN;
     }
-    m0 = pm * BMC;
+    m0 = p.m_lo + pm * BMC;
     n0 = pn * BN;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -930,7 +930,7 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
     n_cu_of[dev] = cus < 8 ? 8 : cus;
   }
   const int n_cu = n_cu_of[dev];
-  const int tiles = ((p.N + BN - 1) / BN) * ((p.M + MF * 32 - 1) / (MF * 32));
+  const int tiles = ((p.N + BN - 1) / BN) * ((p.M - p.m_lo + MF * 32 - 1) / (MF * 32));
   dim3 grid(tiles < n_cu ? tiles : n_cu, 1, groups);  // persistent: at most one workgroup per CU
   hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN, MF, PH, TS>), grid, dim3(512), lds, s, p);
   return hipGetLastError();
@@ -1012,6 +1012,8 @@ static int gemm_split_rows(const GemmArgs& p, int groups) {
 // per round at 8 / 7 / 6 / 5 fragments): the operand DMA of a K-tile does not shrink with the height, only the MFMAs do.
 static int g_ph4 = 0;  // A/B knob (full-height tiles): 1 = the 4-phase K-tile (16-MFMA segments)
 void gemm_set_ph4(int v) { g_ph4 = v; }
+static int g_conv_split = 1;  // A/B knob: remainder split of multi-round conv layers
+void gemm_set_conv_split(int v) { g_conv_split = v; }
 static int g_fit = 1;  // A/B knob: 0 = always 256 rows, 1 = fitted, 5..8 = forced
 void gemm_set_fit(int v) { g_fit = v; }
 static int gemm8_fit_mf(const GemmArgs& p, long* cost_out = nullptr) {
@@ -1131,6 +1133,20 @@ const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t
   } else if (tile == 8) {
     const int mf = gemm8_fit_rowln(p);
     if (mf < 4) tile = 80 + mf;
+    // Remainder split of a multi-round conv layer: T tiles of 128 rows on 256 CUs cost ceil(T / 256) rounds however few tiles
+    // the last one holds (B = 64: layer 1 3200 tiles = 12.5 rounds, layer 2 1600 = 6.25, layer 3 800 = 3.125).  When the
+    // last round is at most 3/8 full, the whole rounds run at 128 rows and the remaining rows as 64-row tiles of the same
+    // kernel in a second launch (rows [m_lo, M) -- same rows, bit for bit).  Worth 2-4 % of such a layer (209 -> 203 us at
+    // 800 tiles; the persistent grid's tail is cheaper than a full round, so less than the tile count suggests).
+    const long t128 = (p.M + 127) / 128, frac = t128 % 256;
+    if (mf == 4 && g_fit == 1 && g_conv_split && t128 > 256 && frac != 0 && frac <= 96 && p.K >= 1536 && p.m_lo == 0) {
+      GemmArgs a = p, b = p;
+      a.M = (int)((t128 / 256) * 256 * 128);
+      b.m_lo = a.M;
+      hipError_t err = dtype == DT_BF16 ? dispatch<BF16>(a, 8, groups, s) : dispatch<FP16>(a, 8, groups, s);
+      if (err == hipSuccess) err = dtype == DT_BF16 ? dispatch<BF16>(b, 82, groups, s) : dispatch<FP16>(b, 82, groups, s);
+      return err == hipSuccess ? nullptr : hipGetErrorString(err);
+    }
   }
   const hipError_t err = dtype == DT_BF16 ? dispatch<BF16>(p, tile, groups, s) : dispatch<FP16>(p, tile, groups, s);
   return err == hipSuccess ? nullptr : hipGetErrorString(err);

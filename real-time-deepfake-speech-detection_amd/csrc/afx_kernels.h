@@ -46,6 +46,7 @@ struct GemmArgs {
   const float* ln_beta;
   float ln_eps;
   int a_nt;  // 1: non-temporal LDS-DMA for the A panel (set by launch_gemm)
+  int m_lo;  // 8-wave kernels only: the launch covers rows [m_lo, M) (set by launch_gemm for a remainder launch; 0 otherwise)
   int dbg_nodma;  // attribution build (-DAFX_ATTR) only, ignored otherwise: epilogue bits 8 no activation, 16 narrow stores, 32 no stores, 64 no epilogue
 };
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
@@ -55,6 +56,7 @@ int gemm_tile_of(const GemmArgs& p, int groups);  // tile instance id (afx_gemm.
 void gemm_set_map_mode(int m);  // A/B knob: -1 default, else force map_mode
 void gemm_set_tile(int t);      // A/B knob: -1 default, 0: 128x128 tile, 1: 256x256 tile
 void gemm_set_a_nt(int v);      // A/B knob: -1 auto, 0/1 non-temporal A-panel loads
+void gemm_set_conv_split(int v);  // A/B knob: 1 (default) = multi-round conv layers as whole rounds of 128-row tiles + a 64-row remainder launch
 void gemm_set_ph4(int v);       // A/B knob: 1 = 4-phase K-tile of the 8-wave kernels (default 0: two phases of 32 MFMAs)
 void gemm_set_fit(int v);       // A/B knob: 1 (default) = 8-phase tile height fitted to one round of the CUs (160..256 rows)
 void gemm_set_split(int v);     // A/B knob: 1 (default) = whole rounds on the 8-phase kernel + 128x128 remainder rows

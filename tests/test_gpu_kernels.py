@@ -255,6 +255,31 @@ def test_conv_layernorm_8phase_tile_is_bit_identical_to_the_2stage_tile(K):
             check(lib().afx_debug_set(b"gemm_fit", 1))
 
 
+def test_conv_layer_remainder_split_is_bit_identical(K):
+    """A conv layer of more than one round of 128-row tiles whose last round is at most half full runs as whole rounds +
+    a second launch of 64-row tiles over the remaining rows (rows [m_lo, M) of the same kernel): 300 tiles here = one round
+    + 44 tiles.  Same rows as the single launch and as the 2-stage tile, bit for bit."""
+    from afx._lib import check, lib
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(24, 3199, 512, generator=g).half().cuda()
+    bias = (torch.randn(512, generator=g) * 0.5).cuda()
+    ga = (1 + 0.1 * torch.randn(512, generator=g)).cuda()
+    be = (0.1 * torch.randn(512, generator=g)).cuda()
+    wp = K.pack_conv("fp16", (torch.randn(512, 512, 3, generator=g) / math.sqrt(1536)).cuda())
+    try:
+        check(lib().afx_debug_set(b"gemm_deep", 0))  # the 2-stage tile
+        want, _ = K.conv_ln_act("fp16", x, wp, 3, 2, bias, ga, be, out_f=True, out_h=False)
+        check(lib().afx_debug_set(b"gemm_deep", 2))
+        for split in (1, 0):
+            check(lib().afx_debug_set(b"gemm_conv_split", split))
+            for _ in range(3):
+                got, _ = K.conv_ln_act("fp16", x, wp, 3, 2, bias, ga, be, out_f=True, out_h=False)
+                assert torch.equal(got, want), split
+    finally:
+        check(lib().afx_debug_set(b"gemm_deep", -1))
+        check(lib().afx_debug_set(b"gemm_conv_split", 1))
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("pre", [False, True])
 def test_conv0_layernorm_gelu(K, dtype, pre):

@@ -13,7 +13,8 @@ from afx._lib import check, lib  # noqa: E402
 
 B = int(os.environ.get("BENCH_B", 16))
 LAYERS = [(1, 12799, 3), (2, 6399, 3), (3, 3199, 3), (4, 1599, 3), (5, 799, 2), (6, 399, 2)]
-FITS = [("128 rows", 14), ("128 rows 4ph", 114), ("96 rows", 13), ("64 rows", 12), ("fitted", 1)]  # + 100: the 4-phase K-tile
+# "fitted" = the default dispatch incl. the remainder split of multi-round layers; "fitted nosplit" switches that off
+FITS = [("128 rows", 14), ("128 rows 4ph", 114), ("96 rows", 13), ("64 rows", 12), ("fitted", 1), ("fitted nosplit", 1001)]  # + 100: the 4-phase K-tile
 
 
 def timeit(fn, reps=20):
@@ -37,11 +38,13 @@ def main():
         times = {n: [] for n, _ in FITS}
         for _ in range(5):
             for n, fit in FITS:
+                check(lib().afx_debug_set(b"gemm_conv_split", 0 if fit >= 1000 else 1))
                 check(lib().afx_debug_set(b"gemm_fit", fit % 100))
-                check(lib().afx_debug_set(b"gemm_ph4", fit // 100))
+                check(lib().afx_debug_set(b"gemm_ph4", fit % 1000 // 100))
                 times[n].append(timeit(lambda: K.conv_ln_act("fp16", x, wp, k, 2, bias, ga, bias)))
         check(lib().afx_debug_set(b"gemm_fit", 1))
         check(lib().afx_debug_set(b"gemm_ph4", 0))
+        check(lib().afx_debug_set(b"gemm_conv_split", 1))
         Tout = (Tin - k) // 2 + 1
         print(f"layer {li} M={B * Tout:6d} K={k * 512}: " + "  ".join(f"{n}: {statistics.median(t):6.1f} us" for n, t in times.items()), flush=True)
 
