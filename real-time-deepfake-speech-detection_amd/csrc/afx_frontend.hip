@@ -308,6 +308,12 @@ __global__ __launch_bounds__(256, 2) void conv0_split_kernel(const float* __rest
     int qe = ge - bexp;                                   // G / cb is an fp16 operand (k = 30, 31): keep it normal
     qe = qe < -14 ? -14 : (qe > 15 ? 15 : qe);
     ge = qe + bexp;
+    // a frame far beyond any audio scale (|x| > 2^14 / its scale): keep S_f * m inside fp16 and let the bias operand
+    // underflow instead -- against such a signal the bias is below fp32 resolution anyway
+    if (eb > 0 && eb < 255 && ge - cexp + (eb - 127) > 14) {
+      ge = 14 - (eb - 127) + cexp;
+      qe = ge - bexp;
+    }
     const float S = ldexpf(1.0f, ge - cexp), G = ldexpf(1.0f, ge);
     _Float16 h[32];
 #pragma unroll

@@ -298,7 +298,7 @@ def test_conv0_layernorm_gelu(K, dtype, pre):
     _close(got, ref, _eps(dtype), 2e-3 if dtype == "fp16" else 1e-2)
 
 
-@pytest.mark.parametrize("amp,wscale", [(0.1, 1.0), (1e-4, 1.0), (30.0, 1.0), (0.05, 0.01), (3e-7, 20.0)])
+@pytest.mark.parametrize("amp,wscale", [(0.1, 1.0), (1e-4, 1.0), (30.0, 1.0), (0.05, 0.01), (3e-7, 20.0), (3e7, 1.0)])
 def test_conv0_split_precision_form_is_fp32_accurate_at_any_level(K, amp, wscale):
     """The half-precision engines run conv layer 0 as ONE fp16 MFMA per tile (hi/lo split of samples and weights, per-frame
     and per-layer power-of-two scaling folded into the LayerNorm).  Against the true-fp32 matrix-core form of the same
