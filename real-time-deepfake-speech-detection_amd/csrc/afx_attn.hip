@@ -396,14 +396,17 @@ __global__ __launch_bounds__(256, 2) void mhsa_long_kernel(const typename HT::T*
 
 static int g_mhsa_force_long = 0;  // test knob: the blocked kernel at any length
 void mhsa_set_force_long(int v) { g_mhsa_force_long = v != 0; }
+static int g_mhsa_zsplit = 0;  // A/B knob: workgroups per (utterance, head) (0 = automatic)
+void mhsa_set_zsplit(int v) { g_mhsa_zsplit = v; }
 static int g_mhsa_waves = 7;  // A/B knob: waves per workgroup of the one-pass kernel beyond 128 frames (4 or 7)
 void mhsa_set_waves(int v) { g_mhsa_waves = v == 4 ? 4 : 7; }
 
 template <class HT>
 static void launch_mhsa_t(const void* qkv, void* out, int B, int T, int H, float scale, const int* lens, hipStream_t s) {
   typedef typename HT::T Tt;
-  // two workgroups fit a CU: below one full wave of them (B x H < 512), split each head's query tiles in two
-  dim3 grid(H, B, (long)H * B < 512 && T > 64 ? 2 : 1), blk(256);
+  // below one workgroup per CU (B x H < 256) each head's query tiles are split over two workgroups (with seven waves per
+  // workgroup the split stopped paying at B = 16: 11.4 us whole against 11.8 us split; B = 8: 9.9 against 9.1)
+  dim3 grid(H, B, g_mhsa_zsplit > 0 ? g_mhsa_zsplit : ((long)H * B < 256 && T > 64 ? 2 : 1)), blk(256);
   if (T > ATT_KEYS || g_mhsa_force_long)
     hipLaunchKernelGGL((mhsa_long_kernel<HT>), dim3(H, B, (T + 63) / 64), blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
   else if (T <= 64)

@@ -60,6 +60,7 @@ void gemm_set_conv_split(int v);  // A/B knob: 1 (default) = multi-round conv la
 void gemm_set_ph4(int v);       // A/B knob: 1 = 4-phase K-tile of the 8-wave kernels (default 0: two phases of 32 MFMAs)
 void gemm_set_fit(int v);       // A/B knob: 1 (default) = 8-phase tile height fitted to one round of the CUs (160..256 rows)
 void gemm_set_split(int v);     // A/B knob: 1 (default) = whole rounds on the 8-phase kernel + 128x128 remainder rows
+void mhsa_set_zsplit(int v);       // A/B knob: workgroups per (utterance, head) of the one-pass trunk attention (0 = automatic)
 void mhsa_set_waves(int v);        // A/B knob: 4 or 7 (default) waves per workgroup of the one-pass trunk attention
 void mhsa_set_force_long(int v);   // test knob: the blocked any-length trunk attention kernel at every length
 void conf_attn_mfma_set_waves(int v);       // A/B knob: 4 or 7 (default) waves per workgroup of the one-pass Shaw attention
