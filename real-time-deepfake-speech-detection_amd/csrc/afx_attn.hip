@@ -26,7 +26,7 @@ constexpr int ATT_VT_STRIDE = 232;  // halfs per V^T row: 464 B, conflict-free d
 
 // NW waves per workgroup: the 16-query tiles of a head are dealt to the waves round-robin, so the compute phase is
 // ceil(tiles / NW) tiles long -- 13 tiles (T = 199): 4 with four waves, 2 with seven (and 1 when the tiles are split over
-// two workgroups, B x H < 512); the staging loop is spread over all threads.
+// two workgroups, B x H < 256); the staging loop is spread over all threads.
 template <class HT, int KS, int NW>  // KS = number of 32-key steps actually computed
 __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typename HT::T* __restrict__ qkv,
                                                    typename HT::T* __restrict__ out, int T, int H, float scale,
