@@ -687,6 +687,39 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
         }
     __builtin_amdgcn_s_setprio(0);
   };
+  // ---- PH == 3 ("ring3", the DEFAULT of the 256-wide instance; 0-4.5 % over the two-buffer form,
+  // profiles/r02_gemm_ring3_ab.txt): all 160 KB of LDS -- the resident operand (B) double-buffered as
+  // before, the flowing one (A) in a ring of THREE K-tile buffers, so that A of tile t+2 can go out a whole phase
+  // earlier (its slot was last read by tile t-1) and the DMA splits 4 + 4 over the two read intervals instead of 2 + 6;
+  // one DMA wait per K-tile (end of phase B), none in phase A.
+  //     LDS: [B buf 0 | B buf 1 | A buf 0 | A buf 1 | A buf 2], 32 KB each
+  //     phase A: read B0 B1 A0(t)   stage A0 A1 (t+2)   MFMA (A0,B0) (A0,B1)
+  //     phase B: read A1(t)         stage B0 B1 (t+2)   wait: tile t+1 landed   MFMA (A1,B1) (A1,B0)
+  constexpr int RSZ3 = 2 * RB * 128, FSZ3 = 2 * RA * 128;
+  auto stageA3 = [&](int h, int fboff, int kt) {
+#pragma unroll
+    for (int i = 0; i < DA; ++i) dma16(srcA[h][i] + kt * 64, 2 * RSZ3 + fboff + h * (RA * 128) + (i * 8 + wave) * 1024);
+  };
+  auto stageB3 = [&](int h, int rb, int kt) {
+#pragma unroll
+    for (int i = 0; i < DB; ++i) dma16(srcB[h][i] + kt * 64, rb * RSZ3 + h * (RB * 128) + (i * 8 + wave) * 1024);
+  };
+  auto readA3 = [&](int fboff, int h) {
+#pragma unroll
+    for (int mi = 0; mi < MTH; ++mi)
+      if (mi < (h ? MF1 : MF0)) {
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks)
+          af[0][mi][ks] = *(const V8*)(aR + 2 * RSZ3 + fboff + h * (RA * 128) + mi * (FR * 128) + slot[ks]);
+      }
+  };
+  auto readB3 = [&](int rb, int h) {
+#pragma unroll
+    for (int nj = 0; nj < NTH; ++nj)
+#pragma unroll
+      for (int ks = 0; ks < KSN; ++ks)
+        wf[h][nj][ks] = *(const V8*)(bR + rb * RSZ3 + h * (RB * 128) + nj * (FR * 128) + slot[ks]);
+  };
   // R / F views of the two operands
   // (AFX_DBG 4096, timing only: K-loop without its LDS fragment reads)
   auto readR = [&](int buf, int h) { if (AFX_DBG(p, 4096)) return; if constexpr (WIDE) readA(buf, h); else readB(buf, h); };
@@ -830,6 +863,52 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     AFX_BAR();
     stamp(t, 8);
   };
+  auto ktile_r3 = [&](auto rbc, int t, int fb, int fb2) {  // fb / fb2: byte offsets of A's ring slots of tiles t / t+2
+    constexpr int rb = decltype(rbc)::value;
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+    // ---- phase A
+    readB3(rb, 0);
+    readB3(rb, 1);
+    readA3(fb, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) {
+      stageA3(0, fb2, t + 2);
+      stageA3(1, fb2, t + 2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    AFX_BAR();
+    quadrant(0, 0);
+    quadrant(0, 1);
+    AFX_BAR();
+    // ---- phase B
+    readA3(fb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) {
+      stageB3(0, rb, t + 2);
+      stageB3(1, rb, t + 2);
+      wait_vmcnt<2 * DA + 2 * DB>();  // tile t+1 (issued one K-tile and more ago) has landed; tile t+2 stays in flight
+    } else {
+      wait_vmcnt<0>();
+    }
+    (void)more1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    AFX_BAR();
+    quadrant(1, 1);
+    quadrant(1, 0);
+    AFX_BAR();
+  };
+  auto issue_prologue_r3 = [&] {  // tiles 0 and 1 entirely
+    stageB3(0, 0, 0);
+    stageB3(1, 0, 0);
+    stageA3(0, 0, 0);
+    stageA3(1, 0, 0);
+    if (nk > 1) {
+      stageB3(0, 1, 1);
+      stageB3(1, 1, 1);
+      stageA3(0, FSZ3, 1);
+      stageA3(1, FSZ3, 1);
+    }
+  };
   auto issue_prologue2 = [&] {
     stageR(0, 0, 0);
     stageR(1, 0, 0);
@@ -843,14 +922,17 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   };
   int v = blockIdx.x;
   setup(v);
-  if constexpr (PH != 0) issue_prologue2(); else issue_prologue();
+  if constexpr (PH == 3) issue_prologue_r3(); else if constexpr (PH != 0) issue_prologue2(); else issue_prologue();
   bool first = true;
   for (;;) {
     // K-tile 0 has landed.  For the first output tile that is the counted wait of the template;
     // for later ones the epilogue stores of the previous tile were issued BEHIND these DMAs and
     // vmcnt retires in order, so the wait is vmcnt(0) (the stores were issued all through the
     // epilogue and are mostly acknowledged by now).
-    if constexpr (PH != 0) {
+    if constexpr (PH == 3) {
+      if (first && nk > 1) wait_vmcnt<2 * DA + 2 * DB>();  // K-tile 0 has landed, K-tile 1 may be in flight
+      else wait_vmcnt<0>();
+    } else if constexpr (PH != 0) {
       constexpr int NF1 = WIDE ? DB : DA, NRRF = 2 * (WIDE ? DA : DB) + (WIDE ? DB : DA);
       if (first && nk > 1) wait_vmcnt<NF1 + NRRF>();  // R0 R1 F0 of K-tile 0 have landed
       else if (first) wait_vmcnt<NF1>();
@@ -874,7 +956,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     // output tile of a workgroup waits for all of its prologue instead of the first K-tile only.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only (gfx9 encoding: expcnt / lgkmcnt fields at their maximum)
     for (int t = 0; t < nk; t += 2) {
-      if constexpr (PH == 1) {
+      if constexpr (PH == 3) {
+        // A's ring slot of tile t is (t % 3) * FSZ3; t advances by 2 per iteration
+        const int f0 = (t % 3) * FSZ3, f1 = ((t + 1) % 3) * FSZ3, f2 = ((t + 2) % 3) * FSZ3;
+        ktile_r3(std::integral_constant<int, 0>{}, t, f0, f2);
+        if (t + 1 < nk) ktile_r3(std::integral_constant<int, 1>{}, t + 1, f1, f0);
+      } else if constexpr (PH == 1) {
         ktile2(std::integral_constant<int, 0>{}, t);
         if (t + 1 < nk) ktile2(std::integral_constant<int, 1>{}, t + 1);
       } else {
@@ -890,7 +977,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     const int vn = v + gridDim.x;
     if (vn < nwg) {
       setup(vn);
-      if constexpr (PH != 0) issue_prologue2(); else issue_prologue();
+      if constexpr (PH == 3) issue_prologue_r3(); else if constexpr (PH != 0) issue_prologue2(); else issue_prologue();
     }
     if (AFX_DBG(p, 64)) {  // timing only: no epilogue at all
 #pragma unroll
@@ -916,7 +1003,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 
 template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, int PH = 1, bool TS = false>
 static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
-  constexpr int lds = 2 * (BM + BN) * 128 + (TS ? 16384 : 0);
+  constexpr int lds = 2 * (BM + BN) * 128 + (TS ? 16384 : 0) + (PH == 3 ? BM * 128 : 0);  // ring3: a third buffer for A
   static_assert(lds <= 160 * 1024, "two K-tile buffers must fit the 160 KB LDS");
   static LdsLimit lim;
   if (hipError_t e = lim.ensure((const void*)gemm8_kernel<HT, BM, BN, ROWLN, MF, PH, TS>, lds); e != hipSuccess) return e;
@@ -1010,7 +1097,7 @@ static int gemm_split_rows(const GemmArgs& p, int groups) {
 // Height of the 8-phase 256-wide tile for a product that is NOT round-split: fragments per wave row (8 = 256 rows).
 // Cost model: rounds x (MF + 5) -- fitted to tools/bench_teacher_gemm.py (M = 12736, N = 4096: 33.4 / 30.3 / 27.3 / 25.6 us
 // per round at 8 / 7 / 6 / 5 fragments): the operand DMA of a K-tile does not shrink with the height, only the MFMAs do.
-static int g_ph4 = 0;  // A/B knob (full-height tiles): 1 = the 4-phase K-tile (16-MFMA segments)
+static int g_ph4 = 0;  // A/B knob: 0 = default (256-wide tiles: two-phase K-tile over a three-buffer A ring; conv tile: two-phase, two buffers), 1 = the 4-phase K-tile (16-MFMA segments) on the full-height tiles, 2 = the two-buffer two-phase form on the 256-wide tiles
 void gemm_set_ph4(int v) { g_ph4 = v; }
 static int g_conv_split = 1;  // A/B knob: remainder split of multi-round conv layers
 void gemm_set_conv_split(int v) { g_conv_split = v; }
@@ -1080,13 +1167,14 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
     case 7:
+      if (g_ph4 == 0) return launch_gemm8_t<HT, 256, 256, false, 8, 3>(p, groups, s);  // default: the three-buffer ring form
 #ifdef AFX_ATTR
       if (p.dbg_nodma & 8192) return launch_gemm8_t<HT, 256, 256, false, 8, 1, true>(p, groups, s);  // clock stamps (TS)
 #endif
-      return g_ph4 ? launch_gemm8_t<HT, 256, 256, false, 8, 0>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
-    case 75: return launch_gemm8_t<HT, 256, 256, false, 5>(p, groups, s);
-    case 76: return launch_gemm8_t<HT, 256, 256, false, 6>(p, groups, s);
-    case 77: return launch_gemm8_t<HT, 256, 256, false, 7>(p, groups, s);
+      return g_ph4 == 1 ? launch_gemm8_t<HT, 256, 256, false, 8, 0>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false>(p, groups, s);
+    case 75: return g_ph4 == 0 ? launch_gemm8_t<HT, 256, 256, false, 5, 3>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false, 5>(p, groups, s);
+    case 76: return g_ph4 == 0 ? launch_gemm8_t<HT, 256, 256, false, 6, 3>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false, 6>(p, groups, s);
+    case 77: return g_ph4 == 0 ? launch_gemm8_t<HT, 256, 256, false, 7, 3>(p, groups, s) : launch_gemm8_t<HT, 256, 256, false, 7>(p, groups, s);
     case 8: return g_ph4 ? launch_gemm8_t<HT, 128, 512, true, 4, 0>(p, groups, s) : launch_gemm8_t<HT, 128, 512, true>(p, groups, s);
     case 82: return launch_gemm8_t<HT, 128, 512, true, 2>(p, groups, s);
     case 83: return launch_gemm8_t<HT, 128, 512, true, 3>(p, groups, s);

@@ -117,14 +117,17 @@ def test_gemm_8phase_short_tiles_are_bit_identical(K, M, N, K_):
         want_f, want_h = K.gemm("fp16", A, W, bias=bias, resid=R, out_f=True, out_h=True)
         _close(want_f, A.float().cpu() @ W.float().cpu().t() + bias.cpu() + R.cpu(), 1e-4, 2e-4)
         check(lib().afx_debug_set(b"gemm_tile", 3))
-        for fit in (5, 6, 7, 8, 1):
-            check(lib().afx_debug_set(b"gemm_fit", fit))
-            for _ in range(4):
-                got_f, got_h = K.gemm("fp16", A, W, bias=bias, resid=R, out_f=True, out_h=True)
-                assert torch.equal(got_f, want_f) and torch.equal(got_h, want_h), fit
+        for ph in (0, 2):  # the shipped form (two-phase K-tile over a three-buffer A ring), then the two-buffer form (A/B knob)
+            check(lib().afx_debug_set(b"gemm_ph4", ph))
+            for fit in (5, 6, 7, 8, 1):
+                check(lib().afx_debug_set(b"gemm_fit", fit))
+                for _ in range(4):
+                    got_f, got_h = K.gemm("fp16", A, W, bias=bias, resid=R, out_f=True, out_h=True)
+                    assert torch.equal(got_f, want_f) and torch.equal(got_h, want_h), (ph, fit)
     finally:
         check(lib().afx_debug_set(b"gemm_tile", -1))
         check(lib().afx_debug_set(b"gemm_fit", 1))
+        check(lib().afx_debug_set(b"gemm_ph4", 0))
 
 
 @pytest.mark.parametrize("M,N,K_,resid", [(12736, 3072, 1024, False), (12736, 4096, 1024, False), (6500, 2048, 512, True)])

@@ -15,8 +15,8 @@ from afx._lib import check, lib  # noqa: E402
 M = int(os.environ.get("BENCH_M", 3184))
 SHAPES = [("qkv", 3072, 1024, False), ("out", 1024, 1024, True), ("fc1", 4096, 1024, False), ("fc2", 1024, 4096, True)]
 # (name, gemm_tile, gemm_fit): the 8-phase kernel at forced heights 256 / 224 / 192 / 160 rows and fitted
-# gemm_fit + 100 = the same on the 4-phase K-tile (full-height tiles only)
-TILES = [("auto", -1, 1), ("auto 4ph", -1, 101), ("auto nofit", -1, 0), ("128x128/4w", 0, 1), ("128x64/4w", 5, 1), ("8ph 256", 3, 8), ("8ph 256 4ph", 3, 108), ("8ph 224", 3, 7),
+# gemm_fit + 100 = the 4-phase K-tile (full-height tiles only), + 200 = the two-buffer two-phase form instead of the three-buffer A ring
+TILES = [("auto", -1, 1), ("auto 4ph", -1, 101), ("auto 2buf", -1, 201), ("auto nofit", -1, 0), ("128x128/4w", 0, 1), ("128x64/4w", 5, 1), ("8ph 256", 3, 8), ("8ph 256 4ph", 3, 108), ("8ph 256 2buf", 3, 208), ("8ph 224 2buf", 3, 207), ("8ph 160 2buf", 3, 205), ("8ph 224", 3, 7),
          ("8ph 192", 3, 6), ("8ph 160", 3, 5)]
 
 
