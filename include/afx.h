@@ -34,7 +34,8 @@ extern "C" {
 
 typedef struct afx_engine* afx_handle;
 
-enum { AFX_ARCH_SSL = 0, AFX_ARCH_XLSR_AASIST = 1, AFX_ARCH_CONFORMER = 2 };
+enum { AFX_ARCH_SSL = 0, AFX_ARCH_XLSR_AASIST = 1, AFX_ARCH_CONFORMER = 2,
+       AFX_ARCH_CONFORMER_HEAD = 3 /* MyConformer alone (models/conformer_baseline.py:8-29): class token, Conformer blocks, fc5; no trunk */ };
 enum { AFX_EXTRACTOR_LAYER_NORM = 0, /* XLS-R: every conv layer conv+bias -> LayerNorm(512) -> GELU (what the reference loads) */
        AFX_EXTRACTOR_GROUP_NORM = 1  /* wav2vec2-base: bias-free convs, GroupNorm(512,512) on layer 0 only, GELU */ };
 enum { AFX_DT_BF16 = 0, AFX_DT_FP16 = 1, AFX_DT_FP32 = 2 }; /* operand type (FP32: exact mode, fp32 MFMA); accumulation is always fp32 */
@@ -100,10 +101,21 @@ int afx_ssl_forward_ragged(afx_handle h, const float* wave, int B, int Lmax, con
 size_t afx_tail_workspace_bytes(afx_handle h, int B, int T5);
 int afx_tail_forward(afx_handle h, const void* conv5_h, int B, int T5, float* logits, void* ws, size_t ws_bytes,
                      void* stream);
+/* the same with the window inside a longer per-stream buffer: utterance b's T5 rows start at conv5_h + b * batch_stride
+ * elements (0 = packed; a multiple of 8, at least T5 * 512) -- a streaming caller appends the new frames to a ring and
+ * passes a view, no copy per hop */
+int afx_tail_forward_strided(afx_handle h, const void* conv5_h, long batch_stride, int B, int T5, float* logits, void* ws,
+                             size_t ws_bytes, void* stream);
 /* back-end alone from given SSL features (B,T,1024) fp32 -> logits (B,2) */
 int afx_head_forward(afx_handle h, const float* feats, int B, int T, float* logits, void* ws, size_t ws_bytes,
                      void* stream);
 size_t afx_head_workspace_bytes(afx_handle h, int B, int T);
+/* MyConformer.forward (models/conformer_baseline.py:22-29) alone: tokens device (B,T,emb) fp32 (what Model.forward hands it
+ * after LL / BatchNorm / SELU, :58-63) -> class token prepended, the n_encoders Conformer blocks -> logits (B,2) = fc5(token 0)
+ * and, when `embedding` is not NULL, token 0 itself (B,emb).  Handles of arch CONFORMER or CONFORMER_HEAD; workspace
+ * afx_head_workspace_bytes(h, B, T). */
+int afx_conformer_forward(afx_handle h, const float* tokens, int B, int T, float* logits, float* embedding, void* ws,
+                          size_t ws_bytes, void* stream);
 /* debug taps (off by default; when on, forward keeps fp32 copies of intermediates) */
 int afx_enable_taps(afx_handle h, int on);
 /* debug taps: copy an intermediate of the LAST forward on this workspace into `out`
@@ -120,6 +132,11 @@ int afx_profile_end(afx_handle h, int n_classes, double* ms, double* flops, long
 int afx_profile_num_classes(void);
 const char* afx_profile_class_name(int cls);
 
+/* per-handle switches between two forms of the same op (A/B measurements and the per-op reference paths of the tests):
+ * "posconv_sliding" 1 (default) sliding-window positional conv / 0 chunked-K GEMM; "conf_attn_mfma" 1 matrix-core Shaw
+ * attention / 0 the fp32 VALU kernel; "fuse_conformer" 1 fused row chains / 0 one kernel per op; "fuse_conv_ln" 1 conv +
+ * LayerNorm + GELU in one kernel / 0 two.  They act on THIS handle only. */
+int afx_engine_set(afx_handle h, const char* key, int value);
 /* tuning knobs for A/B measurements (process-wide; not part of the drop-in surface).
  * "gemm_map": workgroup->tile order of the MFMA GEMM, -1 default, 0 linear, 1 XCD-
  * contiguous, 2 XCD-contiguous + grouped.  "gemm_tile": -1 auto, 0 128x128, 1 256x256.
@@ -146,6 +163,13 @@ int afx_k_pack_linear(int dtype, const float* w, int N, int K, int Kpad, void* o
 int afx_k_pack_conv(int dtype, const float* w, int N, int Cin, int k, void* out_h, void* stream);
 int afx_k_conv0(int dtype, const float* wave, int B, int L, const float* w, const float* bias, const float* gamma,
                 const float* beta, int pre_emph, float coef, void* out_h, void* stream);
+/* the same without the per-call operand build of the test hook above (device allocation + stream synchronisation): the
+ * layer's split-precision fp16 operand block is built once per checkpoint into afx_k_conv0_pack_bytes() bytes and passed in;
+ * asynchronous, allocates nothing -- what the streaming scorer runs every hop */
+size_t afx_k_conv0_pack_bytes(void);
+int afx_k_conv0_pack(const float* w, const float* bias, void* pack, void* stream);
+int afx_k_conv0_packed(int dtype, const float* wave, int B, int L, const void* pack, const float* w, const float* bias,
+                       const float* gamma, const float* beta, int pre_emph, float coef, void* out_h, void* stream);
 /* data/preprocess.py:16-29 as a stand-alone op: y[t] = x[t] - coef*x[t-1], reflect pad */
 int afx_k_pre_emphasis(const float* x, int B, int L, float coef, float* y, void* stream);
 /* Utterance length policy, batched (data/test_set.py:139-146 pad, :201-227 adjustDuration, :229-248

@@ -114,15 +114,21 @@ def conformer_head(sd, feats, heads=4, q=None, taps=None):
     x = (x - sd["first_bn.running_mean"]) / torch.sqrt(sd["first_bn.running_var"] + BN_EPS) \
         * sd["first_bn.weight"] + sd["first_bn.bias"]
     x = F.selu(x)
-    tok = sd["conformer.class_token"].unsqueeze(0).expand(x.shape[0], -1, -1)
+    return my_conformer(sd, x, heads=heads, q=q, taps=taps)[0]
+
+
+def my_conformer(sd, x, heads=4, q=None, taps=None, prefix="conformer."):
+    """``MyConformer.forward`` (models/conformer_baseline.py:22-29): x (B,T,emb) -> (logits (B,2), embedding (B,emb)).
+    Class token prepended (:23-24), the cloned blocks (:25-26), token 0 (:27), fc5 (:28)."""
+    tok = sd[prefix + "class_token"].unsqueeze(0).expand(x.shape[0], -1, -1)
     x = torch.cat([tok, x], dim=1)
     if taps is not None:
         taps["tokens"] = x
     n = 0
-    while f"conformer.encoder_blocks.{n}.post_norm.weight" in sd:
-        x = conformer_block(sd, f"conformer.encoder_blocks.{n}.", x, heads, q)
+    while f"{prefix}encoder_blocks.{n}.post_norm.weight" in sd:
+        x = conformer_block(sd, f"{prefix}encoder_blocks.{n}.", x, heads, q)
         if taps is not None:
             taps[f"block{n}"] = x
         n += 1
     emb = x[:, 0, :]
-    return F.linear(emb, sd["conformer.fc5.weight"], sd["conformer.fc5.bias"])
+    return F.linear(emb, sd[prefix + "fc5.weight"], sd[prefix + "fc5.bias"]), emb

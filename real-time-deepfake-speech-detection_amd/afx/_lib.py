@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AFX_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libafx.so")
 
-ARCH_SSL, ARCH_XLSR_AASIST, ARCH_CONFORMER = 0, 1, 2
+ARCH_SSL, ARCH_XLSR_AASIST, ARCH_CONFORMER, ARCH_CONFORMER_HEAD = 0, 1, 2, 3
 DT_BF16, DT_FP16, DT_FP32 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_SWISH, ACT_SELU = 0, 1, 2, 3
 
@@ -47,6 +47,9 @@ SIGNATURES = {
     "afx_ssl_forward_ragged": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), _P, _Z, _P]),
     "afx_tail_workspace_bytes": (_Z, [_P, _I, _I]),
     "afx_tail_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
+    "afx_tail_forward_strided": (_I, [_P, _P, _L, _I, _I, _P, _P, _Z, _P]),
+    "afx_conformer_forward": (_I, [_P, _P, _I, _I, _P, _P, _P, _Z, _P]),
+    "afx_engine_set": (_I, [_P, C.c_char_p, _I]),
     "afx_enable_taps": (_I, [_P, _I]),
     "afx_tap": (_I, [_P, C.c_char_p, _P, _Z, C.POINTER(_Z), _P]),
     "afx_profile_begin": (_I, [_P]),
@@ -60,6 +63,9 @@ SIGNATURES = {
     "afx_k_pack_linear": (_I, [_I, _P, _I, _I, _I, _P, _P]),
     "afx_k_pack_conv": (_I, [_I, _P, _I, _I, _I, _P, _P]),
     "afx_k_conv0": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
+    "afx_k_conv0_pack_bytes": (_Z, []),
+    "afx_k_conv0_pack": (_I, [_P, _P, _P, _P]),
+    "afx_k_conv0_packed": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _F, _P, _P]),
     "afx_k_pre_emphasis": (_I, [_P, _I, _I, _F, _P, _P]),
     "afx_k_tile_crop": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "afx_k_rownorm": (_I, [_I, _P, _L, _I, _I, _P, _P, _F, _I, _P, _L, _P, _L, _P]),
@@ -90,11 +96,8 @@ def lib():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
         _lib = l
-        # A/B knobs for measurement runs, e.g. AFX_DEBUG="fuse_conformer=0,gemm_tile=0" (afx_debug_set keys)
-        for kv in filter(None, os.environ.get("AFX_DEBUG", "").split(",")):
-            key, _, val = kv.partition("=")
-            if l.afx_debug_set(key.strip().encode(), int(val)) != 0:
-                raise AfxError(l.afx_last_error().decode())
+        # (no environment hook: the A/B knobs are reached through afx_debug_set / Engine.set by the tools and tests that
+        # own the process, never by a stray variable in a product run)
     return _lib
 
 
@@ -112,3 +115,13 @@ def stream_ptr(device=None):
     """hipStream_t of torch's current stream on ``device`` (default: the current device)."""
     import torch
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def call_on(t, fn, *args):
+    """``fn(*args, stream)`` with the device ``t`` lives on made current and ``stream`` = torch's current stream ON THAT
+    DEVICE: a single-kernel entry point launches where its operands are, whatever torch's current device is (the
+    reference passes ``device=rank`` and never calls ``torch.cuda.set_device``, main.py:48)."""
+    import torch
+    with torch.cuda.device(t.device):
+        return fn(*args, stream_ptr(t.device))
+

@@ -9,7 +9,8 @@ import torch
 from . import _lib
 from ._lib import AfxError, Config, check, lib, ptr, stream_ptr
 
-ARCHS = {"ssl": _lib.ARCH_SSL, "xlsr_aasist": _lib.ARCH_XLSR_AASIST, "conformer": _lib.ARCH_CONFORMER}
+ARCHS = {"ssl": _lib.ARCH_SSL, "xlsr_aasist": _lib.ARCH_XLSR_AASIST, "conformer": _lib.ARCH_CONFORMER,
+         "conformer_head": _lib.ARCH_CONFORMER_HEAD}  # conformer_head: MyConformer alone (no trunk)
 DTYPES = {"bf16": _lib.DT_BF16, "fp16": _lib.DT_FP16, "fp32": _lib.DT_FP32}
 # fairseq extractor_mode: "layer_norm" = XLS-R (what the reference loads), "group_norm" = wav2vec2-base ("default")
 EXTRACTORS = {"layer_norm": 0, "group_norm": 1, "default": 1}
@@ -17,7 +18,7 @@ EXTRACTORS = {"layer_norm": 0, "group_norm": 1, "default": 1}
 # are what keeps the scores within 1e-3 of the fp32 reference (DESIGN.md "Numerics").
 # "fp32" is the exact mode: fp32 operands on the fp32 matrix instruction, 1/16 of the rate,
 # no reduced-precision rounding anywhere -- for parity work, not for throughput.
-DEFAULT_DTYPE = os.environ.get("AFX_DTYPE", "fp16")
+DEFAULT_DTYPE = "fp16"  # (no environment override: a stray variable must not change what a product run computes)
 
 
 def torch_dtype(name):
@@ -180,18 +181,42 @@ class Engine:
         return buf, list(frames)
 
     def tail(self, conv5):
-        """conv5: (B,T5,512) output of conv layer 5 in the operand type -> logits (B,2) (afx_tail_forward)."""
+        """conv5: (B,T5,512) output of conv layer 5 in the operand type -> logits (B,2) (afx_tail_forward).  A view into a
+        longer per-stream buffer (rows contiguous, any batch stride that is a multiple of 8 elements) is read in place."""
         self._on_device(conv5, "conv-layer-5 activations")
         if conv5.dtype != torch_dtype(self.dtype) or conv5.ndim != 3 or conv5.shape[2] != 512:
             raise ValueError(f"expected a (B,T5,512) {self.dtype} tensor, got {tuple(conv5.shape)} {conv5.dtype}")
-        c = conv5.contiguous()
-        B, T5 = c.shape[0], c.shape[1]
+        B, T5 = conv5.shape[0], conv5.shape[1]
+        c = conv5
+        if not (c.stride(2) == 1 and c.stride(1) == 512 and (B == 1 or (c.stride(0) >= T5 * 512 and c.stride(0) % 8 == 0))):
+            c = conv5.contiguous()
         l = lib()
         with torch.cuda.device(self.device):
             ws = self._workspace(l.afx_tail_workspace_bytes(self._h, B, T5))
             out = torch.empty(B, 2, dtype=torch.float32, device=self.device)
-            check(l.afx_tail_forward(self._h, ptr(c), B, T5, ptr(out), ptr(ws), ws.numel(), self._stream()))
+            check(l.afx_tail_forward_strided(self._h, ptr(c), c.stride(0) if B > 1 else 0, B, T5, ptr(out), ptr(ws), ws.numel(),
+                                             self._stream()))
         return out
+
+    def conformer(self, tokens):
+        """MyConformer.forward (models/conformer_baseline.py:22-29): tokens (B,T,emb) fp32 -> (logits (B,2), embedding (B,emb))."""
+        self._on_device(tokens, "tokens")
+        t = tokens.to(torch.float32).contiguous()
+        if t.ndim != 3:
+            raise ValueError(f"expected (B,T,emb) tokens, got shape {tuple(t.shape)}")
+        B, T, E = t.shape
+        l = lib()
+        with torch.cuda.device(self.device):
+            ws = self._workspace(l.afx_head_workspace_bytes(self._h, B, T))
+            out = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+            emb = torch.empty(B, E, dtype=torch.float32, device=self.device)
+            check(l.afx_conformer_forward(self._h, ptr(t), B, T, ptr(out), ptr(emb), ptr(ws), ws.numel(), self._stream()))
+        return out, emb
+
+    def set(self, key, value):
+        """Per-engine switch between two forms of the same op (afx_engine_set): posconv_sliding, conf_attn_mfma,
+        fuse_conformer, fuse_conv_ln."""
+        check(lib().afx_engine_set(self._h, key.encode(), int(value)))
 
     # ---- hipGraph replay: the ~130 launches of a forward as ONE graph launch ----------
     def capture(self, B, L):

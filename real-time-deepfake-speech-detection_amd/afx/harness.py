@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from . import dist as adist
-from ._lib import check, lib, ptr, stream_ptr
+from ._lib import call_on, check, lib, ptr, stream_ptr
 
 
 def f_state_dict_wrapper(state_dict, data_parallel=False):
@@ -48,7 +48,7 @@ class PreEmphasis(nn.Module):
             raise RuntimeError("PreEmphasis: input must be on the GPU (no CPU fallback)")
         x = x.to(torch.float32).contiguous()
         y = torch.empty_like(x)
-        check(lib().afx_k_pre_emphasis(ptr(x), x.shape[0], x.shape[1], self.coef, ptr(y), stream_ptr()))
+        check(call_on(x, lib().afx_k_pre_emphasis, ptr(x), x.shape[0], x.shape[1], self.coef, ptr(y)))
         return y
 
 
@@ -71,7 +71,7 @@ def batch_adjust_duration(clips, duration, starts=None, device="cuda"):
     clip) are the crop starts of data/test_set.py:229-248 for clips longer than ``duration``."""
     import ctypes as C
 
-    from ._lib import check, lib, ptr, stream_ptr
+    from ._lib import call_on, check, lib, ptr, stream_ptr
     lens = [int(c.numel()) for c in clips]
     if not clips or min(lens) <= 0:
         raise ValueError("every clip needs at least one sample")
@@ -85,7 +85,7 @@ def batch_adjust_duration(clips, duration, starts=None, device="cuda"):
                 raise ValueError("crop start outside the clip")
         st = torch.tensor(list(starts), dtype=torch.int64, device=device)
     out = torch.empty(len(clips), duration, dtype=torch.float32, device=device)
-    check(lib().afx_k_tile_crop(ptr(packed), ptr(offs_d), ptr(st), len(clips), duration, ptr(out), stream_ptr()))
+    check(call_on(packed, lib().afx_k_tile_crop, ptr(packed), ptr(offs_d), ptr(st), len(clips), duration, ptr(out)))
     return out
 
 
@@ -112,21 +112,34 @@ def write_score_file(save_path, utt_ids, scores):
             fh.write("{} {}\n".format(f, cm))
 
 
+def _as_device(device):
+    """``device`` as the reference passes it -- an int rank (main.py:48), 'cuda' / 'cuda:1' / 'cpu' or a torch.device --
+    as a torch.device; a CUDA device without an index means the current one."""
+    d = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+    if d.type == "cuda" and d.index is None and torch.cuda.is_available():
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d
+
+
 def prefetch_to_device(batches, device):
     """Iterate ``(meta, x_on_device)`` over ``(meta, x_host)`` pairs with the NEXT batch's H2D copy
     (pinned staging buffer, side stream) running under the current batch's forward.  The compute
     stream only waits on the copy's event, so a pass is bounded by max(compute, PCIe), not the sum."""
-    if not torch.cuda.is_available() or str(device) == "cpu":
+    dev = _as_device(device)
+    if not torch.cuda.is_available() or dev.type != "cuda":
         for meta, x in batches:
-            yield meta, x.to(device)
+            yield meta, x.to(dev)
         return
-    side = torch.cuda.Stream()
+    # every stream below is a stream OF `dev`, whatever torch's current device is (the reference passes device=rank and
+    # never calls torch.cuda.set_device, main.py:48): the copy runs on a side stream of the engine's GPU and the wait
+    # goes to that GPU's compute stream
+    side = torch.cuda.Stream(device=dev)
     it = iter(batches)
 
     def stage(item):
         meta, x = item
         with torch.cuda.stream(side):
-            xd = x.pin_memory().to(device, non_blocking=True)
+            xd = x.pin_memory().to(dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(side)
         return meta, xd, ev
@@ -137,8 +150,8 @@ def prefetch_to_device(batches, device):
         nxt = next(it, None)
         nxt = stage(nxt) if nxt is not None else None  # in flight while `cur` is consumed
         meta, xd, ev = cur
-        torch.cuda.current_stream().wait_event(ev)
-        xd.record_stream(torch.cuda.current_stream())
+        torch.cuda.current_stream(dev).wait_event(ev)
+        xd.record_stream(torch.cuda.current_stream(dev))
         yield meta, xd
         cur = nxt
 
@@ -273,6 +286,16 @@ def produce_evaluation_file_distributed(dataset, model, device, save_path, batch
 
     The utterance ids are collected in the scoring loop (each clip is decoded exactly once, by the loader's workers)
     and gathered as Python objects after the scores -- rank 0 never re-reads the dataset for a name."""
+    import contextlib
+    import torch.distributed as tdist
+    dev = _as_device(device)
+    # the engine's GPU is made current for the whole pass: under NCCL / RCCL all_gather_object stages its byte tensors on
+    # torch.cuda.current_device(), which without this is cuda:0 on every rank of a caller that passes device=rank
+    with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
+        return _produce_evaluation_file_distributed(dataset, model, dev, save_path, batch_size, num_workers, group)
+
+
+def _produce_evaluation_file_distributed(dataset, model, device, save_path, batch_size, num_workers, group):
     import torch.distributed as tdist
     rank, world = tdist.get_rank(group), tdist.get_world_size(group)
     idx = adist.shard_indices(len(dataset), rank, world)

@@ -80,41 +80,61 @@ class Wav2Vec2Trunk(nn.Module):
 
 class _StubPickle:
     """``pickle_module`` for torch.load of a fairseq checkpoint (``xlsr2_300m.pt`` carries argparse / omegaconf /
-    fairseq config objects beside the tensors).  ALLOW-LIST: only what rebuilding tensors and plain containers needs is
-    resolved to the real object (torch's own rebuild helpers and storage / dtype types, ``collections.OrderedDict``,
-    ``argparse.Namespace``, numpy's array / scalar reconstructors); EVERY other global -- installed or not, ``os.system``
-    and ``builtins.eval`` included -- becomes an inert stand-in class whose construction and ``__setstate__`` only store
-    what they are given.  So a crafted file cannot run code through this loader; only the ``model`` state_dict is read
-    afterwards."""
+    fairseq config objects beside the tensors).  ALLOW-LIST of exact ``(module, name)`` pairs: only what rebuilding
+    tensors and plain containers needs is resolved to the real object -- torch's tensor / parameter rebuild helpers, the
+    typed storage classes, ``torch.Size`` / ``torch.device`` / the dtype singletons, ``collections.OrderedDict``,
+    ``argparse.Namespace``, numpy's array / scalar reconstructors and a few builtin containers.  The pair is looked up
+    with ONE ``getattr`` on the already-imported module, never through ``pickle``'s own ``find_class``: protocol >= 4
+    resolves dotted names attribute by attribute, so "every attribute of torch.serialization" (round 2's rule) reached
+    ``torch.serialization.os.system``, ``torch.storage.io.open`` and ``torch._utils._import_dotted_name``.  A name with
+    a dot in it is never resolved.  EVERY other global -- installed or not -- becomes an inert stand-in class whose
+    construction and ``__setstate__`` only store what they are given.  So a crafted file cannot run code through this
+    loader; only the ``model`` state_dict is read afterwards."""
     import pickle as _pickle
 
     __name__ = "afx_stub_pickle"
-    _ALLOWED_MODULES = ("torch._utils", "torch.storage", "torch._tensor", "torch.serialization")
+    _STORAGES = ("UntypedStorage", "FloatStorage", "HalfStorage", "BFloat16Storage", "DoubleStorage", "LongStorage",
+                 "IntStorage", "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "ComplexFloatStorage",
+                 "ComplexDoubleStorage")
     _ALLOWED = {("collections", "OrderedDict"), ("argparse", "Namespace"), ("torch", "Size"), ("torch", "device"),
-                ("torch", "dtype"), ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"),
+                ("torch._utils", "_rebuild_parameter"), ("torch.nn.parameter", "Parameter"), ("torch", "Tensor"),
+                ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
                 ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy", "ndarray"),
                 ("numpy", "dtype"), ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "slice"),
-                ("builtins", "complex"), ("builtins", "bytearray")}
+                ("builtins", "complex"), ("builtins", "bytearray")} | {("torch", s) for s in _STORAGES}
+
+    @staticmethod
+    def _resolve(module, name):
+        """The real object behind an allow-listed pair, or None."""
+        import importlib
+        import sys
+        if "." in name:
+            return None
+        ok = (module, name) in _StubPickle._ALLOWED or \
+            (module == "torch" and isinstance(torch.__dict__.get(name), torch.dtype))
+        if not ok:
+            return None
+        try:
+            mod = sys.modules.get(module) or importlib.import_module(module)
+        except ImportError:
+            return None
+        return mod.__dict__.get(name)  # the module's OWN attribute: no attribute walk, no __getattr__ hook
 
     class Unpickler(_pickle.Unpickler):
         def find_class(self, module, name):
-            ok = (module, name) in _StubPickle._ALLOWED or \
-                (module in _StubPickle._ALLOWED_MODULES and name != "_load_from_bytes") or \
-                (module == "torch" and (name.endswith("Storage") or name.endswith("Tensor") or name in torch.__dict__
-                                        and isinstance(torch.__dict__[name], torch.dtype)))
-            if ok:
-                try:
-                    return super().find_class(module, name)
-                except (ImportError, AttributeError):
-                    pass
+            obj = _StubPickle._resolve(module, name)
+            if obj is not None:
+                return obj
 
             def __init__(self, *a, **k):
                 pass
 
             def __setstate__(self, state):
                 self.__dict__.update(state if isinstance(state, dict) else {"state": state})
-            return type(name, (), {"__module__": module, "__init__": __init__, "__setstate__": __setstate__,
-                                   "__call__": lambda self, *a, **k: None})
+            return type(name.rpartition(".")[2] or "stub", (), {"__module__": module, "__init__": __init__,
+                                                                "__setstate__": __setstate__,
+                                                                "__call__": lambda self, *a, **k: None})
 
     @staticmethod
     def load(f, **kw):

@@ -26,6 +26,7 @@ class ForwardHookManager:
         self.target_device = torch.device(target_device) if target_device is not None else None
         self.io_dict = {}
         self._wanted = {}   # id(model) -> {path: (requires_input, requires_output)}
+        self._models = {}   # id(model) -> model (to turn its engine's taps off again)
         self._handles = []
 
     # ---- path -> (input tap, output tap, shape fixers) ---------------------------------------
@@ -61,6 +62,7 @@ class ForwardHookManager:
         first = id(model) not in self._wanted
         self._wanted.setdefault(id(model), {})[module_path] = (bool(requires_input), bool(requires_output))
         if first:
+            self._models[id(model)] = model
             self._handles.append(model.register_forward_pre_hook(lambda mod, args: mod._afx_engine().enable_taps(True)))
             self._handles.append(model.register_forward_hook(self._collect))
 
@@ -84,6 +86,12 @@ class ForwardHookManager:
         return out
 
     def clear(self):
+        """Remove the hooks AND switch the engines' taps off again: with taps on every forward keeps fp32 copies of all
+        intermediates (device allocations, D2D copies, half -> fp32 kernels -- none of it capturable in a hipGraph)."""
         for h in self._handles:
             h.remove()
-        self._handles, self._wanted, self.io_dict = [], {}, {}
+        for model in self._models.values():
+            eng = model.__dict__.get("_afx_eng")
+            if eng is not None:
+                eng.enable_taps(False)
+        self._handles, self._wanted, self._models, self.io_dict = [], {}, {}, {}

@@ -3,7 +3,7 @@ parity tests.  All tensors must be contiguous CUDA tensors; ``dtype`` is "bf16" 
 "fp16" and names the matrix-core operand type of the half-precision arguments."""
 import torch
 
-from ._lib import ACT_GELU, ACT_NONE, ACT_SELU, ACT_SWISH, check, lib, ptr, stream_ptr
+from ._lib import ACT_GELU, ACT_NONE, ACT_SELU, ACT_SWISH, call_on, check, lib, ptr, stream_ptr
 from .engine import DTYPES, torch_dtype
 
 ACTS = {None: ACT_NONE, "gelu": ACT_GELU, "swish": ACT_SWISH, "selu": ACT_SELU}
@@ -15,8 +15,8 @@ def gemm(dtype, A, W, bias=None, act=None, alpha=1.0, resid=None, out_f=True, ou
     N = W.shape[0]
     of = torch.empty(M, N, dtype=torch.float32, device=A.device) if out_f else None
     oh = torch.empty(M, N, dtype=torch_dtype(dtype), device=A.device) if out_h else None
-    check(lib().afx_k_gemm(DTYPES[dtype], ptr(A), A.stride(0), ptr(W), W.stride(0), M, N, K, ptr(bias), ACTS[act],
-                           alpha, ptr(resid), N, ptr(of), N, ptr(oh), N, stream_ptr()))
+    check(call_on(A, lib().afx_k_gemm, DTYPES[dtype], ptr(A), A.stride(0), ptr(W), W.stride(0), M, N, K, ptr(bias), ACTS[act],
+                           alpha, ptr(resid), N, ptr(of), N, ptr(oh), N))
     return of, oh
 
 
@@ -24,14 +24,14 @@ def pack_linear(dtype, w, kpad=None):
     N, K = w.shape
     kpad = kpad or K
     out = torch.empty(N, kpad, dtype=torch_dtype(dtype), device=w.device)
-    check(lib().afx_k_pack_linear(DTYPES[dtype], ptr(w), N, K, kpad, ptr(out), stream_ptr()))
+    check(call_on(w, lib().afx_k_pack_linear, DTYPES[dtype], ptr(w), N, K, kpad, ptr(out)))
     return out
 
 
 def pack_conv(dtype, w):
     N, Cin, k = w.shape
     out = torch.empty(N, k * Cin, dtype=torch_dtype(dtype), device=w.device)
-    check(lib().afx_k_pack_conv(DTYPES[dtype], ptr(w), N, Cin, k, ptr(out), stream_ptr()))
+    check(call_on(w, lib().afx_k_pack_conv, DTYPES[dtype], ptr(w), N, Cin, k, ptr(out)))
     return out
 
 
@@ -41,8 +41,7 @@ def conv_gemm(dtype, x_h, wp, k, s, bias=None):
     N = wp.shape[0]
     Tout = (Tin - k) // s + 1
     out = torch.empty(B, Tout, N, dtype=torch.float32, device=x_h.device)
-    check(lib().afx_k_conv_gemm(DTYPES[dtype], ptr(x_h), ptr(wp), B, Tin, Tout, Cin, k, s, N, ptr(bias), ptr(out),
-                                stream_ptr()))
+    check(call_on(x_h, lib().afx_k_conv_gemm, DTYPES[dtype], ptr(x_h), ptr(wp), B, Tin, Tout, Cin, k, s, N, ptr(bias), ptr(out)))
     return out
 
 
@@ -52,8 +51,8 @@ def conv_ln_act(dtype, x_h, wp, k, s, bias, gamma, beta, act="gelu", eps=1e-5, o
     Tout = (Tin - k) // s + 1
     of = torch.empty(B, Tout, 512, dtype=torch.float32, device=x_h.device) if out_f else None
     oh = torch.empty(B, Tout, 512, dtype=torch_dtype(dtype), device=x_h.device) if out_h else None
-    check(lib().afx_k_conv_ln_act(DTYPES[dtype], ptr(x_h), ptr(wp), B, Tin, Tout, Cin, k, s, ptr(bias), ptr(gamma),
-                                  ptr(beta), eps, ACTS[act], ptr(of), ptr(oh), stream_ptr()))
+    check(call_on(x_h, lib().afx_k_conv_ln_act, DTYPES[dtype], ptr(x_h), ptr(wp), B, Tin, Tout, Cin, k, s, ptr(bias), ptr(gamma),
+                                  ptr(beta), eps, ACTS[act], ptr(of), ptr(oh)))
     return of, oh
 
 
@@ -61,8 +60,25 @@ def conv0(dtype, wave, w, bias, gamma, beta, pre_emph=False, coef=0.97):
     B, L = wave.shape
     T0 = (L - 10) // 5 + 1
     out = torch.empty(B, T0, 512, dtype=torch_dtype(dtype), device=wave.device)
-    check(lib().afx_k_conv0(DTYPES[dtype], ptr(wave), B, L, ptr(w), ptr(bias), ptr(gamma), ptr(beta),
-                            1 if pre_emph else 0, coef, ptr(out), stream_ptr()))
+    check(call_on(wave, lib().afx_k_conv0, DTYPES[dtype], ptr(wave), B, L, ptr(w), ptr(bias), ptr(gamma), ptr(beta),
+                            1 if pre_emph else 0, coef, ptr(out)))
+    return out
+
+
+def conv0_pack(w, bias):
+    """The layer's split-precision fp16 operand block, built once per checkpoint (afx_k_conv0_pack)."""
+    pack = torch.empty(lib().afx_k_conv0_pack_bytes(), dtype=torch.uint8, device=w.device)
+    check(call_on(w, lib().afx_k_conv0_pack, ptr(w), ptr(bias), ptr(pack)))
+    return pack
+
+
+def conv0_packed(dtype, wave, pack, w, bias, gamma, beta, pre_emph=False, coef=0.97):
+    """conv0 with the operand block passed in: asynchronous, no allocation inside the library (the streaming hot path)."""
+    B, L = wave.shape
+    T0 = (L - 10) // 5 + 1
+    out = torch.empty(B, T0, 512, dtype=torch_dtype(dtype), device=wave.device)
+    check(call_on(wave, lib().afx_k_conv0_packed, DTYPES[dtype], ptr(wave), B, L, ptr(pack), ptr(w), ptr(bias), ptr(gamma),
+                  ptr(beta), 1 if pre_emph else 0, coef, ptr(out)))
     return out
 
 
@@ -70,23 +86,23 @@ def rownorm(dtype, x, gamma, beta, eps=1e-5, act=None, out_f=True, out_h=False):
     rows, Cc = x.shape
     of = torch.empty(rows, Cc, dtype=torch.float32, device=x.device) if out_f else None
     oh = torch.empty(rows, Cc, dtype=torch_dtype(dtype), device=x.device) if out_h else None
-    check(lib().afx_k_rownorm(DTYPES[dtype], ptr(x), x.stride(0), rows, Cc, ptr(gamma), ptr(beta), eps, ACTS[act],
-                              ptr(of), Cc, ptr(oh), Cc, stream_ptr()))
+    check(call_on(x, lib().afx_k_rownorm, DTYPES[dtype], ptr(x), x.stride(0), rows, Cc, ptr(gamma), ptr(beta), eps, ACTS[act],
+                              ptr(of), Cc, ptr(oh), Cc))
     return of, oh
 
 
 def mhsa(dtype, qkv, B, T, H):
     """qkv (B*T, 3*H*64) half -> (B*T, H*64) half."""
     out = torch.empty(B * T, H * 64, dtype=torch_dtype(dtype), device=qkv.device)
-    check(lib().afx_k_mhsa(DTYPES[dtype], ptr(qkv), ptr(out), B, T, H, stream_ptr()))
+    check(call_on(qkv, lib().afx_k_mhsa, DTYPES[dtype], ptr(qkv), ptr(out), B, T, H))
     return out
 
 
 def conf_attn(dtype, q, kv, rel, B, N, H, dh, max_pos=512):
     """q (B*N,H*dh) fp32, kv (B*N,2*H*dh) fp32, rel (2*max_pos+1,dh) -> (B*N,H*dh) half."""
     out = torch.empty(B * N, H * dh, dtype=torch_dtype(dtype), device=q.device)
-    check(lib().afx_k_conf_attn(DTYPES[dtype], ptr(q), q.stride(0), ptr(kv), kv.stride(0), ptr(rel), max_pos, B, N, H,
-                                dh, ptr(out), H * dh, stream_ptr()))
+    check(call_on(q, lib().afx_k_conf_attn, DTYPES[dtype], ptr(q), q.stride(0), ptr(kv), kv.stride(0), ptr(rel), max_pos, B, N, H,
+                                dh, ptr(out), H * dh))
     return out
 
 
@@ -94,16 +110,16 @@ def conf_attn_mfma(dtype, q, kv, rel, B, N, H, dh, max_pos=512):
     """Matrix-core form of conf_attn (head dim 36, N <= 209): the table is packed to (2*max_pos+1, 64) halfs first."""
     rel_h = pack_linear(dtype, rel, 64)
     out = torch.empty(B * N, H * dh, dtype=torch_dtype(dtype), device=q.device)
-    check(lib().afx_k_conf_attn_mfma(DTYPES[dtype], ptr(q), q.stride(0), ptr(kv), kv.stride(0), ptr(rel_h), max_pos, B, N,
-                                     H, dh, ptr(out), H * dh, stream_ptr()))
+    check(call_on(q, lib().afx_k_conf_attn_mfma, DTYPES[dtype], ptr(q), q.stride(0), ptr(kv), kv.stride(0), ptr(rel_h), max_pos, B, N,
+                                     H, dh, ptr(out), H * dh))
     return out
 
 
 def conf_dwconv(dtype, x, w, bias, bn_scale, bn_shift, B, N, Cc, k):
     """x (B*N, 2*C) fp32 -> (B*N, C) half."""
     out = torch.empty(B * N, Cc, dtype=torch_dtype(dtype), device=x.device)
-    check(lib().afx_k_conf_dwconv(DTYPES[dtype], ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(bn_scale), ptr(bn_shift),
-                                  B, N, Cc, k, ptr(out), Cc, stream_ptr()))
+    check(call_on(x, lib().afx_k_conf_dwconv, DTYPES[dtype], ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(bn_scale), ptr(bn_shift),
+                                  B, N, Cc, k, ptr(out), Cc))
     return out
 
 
@@ -126,9 +142,9 @@ def gat(x, p, temp):
     B, N, din = x.shape
     dout = p["att_w"].shape[0]
     y = torch.empty(B, N, dout, dtype=torch.float32, device=x.device)
-    _check_aasist(lib().afx_k_gat(ptr(x), B, N, din, dout, ptr(p["att_w"]), ptr(p["att_b"]), ptr(p["att_vec"]),
+    _check_aasist(call_on(x, lib().afx_k_gat, ptr(x), B, N, din, dout, ptr(p["att_w"]), ptr(p["att_b"]), ptr(p["att_vec"]),
                                   ptr(p["w1"]), ptr(p["b1"]), ptr(p["w2"]), ptr(p["b2"]), ptr(p["bn_scale"]),
-                                  ptr(p["bn_shift"]), temp, ptr(y), stream_ptr()))
+                                  ptr(p["bn_shift"]), temp, ptr(y)))
     return y
 
 
@@ -138,9 +154,8 @@ def resblock(x, conv1_w, conv1_b, bn2_scale, bn2_shift, conv2_w, conv2_b, down_w
     cout = conv1_w.shape[0]
     scratch = torch.empty(lib().afx_k_resblock_scratch_floats(B, cin, cout, H, W), dtype=torch.float32, device=x.device)
     y = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
-    _check_aasist(lib().afx_k_resblock(ptr(x), B, cin, cout, H, W, ptr(conv1_w), ptr(conv1_b), ptr(bn2_scale),
-                                       ptr(bn2_shift), ptr(conv2_w), ptr(conv2_b), ptr(down_w), ptr(down_b),
-                                       ptr(scratch), ptr(y), stream_ptr()))
+    _check_aasist(call_on(x, lib().afx_k_resblock, ptr(x), B, cin, cout, H, W, ptr(conv1_w), ptr(conv1_b), ptr(bn2_scale),
+                          ptr(bn2_shift), ptr(conv2_w), ptr(conv2_b), ptr(down_w), ptr(down_b), ptr(scratch), ptr(y)))
     return y
 
 
@@ -164,8 +179,8 @@ def hgat(x1, x2, p, temp, master=None):
     if master is not None:
         master = master.contiguous()
         mstride = 0 if master.shape[0] == 1 else din  # a (1,1,D) parameter is shared by the batch
-    _check_aasist(lib().afx_k_hgat(ptr(x1), n1, ptr(x2), n2, B, din, dout, arr, temp, ptr(master), mstride,
-                                   ptr(scratch), ptr(y1), ptr(y2), ptr(mo), stream_ptr()))
+    _check_aasist(call_on(x1, lib().afx_k_hgat, ptr(x1), n1, ptr(x2), n2, B, din, dout, arr, temp, ptr(master), mstride,
+                                   ptr(scratch), ptr(y1), ptr(y2), ptr(mo)))
     return y1, y2, mo
 
 
@@ -174,5 +189,5 @@ def graph_pool(h, w, b, k):
     B, N, D = h.shape
     keep = max(int(N * k), 1)
     out = torch.empty(B, keep, D, dtype=torch.float32, device=h.device)
-    _check_aasist(lib().afx_k_graph_pool(ptr(h), B, N, D, keep, ptr(w), ptr(b), ptr(out), stream_ptr()))
+    _check_aasist(call_on(h, lib().afx_k_graph_pool, ptr(h), B, N, D, keep, ptr(w), ptr(b), ptr(out)))
     return out

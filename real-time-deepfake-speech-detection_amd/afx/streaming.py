@@ -32,7 +32,7 @@ import torch
 
 from . import harness
 from . import kernels as K
-from ._lib import check, lib, ptr, stream_ptr
+from ._lib import call_on, check, lib, ptr, stream_ptr
 
 CONV_KS = [(10, 5), (3, 2), (3, 2), (3, 2), (3, 2), (2, 2), (2, 2)]
 
@@ -45,6 +45,7 @@ class SlidingWindowScorer:
             raise ValueError("window, hop and the number of streams must be positive")
         self.model, self.S, self.window, self.hop = model, n_streams, window, hop
         self.ring = torch.zeros(n_streams, window, dtype=torch.float32, device=device)
+        self.device = self.ring.device  # every launch of a push() goes to THIS GPU, whatever torch's current device is
         self.total = 0  # samples received per stream (streams advance in lockstep)
         self._offs = (torch.arange(n_streams + 1, dtype=torch.int64) * window).to(device)
         self._starts = torch.zeros(n_streams, dtype=torch.int64, device=device)
@@ -64,13 +65,17 @@ class SlidingWindowScorer:
         if self.total < self.window:  # warm-up: the history so far, repeated (reference pad policy)
             return harness.batch_adjust_duration([self.ring[s, : self.total] for s in range(self.S)], self.window)
         self._starts.fill_(self.total % self.window)  # steady state: one batched ring read, oldest sample first
-        check(lib().afx_k_tile_crop(ptr(self.ring), ptr(self._offs), ptr(self._starts), self.S, self.window,
-                                    ptr(self._batch), stream_ptr()))
+        check(call_on(self.ring, lib().afx_k_tile_crop, ptr(self.ring), ptr(self._offs), ptr(self._starts), self.S, self.window,
+                                    ptr(self._batch)))
         return self._batch
 
     def push(self, chunk):
         """chunk: (S, hop) fp32 on the GPU, the newest `hop` samples of every stream.
         Returns the (S,) bonafide scores of the current windows."""
+        with torch.cuda.device(self.device):
+            return self._push(chunk)
+
+    def _push(self, chunk):
         self._store(chunk)
         batch = self._window_batch()
         out = self.model.forward(batch) if hasattr(self.model, "forward") else self.model(batch)
@@ -100,6 +105,7 @@ class IncrementalScorer(SlidingWindowScorer):
         dev = engine.device
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
         self.w0 = f32(sd[pre + "0.0.weight"])
+        self.pack0 = K.conv0_pack(self.w0, f32(sd[pre + "0.0.bias"]))  # layer 0's matrix-core operand block: once, not per hop
         self.cw = [None] + [K.pack_conv(self.dt, f32(sd[f"{pre}{i}.0.weight"])) for i in range(1, 6)]
         self.cb = [f32(sd[f"{pre}{i}.0.bias"]) for i in range(6)]
         self.lg = [f32(sd[f"{pre}{i}.2.1.weight"]) for i in range(6)]
@@ -112,7 +118,25 @@ class IncrementalScorer(SlidingWindowScorer):
             raise ValueError("window too short")
         self.carry = [torch.empty(n_streams, 0, dtype=torch.float32, device=dev)] + \
                      [torch.empty(n_streams, 0, 512, dtype=K.torch_dtype(self.dt), device=dev) for _ in range(5)]
-        self.l5 = torch.empty(n_streams, 0, 512, dtype=K.torch_dtype(self.dt), device=dev)  # newest T5 layer-5 frames
+        # Layer-5 ring: a linear buffer of 2 x T5 frames per stream; new frames are written at `_l5_end`, the window is the
+        # VIEW of the T5 frames that end there (afx_tail_forward_strided reads it in place), and when the buffer is full
+        # the newest T5 - 1 frames move to its front: one copy of the window every ~T5 / 25 hops instead of two per hop.
+        self._l5_buf = torch.empty(n_streams, 2 * self.T5, 512, dtype=K.torch_dtype(self.dt), device=dev)
+        self._l5_end = 0
+
+    @property
+    def l5(self):
+        """The newest (at most T5) layer-5 frames of every stream: a view into the ring, no copy."""
+        return self._l5_buf[:, max(self._l5_end - self.T5, 0):self._l5_end]
+
+    def _l5_append(self, new5):
+        n = new5.shape[1]
+        if self._l5_end + n > self._l5_buf.shape[1]:  # full: keep what the next window still needs, at the front
+            keep = min(self._l5_end, self.T5)
+            self._l5_buf[:, :keep] = self._l5_buf[:, self._l5_end - keep:self._l5_end].clone()
+            self._l5_end = keep
+        self._l5_buf[:, self._l5_end:self._l5_end + n] = new5
+        self._l5_end += n
 
     def _advance(self, chunk):
         """Feed `hop` new samples through conv layers 0-5; only frames that became computable are produced."""
@@ -125,18 +149,18 @@ class IncrementalScorer(SlidingWindowScorer):
                 return None
             xin = x[:, : (n_out - 1) * s + k].contiguous()
             if i == 0:
-                y = K.conv0(self.dt, xin, self.w0, self.cb[0], self.lg[0], self.lb[0])
+                y = K.conv0_packed(self.dt, xin, self.pack0, self.w0, self.cb[0], self.lg[0], self.lb[0])
             else:
                 _, y = K.conv_ln_act(self.dt, xin, self.cw[i], k, s, self.cb[i], self.lg[i], self.lb[i], out_f=False, out_h=True)
             if i < 5:
                 x = torch.cat([self.carry[i + 1], y], dim=1)
         return y
 
-    def push(self, chunk):
+    def _push(self, chunk):
         self._store(chunk)
         new5 = self._advance(chunk)
         if new5 is not None:
-            self.l5 = torch.cat([self.l5, new5], dim=1)[:, -self.T5:]
+            self._l5_append(new5)
         if self.total < self.window:  # the window is still filling: the reference would be given the tiled history
             out = self.eng.forward(self._window_batch())
         else:

@@ -12,7 +12,7 @@ namespace afx {
 // scale/shift), SELU, then the class token prepended to every utterance.
 // ---------------------------------------------------------------------------------
 __global__ void conf_tokens_kernel(const float* __restrict__ ll, const float* __restrict__ cls, float bn_scale,
-                                   float bn_shift, int T, int E, float* __restrict__ out) {
+                                   float bn_shift, int T, int E, float* __restrict__ out, int raw) {
   const int b = blockIdx.y;
   const long n = (long)(T + 1) * E;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -20,14 +20,16 @@ __global__ void conf_tokens_kernel(const float* __restrict__ ll, const float* __
     float v;
     if (row == 0)
       v = cls[c];
+    else if (raw)
+      v = ll[((long)b * T + row - 1) * E + c];
     else
       v = selu(fmaf(ll[((long)b * T + row - 1) * E + c], bn_scale, bn_shift));
     out[(long)b * n + i] = v;
   }
 }
 const char* launch_conf_tokens(const float* ll, const float* cls, float bn_scale, float bn_shift, int B, int T,
-                               int E, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(conf_tokens_kernel, dim3(16, B), dim3(256), 0, s, ll, cls, bn_scale, bn_shift, T, E, out);
+                               int E, float* out, hipStream_t s, bool raw) {
+  hipLaunchKernelGGL(conf_tokens_kernel, dim3(16, B), dim3(256), 0, s, ll, cls, bn_scale, bn_shift, T, E, out, raw ? 1 : 0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -108,6 +108,11 @@ struct afx_engine {
   std::unordered_set<std::string> loaded;
   bool finalized = false;
   bool taps_on = false;
+  // A/B switches between forms of the same op (afx_engine_set; per engine: another engine of the process is not touched)
+  int posconv_sliding = 1;  // positional conv: sliding-window kernel (0: chunked-K GEMM)
+  int conf_attn_mfma = 1;   // Conformer attention on the matrix cores (0: the fp32 VALU kernel)
+  int fuse_conformer = 1;   // Conformer block: row-local chains fused (afx_conformer_fused.hip); 0 = per-op path
+  int fuse_conv_ln = 1;     // conv layers 1-6: LayerNorm + GELU in the GEMM epilogue (0: two kernels)
   std::unordered_map<std::string, TapRec> taps;
 
   // trunk, packed operand-type weights
@@ -147,10 +152,11 @@ extern "C" const char* afx_version(void) { return "afx 0.1 (gfx950)"; }
 
 extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
   if (!cfg || !out) return fail("afx_create: null argument");
-  if (cfg->n_layers < 1 || cfg->n_layers > 24)
+  const bool head_only = cfg->arch == AFX_ARCH_CONFORMER_HEAD;  // MyConformer alone: no trunk in this handle
+  if (!head_only && (cfg->n_layers < 1 || cfg->n_layers > 24))
     return fail("Number of layers must be at least 1 and at most 24.");  // models/fe.py:60-62
   if (cfg->dtype != AFX_DT_BF16 && cfg->dtype != AFX_DT_FP16 && cfg->dtype != AFX_DT_FP32) return fail("afx_create: unknown dtype %d", cfg->dtype);
-  if (cfg->arch < AFX_ARCH_SSL || cfg->arch > AFX_ARCH_CONFORMER) return fail("afx_create: unknown arch %d", cfg->arch);
+  if (cfg->arch < AFX_ARCH_SSL || cfg->arch > AFX_ARCH_CONFORMER_HEAD) return fail("afx_create: unknown arch %d", cfg->arch);
   if (cfg->extractor_mode != AFX_EXTRACTOR_LAYER_NORM && cfg->extractor_mode != AFX_EXTRACTOR_GROUP_NORM)
     return fail("afx_create: unknown extractor_mode %d", cfg->extractor_mode);
   if (cfg->extractor_mode == AFX_EXTRACTOR_GROUP_NORM && cfg->pre_emphasis)
@@ -162,17 +168,20 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
   e->cfg = *cfg;
   e->dt = cfg->dtype;
   e->hsz = dtype_size(cfg->dtype);
-  const int nl = cfg->n_layers;
+  const int nl = head_only ? 0 : cfg->n_layers;
+  e->cfg.n_layers = nl;
   e->wqkv.assign(nl, nullptr);
   e->wo.assign(nl, nullptr);
   e->w1.assign(nl, nullptr);
   e->w2.assign(nl, nullptr);
   e->bqkv.assign(nl, nullptr);
   bool ok = true;
-  for (int i = 1; i < 7; ++i) ok &= (e->convw[i] = e->dalloc((size_t)kC * kC * kConvK[i] * e->hsz)) != nullptr;
-  ok &= (e->projw = e->dalloc((size_t)kD * kC * e->hsz)) != nullptr;
-  ok &= (e->posw = e->dalloc((size_t)kD * (kD / kPosG) * kPosK * e->hsz)) != nullptr;
-  ok &= (e->pos_norm = (float*)e->dalloc(kPosK * 4)) != nullptr;
+  if (!head_only) {
+    for (int i = 1; i < 7; ++i) ok &= (e->convw[i] = e->dalloc((size_t)kC * kC * kConvK[i] * e->hsz)) != nullptr;
+    ok &= (e->projw = e->dalloc((size_t)kD * kC * e->hsz)) != nullptr;
+    ok &= (e->posw = e->dalloc((size_t)kD * (kD / kPosG) * kPosK * e->hsz)) != nullptr;
+    ok &= (e->pos_norm = (float*)e->dalloc(kPosK * 4)) != nullptr;
+  }
   for (int l = 0; l < nl && ok; ++l) {
     ok &= (e->wqkv[l] = e->dalloc((size_t)3 * kD * kD * e->hsz)) != nullptr;
     ok &= (e->wo[l] = e->dalloc((size_t)kD * kD * e->hsz)) != nullptr;
@@ -180,15 +189,15 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
     ok &= (e->w2[l] = e->dalloc((size_t)kD * kF * e->hsz)) != nullptr;
     ok &= (e->bqkv[l] = (float*)e->dalloc((size_t)3 * kD * 4)) != nullptr;
   }
-  if (cfg->arch == AFX_ARCH_CONFORMER) {
+  if (cfg->arch == AFX_ARCH_CONFORMER || head_only) {
     e->E = cfg->conf_emb;
     e->heads = cfg->conf_heads;
     e->ck = cfg->conf_kernel;
     e->nblk = cfg->conf_blocks;
     if (e->E <= 0 || e->heads <= 0 || e->E % e->heads || e->E % 4 || e->ck <= 0 || e->nblk <= 0) {
-      afx_destroy(e);
-      return fail("afx_create: bad Conformer configuration (emb %d heads %d kernel %d blocks %d)", e->E, e->heads,
-                  e->ck, e->nblk);
+      afx_destroy(e);  // (the message reads the caller's cfg: `e` is gone -- a use-after-free found by `make asan`)
+      return fail("afx_create: bad Conformer configuration (emb %d heads %d kernel %d blocks %d)", cfg->conf_emb, cfg->conf_heads,
+                  cfg->conf_kernel, cfg->conf_blocks);
     }
     e->dh = e->E / e->heads;
     e->inner = e->dh * e->heads;
@@ -197,7 +206,7 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
     e->FFp = round_up(e->FF, 64);
     e->C2 = 2 * e->E;
     e->C2p = round_up(e->C2, 64);
-    ok &= (e->conf_ll = e->dalloc((size_t)e->E * kD * e->hsz)) != nullptr;
+    if (!head_only) ok &= (e->conf_ll = e->dalloc((size_t)e->E * kD * e->hsz)) != nullptr;
     e->blk.resize(e->nblk);
     for (int b = 0; b < e->nblk && ok; ++b) {
       ConfBlock& B = e->blk[b];
@@ -387,7 +396,8 @@ extern "C" int afx_load_weight(afx_handle h, const char* name, const float* dev_
     }
     return 0;
   }
-  if (h->cfg.arch == AFX_ARCH_CONFORMER) return load_conformer(h, k, dev_ptr, shape, ndim, s);
+  if (h->cfg.arch == AFX_ARCH_CONFORMER_HEAD && (k == "LL.weight" || starts_with(k, "LL.") || starts_with(k, "first_bn."))) return 0;
+  if (h->cfg.arch == AFX_ARCH_CONFORMER || h->cfg.arch == AFX_ARCH_CONFORMER_HEAD) return load_conformer(h, k, dev_ptr, shape, ndim, s);
   // AASIST head: everything is small fp32; bn1.* never influences the output (Q2)
   if (k.find(".bn1.") != std::string::npos) return 0;
   return store_raw(h, k, dev_ptr, shape, ndim, s);
@@ -411,47 +421,50 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const std::string P = "ssl_model.model.";
   const bool gn = h->cfg.extractor_mode == AFX_EXTRACTOR_GROUP_NORM;
-  for (int i = 0; i < 7; ++i) {
-    const std::string c = P + "feature_extractor.conv_layers." + std::to_string(i);
-    if (need(h, c + ".0.weight")) return 1;
-    if (gn) {  // wav2vec2-base: bias-free convs, GroupNorm(512,512) on layer 0 only
-      if (i == 0 && (need(h, c + ".2.weight") || need(h, c + ".2.bias"))) return 1;
-    } else if (need(h, c + ".0.bias") || need(h, c + ".2.1.weight") || need(h, c + ".2.1.bias")) {
-      return 1;
+  const bool head_only = h->cfg.arch == AFX_ARCH_CONFORMER_HEAD;
+  if (!head_only) {
+    for (int i = 0; i < 7; ++i) {
+      const std::string c = P + "feature_extractor.conv_layers." + std::to_string(i);
+      if (need(h, c + ".0.weight")) return 1;
+      if (gn) {  // wav2vec2-base: bias-free convs, GroupNorm(512,512) on layer 0 only
+        if (i == 0 && (need(h, c + ".2.weight") || need(h, c + ".2.bias"))) return 1;
+      } else if (need(h, c + ".0.bias") || need(h, c + ".2.1.weight") || need(h, c + ".2.1.bias")) {
+        return 1;
+      }
+    }
+    for (const char* k : {"layer_norm.weight", "layer_norm.bias", "post_extract_proj.weight", "post_extract_proj.bias",
+                          "encoder.pos_conv.0.bias", "encoder.layer_norm.weight", "encoder.layer_norm.bias"})
+      if (need(h, P + k)) return 1;
+    for (int l = 0; l < h->cfg.n_layers; ++l) {
+      const std::string L = P + "encoder.layers." + std::to_string(l) + ".";
+      for (const char* k : {"self_attn.q_proj.weight", "self_attn.q_proj.bias", "self_attn.k_proj.weight",
+                            "self_attn.k_proj.bias", "self_attn.v_proj.weight", "self_attn.v_proj.bias",
+                            "self_attn.out_proj.weight", "self_attn.out_proj.bias", "self_attn_layer_norm.weight",
+                            "self_attn_layer_norm.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias",
+                            "final_layer_norm.weight", "final_layer_norm.bias"})
+        if (need(h, L + k)) return 1;
+    }
+    if (!gn && h->dt != AFX_DT_FP32) {  // conv layer 0 as the split-precision fp16 matrix-core operand
+      if (!h->conv0pack && !(h->conv0pack = h->dalloc(conv0_pack_bytes()))) return fail("afx_finalize: device allocation failed");
+      KOK(launch_conv0_pack(h->F("ssl.feature_extractor.conv_layers.0.0.weight"), h->F("ssl.feature_extractor.conv_layers.0.0.bias"),
+                            h->conv0pack, s));
+    }
+    // positional conv: weight-norm (dim=2) folded into the packed operand
+    const float* pv = h->F("ssl.encoder.pos_conv.0.weight_v");
+    const float* pg = h->F("ssl.encoder.pos_conv.0.weight_g");
+    const float* pw = h->F("ssl.encoder.pos_conv.0.weight");
+    if (pv && pg) {
+      KOK(launch_pack_posconv(pv, pg, kD, kD / kPosG, kPosK, h->pos_norm, h->posw, h->dt, s));
+    } else if (pw) {
+      KOK(launch_pack_posconv(pw, nullptr, kD, kD / kPosG, kPosK, h->pos_norm, h->posw, h->dt, s));
+    } else {
+      return fail("afx_finalize: missing weight '%sencoder.pos_conv.0.weight_g/weight_v'", P.c_str());
     }
   }
-  for (const char* k : {"layer_norm.weight", "layer_norm.bias", "post_extract_proj.weight", "post_extract_proj.bias",
-                        "encoder.pos_conv.0.bias", "encoder.layer_norm.weight", "encoder.layer_norm.bias"})
-    if (need(h, P + k)) return 1;
-  for (int l = 0; l < h->cfg.n_layers; ++l) {
-    const std::string L = P + "encoder.layers." + std::to_string(l) + ".";
-    for (const char* k : {"self_attn.q_proj.weight", "self_attn.q_proj.bias", "self_attn.k_proj.weight",
-                          "self_attn.k_proj.bias", "self_attn.v_proj.weight", "self_attn.v_proj.bias",
-                          "self_attn.out_proj.weight", "self_attn.out_proj.bias", "self_attn_layer_norm.weight",
-                          "self_attn_layer_norm.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias",
-                          "final_layer_norm.weight", "final_layer_norm.bias"})
-      if (need(h, L + k)) return 1;
-  }
-  if (!gn && h->dt != AFX_DT_FP32) {  // conv layer 0 as the split-precision fp16 matrix-core operand
-    if (!h->conv0pack && !(h->conv0pack = h->dalloc(conv0_pack_bytes()))) return fail("afx_finalize: device allocation failed");
-    KOK(launch_conv0_pack(h->F("ssl.feature_extractor.conv_layers.0.0.weight"), h->F("ssl.feature_extractor.conv_layers.0.0.bias"),
-                          h->conv0pack, s));
-  }
-  // positional conv: weight-norm (dim=2) folded into the packed operand
-  const float* pv = h->F("ssl.encoder.pos_conv.0.weight_v");
-  const float* pg = h->F("ssl.encoder.pos_conv.0.weight_g");
-  const float* pw = h->F("ssl.encoder.pos_conv.0.weight");
-  if (pv && pg) {
-    KOK(launch_pack_posconv(pv, pg, kD, kD / kPosG, kPosK, h->pos_norm, h->posw, h->dt, s));
-  } else if (pw) {
-    KOK(launch_pack_posconv(pw, nullptr, kD, kD / kPosG, kPosK, h->pos_norm, h->posw, h->dt, s));
-  } else {
-    return fail("afx_finalize: missing weight '%sencoder.pos_conv.0.weight_g/weight_v'", P.c_str());
-  }
-  if (h->cfg.arch == AFX_ARCH_CONFORMER) {
+  if (h->cfg.arch == AFX_ARCH_CONFORMER || head_only) {
     for (const char* k : {"LL.weight", "LL.bias", "first_bn.weight", "first_bn.bias", "first_bn.running_mean",
                           "first_bn.running_var", "conformer.class_token", "conformer.fc5.weight", "conformer.fc5.bias"})
-      if (need(h, k)) return 1;
+      if (!(head_only && strncmp(k, "conformer.", 10)) && need(h, k)) return 1;
     for (int b = 0; b < h->nblk; ++b) {
       const std::string B = "conformer.encoder_blocks." + std::to_string(b) + ".";
       for (const char* k :
@@ -490,6 +503,10 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
             put(2, CP_BA, "conv.net.7.bias", 144))
           return 1;
       }
+    }
+    if (head_only) {
+      h->finalized = true;
+      return 0;
     }
     // BatchNorm2d(1): four scalars -> host (one-off synchronisation)
     float w, b, m, v;
@@ -582,7 +599,7 @@ static size_t carve(const afx_engine* e, int B, int L, int Tfeat, void* base, Ws
       w->bucket_logits = (float*)c.take((size_t)B * 2 * 4);
     }
   }
-  if (e->cfg.arch == AFX_ARCH_CONFORMER) {
+  if (e->cfg.arch == AFX_ARCH_CONFORMER || e->cfg.arch == AFX_ARCH_CONFORMER_HEAD) {
     const size_t M = (size_t)B * (T + 1);
     w->ll32 = (float*)c.take((size_t)B * T * e->E * 4);
     w->xc = (float*)c.take(M * e->E * 4);
@@ -680,10 +697,6 @@ struct Profiler {
   }
 };
 static thread_local Profiler* t_prof = nullptr;  // the profiler of the engine whose forward runs on this thread
-static int g_posconv_sliding = 1;  // positional conv: sliding-window kernel (0: chunked-K GEMM)
-static int g_conf_attn_mfma = 1;   // Conformer attention on the matrix cores (0: the fp32 VALU kernel)
-static int g_fuse_conformer = 1;  // Conformer block: row-local chains fused (afx_conformer_fused.hip); 0 = per-op path
-static int g_fuse_conv_ln = 1;  // conv layers 1-6: LayerNorm+GELU in the GEMM epilogue (A/B knob)
 static void prof_forget(afx_engine* e) {
   if (!e->prof) return;
   for (hipEvent_t ev : e->prof->pool) (void)hipEventDestroy(ev);
@@ -768,7 +781,8 @@ static RowNormArgs plain_norm(const float* x, long ldx, int rows, int C, const f
 #define launch_rownorm P_rownorm
 
 // l5: null = start from the waveform; else the output of conv layer 5, (B, T[5], 512) operand type (tail mode)
-static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipStream_t s, const void* l5 = nullptr) {
+// l5_batch: elements between two utterances of l5 (0 = packed, T[5] * 512): a streaming caller keeps its window inside a longer ring
+static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipStream_t s, const void* l5 = nullptr, long l5_batch = 0) {
   const int dt = e->dt;
   const int* T = w.T;
   if (T[6] < 1) return fail("afx_forward: %d samples are too few for one output frame (need >= 400)", L);
@@ -792,7 +806,7 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
   for (int i = l5 ? 6 : 1; i < 7; ++i) {
     const int M = B * T[i], K = kConvK[i] * kC;
     GemmArgs g = plain_gemm(in, 0, e->convw[i], K, M, kC, K);
-    g.rpb = T[i]; g.a_batch = (long)T[i - 1] * kC; g.a_row = (long)kConvS[i] * kC;
+    g.rpb = T[i]; g.a_batch = (l5 && i == 6 && l5_batch) ? l5_batch : (long)T[i - 1] * kC; g.a_row = (long)kConvS[i] * kC;
     g.o_batch_rows = T[i]; g.oh_batch_rows = T[i];
     g.bias = gn ? nullptr : cf(i, ".0.bias");
     g.act = ACT_GELU;
@@ -803,7 +817,7 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
         g.out_f = w.tmp32; g.ldo_f = kC;
       }
       KOK(launch_gemm(g, dt, 1, s));
-    } else if (g_fuse_conv_ln && dt != DT_FP32) {
+    } else if (e->fuse_conv_ln && dt != DT_FP32) {
       g.ln_gamma = cf(i, ".2.1.weight"); g.ln_beta = cf(i, ".2.1.bias"); g.ln_eps = kLnEps;
       if (i < 6) {
         g.out_h = out; g.ldo_h = kC;
@@ -848,7 +862,7 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
   }
   if (tap(e, "proj", w.x, (size_t)M * kD, false, s)) return 1;
   // positional conv (grouped, k=128) + GELU, added to x in place
-  if (g_posconv_sliding && dt != DT_FP32 && Tt <= 224) {  // (reads the zero-padded operand copy: ragged batches need nothing more)
+  if (e->posconv_sliding && dt != DT_FP32 && Tt <= 224) {  // (reads the zero-padded operand copy: ragged batches need nothing more)
     PosConvArgs pc;
     memset(&pc, 0, sizeof pc);
     pc.xpad = w.xpad; pc.xpad_batch = (long)(Tt + kPosK) * kD; pc.W = e->posw; pc.bias = e->F("ssl.encoder.pos_conv.0.bias");
@@ -907,21 +921,28 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
 }
 
 // Conformer head from SSL features already in w.ssl_h (operand type)
-static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipStream_t s) {
+// tokens: null = from the SSL features in w.ssl_h (Model / MyModel.forward); else the (B,T,E) fp32 rows MyConformer.forward
+// is given (models/conformer_baseline.py:22-29).  embedding (device (B,E) fp32, may be null) receives token 0 of every utterance.
+static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipStream_t s, const float* tokens = nullptr,
+                         float* embedding = nullptr) {
   const int dt = e->dt, E = e->E, Ep = e->Ep, N = T + 1, M = B * N;
-  // LL -> BatchNorm2d(1) -> SELU -> class token
-  GemmArgs ll = plain_gemm(w.ssl_h, kD, e->conf_ll, kD, B * T, E, kD);
-  ll.bias = e->F("LL.bias");
-  ll.out_f = w.ll32; ll.ldo_f = E;
-  KOK(launch_gemm(ll, dt, 1, s));
-  KOK(timed(PC_MISC, 0, s, [&] {
-    return launch_conf_tokens(w.ll32, e->F("conformer.class_token"), e->conf_bn_scale, e->conf_bn_shift, B, T, E, w.xc, s);
-  }));
+  if (tokens) {  // class token + the rows as they are
+    KOK(timed(PC_MISC, 0, s, [&] { return launch_conf_tokens(tokens, e->F("conformer.class_token"), 1.f, 0.f, B, T, E, w.xc, s, true); }));
+  } else {
+    // LL -> BatchNorm2d(1) -> SELU -> class token
+    GemmArgs ll = plain_gemm(w.ssl_h, kD, e->conf_ll, kD, B * T, E, kD);
+    ll.bias = e->F("LL.bias");
+    ll.out_f = w.ll32; ll.ldo_f = E;
+    KOK(launch_gemm(ll, dt, 1, s));
+    KOK(timed(PC_MISC, 0, s, [&] {
+      return launch_conf_tokens(w.ll32, e->F("conformer.class_token"), e->conf_bn_scale, e->conf_bn_shift, B, T, E, w.xc, s);
+    }));
+  }
   if (tap(e, "tokens", w.xc, (size_t)M * E, false, s)) return 1;
   // K-padding columns of the operand buffers must read as zero (the fused chains only read past
   // the real columns of the attention output: 144 -> 160)
   const size_t hs = dtype_size(dt);
-  const bool fused = g_fuse_conformer && dt != DT_FP32 && E == 144 && e->inner == E && e->FFp == 4 * E;
+  const bool fused = e->fuse_conformer && dt != DT_FP32 && E == 144 && e->inner == E && e->FFp == 4 * E;
   HIP_OK(hipMemsetAsync(w.ao, 0, (size_t)M * Ep * hs, s));
   if (!fused) {
     HIP_OK(hipMemsetAsync(w.hc, 0, (size_t)M * Ep * hs, s));
@@ -944,7 +965,7 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     c.out2 = w.qkv32; c.ld_out2 = 3 * e->inner;
     KOK(timed(PC_CONF_CHAIN, ff_fl + 2.0 * M * E * 3 * e->inner, s, [&] { return launch_conf_chain(c, 0, dt, s); }));
     KOK(timed(PC_CONF_ATTN, 6.0 * B * e->heads * (double)N * N * e->dh, s, [&] {
-      if (g_conf_attn_mfma && dt != DT_FP32 && e->dh == 36)
+      if (e->conf_attn_mfma && dt != DT_FP32 && e->dh == 36)
         return launch_conf_attn_mfma(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner, K.rel_h, 512, B, N, e->heads,
                                      e->dh, w.ao, Ep, dt, s, w.lens, 1);
       return launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
@@ -1001,7 +1022,7 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     q.out_f = w.qkv32; q.ldo_f = 3 * e->inner;
     KOK(launch_gemm(q, dt, 1, s));
     KOK(timed(PC_CONF_ATTN, 6.0 * B * e->heads * (double)N * N * e->dh, s, [&] {
-      if (g_conf_attn_mfma && dt != DT_FP32 && e->dh == 36)
+      if (e->conf_attn_mfma && dt != DT_FP32 && e->dh == 36)
         return launch_conf_attn_mfma(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner, K.rel_h, 512, B, N, e->heads,
                                      e->dh, w.ao, Ep, dt, s, w.lens, 1);
       return launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
@@ -1042,6 +1063,8 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     return launch_small_linear(w.xc, (long)N * E, B, E, e->F("conformer.fc5.weight"), e->F("conformer.fc5.bias"), 2,
                                logits, s);
   }));
+  if (embedding)  // x[:, 0, :] (models/conformer_baseline.py:27)
+    HIP_OK(hipMemcpy2DAsync(embedding, (size_t)E * 4, w.xc, (size_t)N * E * 4, (size_t)E * 4, B, hipMemcpyDeviceToDevice, s));
   return 0;
 }
 
@@ -1065,8 +1088,9 @@ static int run_head(afx_engine* e, int B, int T, Ws& w, float* logits, hipStream
 #undef launch_gemm
 #undef launch_rownorm
 
-static int check_call(afx_handle h, const void* in, int B, int L, const void* out, void* ws) {
+static int check_call(afx_handle h, const void* in, int B, int L, const void* out, void* ws, bool needs_trunk = false) {
   if (!h || !in || !out || !ws) return fail("afx: null argument");
+  if (needs_trunk && h->cfg.arch == AFX_ARCH_CONFORMER_HEAD) return fail("afx: this handle holds Conformer blocks only (MyConformer); use afx_conformer_forward");
   if (!h->finalized) return fail("afx: weights not finalized (call afx_finalize after afx_load_weight)");
   if (B <= 0 || L <= 0) return fail("afx: empty batch (B=%d, L=%d)", B, L);
   return 0;
@@ -1074,7 +1098,7 @@ static int check_call(afx_handle h, const void* in, int B, int L, const void* ou
 
 extern "C" int afx_forward(afx_handle h, const float* wave, int B, int L, float* logits, void* ws, size_t ws_bytes,
                            void* stream) {
-  if (check_call(h, wave, B, L, logits, ws)) return 1;
+  if (check_call(h, wave, B, L, logits, ws, true)) return 1;
   Ws w;
   const size_t needb = carve(h, B, L, 0, ws, &w);
   if (ws_bytes < needb) return fail("afx_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
@@ -1092,18 +1116,24 @@ extern "C" size_t afx_tail_workspace_bytes(afx_handle h, int B, int T5) {
   Ws w;
   return carve(h, B, 0, 0, nullptr, &w, T5);
 }
-extern "C" int afx_tail_forward(afx_handle h, const void* conv5_h, int B, int T5, float* logits, void* ws, size_t ws_bytes,
-                                void* stream) {
+extern "C" int afx_tail_forward_strided(afx_handle h, const void* conv5_h, long batch_stride, int B, int T5, float* logits,
+                                        void* ws, size_t ws_bytes, void* stream) {
   if (check_call(h, conv5_h, B, T5, logits, ws)) return 1;
-  if (h->cfg.arch == AFX_ARCH_SSL) return fail("afx_tail_forward: this handle has no back-end");
+  if (h->cfg.arch == AFX_ARCH_SSL || h->cfg.arch == AFX_ARCH_CONFORMER_HEAD) return fail("afx_tail_forward: this handle has no trunk + back-end");
+  if (batch_stride != 0 && batch_stride < (long)T5 * kC) return fail("afx_tail_forward_strided: batch stride %ld is shorter than a window (%ld)", batch_stride, (long)T5 * kC);
+  if (batch_stride % 8) return fail("afx_tail_forward_strided: the batch stride must keep rows 16-byte aligned");
   Ws w;
   const size_t needb = carve(h, B, 0, 0, ws, &w, T5);
   if (ws_bytes < needb) return fail("afx_tail_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   if (w.T[6] < 1) return fail("afx_tail_forward: %d conv-layer-5 frames are too few for one output frame", T5);
   hipStream_t s = (hipStream_t)stream;
   t_prof = h->prof;
-  if (run_trunk(h, nullptr, B, 0, w, s, conv5_h)) return 1;
+  if (run_trunk(h, nullptr, B, 0, w, s, conv5_h, batch_stride)) return 1;
   return run_head(h, B, w.T[6], w, logits, s);
+}
+extern "C" int afx_tail_forward(afx_handle h, const void* conv5_h, int B, int T5, float* logits, void* ws, size_t ws_bytes,
+                                void* stream) {
+  return afx_tail_forward_strided(h, conv5_h, 0, B, T5, logits, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1137,7 +1167,7 @@ extern "C" size_t afx_ragged_workspace_bytes(afx_handle h, int B, int Lmax) {
 
 extern "C" int afx_forward_ragged(afx_handle h, const float* wave, int B, int Lmax, const int* n_samples, float* logits,
                                   void* ws, size_t ws_bytes, void* stream) {
-  if (check_call(h, wave, B, Lmax, logits, ws)) return 1;
+  if (check_call(h, wave, B, Lmax, logits, ws, true)) return 1;
   if (!n_samples) return fail("afx_forward_ragged: null lengths");
   if (h->cfg.arch == AFX_ARCH_SSL) return fail("afx_forward_ragged: this handle is an SSL feature extractor; use afx_ssl_forward_ragged");
   if (h->cfg.pre_emphasis) return fail("afx_forward_ragged: engine-side pre-emphasis is not supported on ragged batches");
@@ -1175,7 +1205,7 @@ extern "C" int afx_forward_ragged(afx_handle h, const float* wave, int B, int Lm
 // null) receives the frame counts
 extern "C" int afx_ssl_forward_ragged(afx_handle h, const float* wave, int B, int Lmax, const int* n_samples, float* feats,
                                       int* n_frames, void* ws, size_t ws_bytes, void* stream) {
-  if (check_call(h, wave, B, Lmax, feats, ws)) return 1;
+  if (check_call(h, wave, B, Lmax, feats, ws, true)) return 1;
   if (!n_samples) return fail("afx_ssl_forward_ragged: null lengths");
   if (h->cfg.pre_emphasis) return fail("afx_ssl_forward_ragged: engine-side pre-emphasis is not supported on ragged batches");
   if (h->cfg.extractor_mode == AFX_EXTRACTOR_GROUP_NORM) return fail("afx_ssl_forward_ragged: the group-norm extractor normalises over the whole clip; zero padding would enter its statistics");
@@ -1199,7 +1229,7 @@ extern "C" int afx_ssl_forward_ragged(afx_handle h, const float* wave, int B, in
 
 extern "C" int afx_ssl_forward(afx_handle h, const float* wave, int B, int L, float* feats, void* ws, size_t ws_bytes,
                                void* stream) {
-  if (check_call(h, wave, B, L, feats, ws)) return 1;
+  if (check_call(h, wave, B, L, feats, ws, true)) return 1;
   Ws w;
   const size_t needb = carve(h, B, L, 0, ws, &w);
   if (ws_bytes < needb) return fail("afx_ssl_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
@@ -1226,6 +1256,7 @@ extern "C" int afx_head_forward(afx_handle h, const float* feats, int B, int T, 
                                 size_t ws_bytes, void* stream) {
   if (check_call(h, feats, B, T, logits, ws)) return 1;
   if (h->cfg.arch == AFX_ARCH_SSL) return fail("afx_head_forward: this handle has no back-end");
+  if (h->cfg.arch == AFX_ARCH_CONFORMER_HEAD) return fail("afx_head_forward: this handle holds Conformer blocks only; use afx_conformer_forward");
   Ws w;
   memset(&w, 0, sizeof w);
   const size_t needb = carve(h, B, 0, T, ws, &w);
@@ -1242,6 +1273,21 @@ extern "C" int afx_head_forward(afx_handle h, const float* feats, int B, int T, 
   }
   t_prof = h->prof;
   return run_head(h, B, T, w, logits, s);
+}
+
+// MyConformer.forward alone (models/conformer_baseline.py:22-29): tokens (B,T,emb) fp32 -> class token prepended -> the
+// Conformer blocks -> logits (B,2) = fc5(token 0), embedding (B,emb) = token 0.  Workspace: afx_head_workspace_bytes(h, B, T).
+extern "C" int afx_conformer_forward(afx_handle h, const float* tokens, int B, int T, float* logits, float* embedding,
+                                     void* ws, size_t ws_bytes, void* stream) {
+  if (check_call(h, tokens, B, T, logits, ws)) return 1;
+  if (h->cfg.arch != AFX_ARCH_CONFORMER && h->cfg.arch != AFX_ARCH_CONFORMER_HEAD)
+    return fail("afx_conformer_forward: this handle holds no Conformer blocks");
+  Ws w;
+  memset(&w, 0, sizeof w);
+  const size_t needb = carve(h, B, 0, T, ws, &w);
+  if (ws_bytes < needb) return fail("afx_conformer_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
+  t_prof = h->prof;
+  return run_conformer(h, B, T, w, logits, (hipStream_t)stream, tokens, embedding);
 }
 
 extern "C" size_t afx_head_workspace_bytes(afx_handle h, int B, int T) {
@@ -1292,10 +1338,24 @@ extern "C" int afx_k_pack_linear(int dtype, const float* w, int N, int K, int Kp
 extern "C" int afx_k_pack_conv(int dtype, const float* w, int N, int Cin, int k, void* out_h, void* stream) {
   KRET(launch_pack_conv(w, N, Cin, k, out_h, dtype, (hipStream_t)stream));
 }
+extern "C" size_t afx_k_conv0_pack_bytes(void) { return conv0_pack_bytes(); }
+extern "C" int afx_k_conv0_pack(const float* w, const float* bias, void* pack, void* stream) {
+  if (!w || !bias || !pack) return fail("afx_k_conv0_pack: null argument");
+  KRET(launch_conv0_pack(w, bias, pack, (hipStream_t)stream));
+}
+// pack: the layer's split-precision operand block (afx_k_conv0_pack, built ONCE per checkpoint); asynchronous, allocates nothing
+extern "C" int afx_k_conv0_packed(int dtype, const float* wave, int B, int L, const void* pack, const float* w,
+                                  const float* bias, const float* gamma, const float* beta, int pre_emph, float coef,
+                                  void* out_h, void* stream) {
+  if (dtype != DT_FP32 && !pack) return fail("afx_k_conv0_packed: null pack");
+  KRET(launch_conv0(wave, B, L, (L - 10) / 5 + 1, w, bias, gamma, beta, pre_emph, coef, out_h, dtype, (hipStream_t)stream,
+                    dtype != DT_FP32 ? pack : nullptr));
+}
+// (test hook of round 1: builds the pack per call -- a device allocation and a stream synchronisation; hot paths use
+// afx_k_conv0_pack once + afx_k_conv0_packed)
 extern "C" int afx_k_conv0(int dtype, const float* wave, int B, int L, const float* w, const float* bias,
                            const float* gamma, const float* beta, int pre_emph, float coef, void* out_h,
                            void* stream) {
-  // (test hook: the packed operand the engine prepares once per checkpoint is built here per call)
   void* pack = nullptr;
   if (dtype != DT_FP32) {
     if (hipMalloc(&pack, conv0_pack_bytes()) != hipSuccess) return fail("afx_k_conv0: device allocation failed");
@@ -1379,24 +1439,17 @@ extern "C" int afx_debug_set(const char* key, int value) {
     conv0_set_mfma(value);
     return 0;
   }
-  if (!strcmp(key, "posconv_sliding")) {
-    g_posconv_sliding = value != 0;
-    return 0;
-  }
-  if (!strcmp(key, "conf_attn_mfma")) {
-    g_conf_attn_mfma = value != 0;
-    return 0;
-  }
-  if (!strcmp(key, "fuse_conformer")) {
-    g_fuse_conformer = value != 0;
-    return 0;
-  }
-  if (!strcmp(key, "fuse_conv_ln")) {
-    g_fuse_conv_ln = value != 0;
-    return 0;
-  }
 
   return fail("afx_debug_set: unknown key '%s'", key);
+}
+extern "C" int afx_engine_set(afx_handle h, const char* key, int value) {
+  if (!h || !key) return fail("afx_engine_set: null argument");
+  if (!strcmp(key, "posconv_sliding")) h->posconv_sliding = value != 0;
+  else if (!strcmp(key, "conf_attn_mfma")) h->conf_attn_mfma = value != 0;
+  else if (!strcmp(key, "fuse_conformer")) h->fuse_conformer = value != 0;
+  else if (!strcmp(key, "fuse_conv_ln")) h->fuse_conv_ln = value != 0;
+  else return fail("afx_engine_set: unknown key '%s'", key);
+  return 0;
 }
 extern "C" int afx_k_pre_emphasis(const float* x, int B, int L, float coef, float* y, void* stream) {
   KRET(launch_pre_emphasis(x, B, L, coef, y, (hipStream_t)stream));

@@ -136,8 +136,9 @@ const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dty
 // ---- Conformer student head (afx_conformer.hip) ----------------------------------
 // y = selu(bn(x)) for rows 1..T of each utterance, row 0 = class token; x is the LL
 // output (B*T, E) fp32; out (B*(T+1), E) fp32 residual stream.
+// raw: rows are copied as they are (no BatchNorm / SELU): MyConformer.forward's own input (models/conformer_baseline.py:22-24)
 const char* launch_conf_tokens(const float* ll, const float* cls, float bn_scale, float bn_shift, int B, int T,
-                               int E, float* out, hipStream_t s);
+                               int E, float* out, hipStream_t s, bool raw = false);
 // Shaw relative-position attention; q (B*N, H*dh) fp32, kv (B*N, 2*H*dh) fp32,
 // rel (2*max_pos+1, dh) fp32; out operand-type rows of stride ldo.
 const char* launch_conf_attn(const float* q, long ldq, const float* kv, long ldkv, const float* rel, int max_pos,

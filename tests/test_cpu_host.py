@@ -282,6 +282,38 @@ def test_checkpoint_loader_does_not_execute_pickled_callables(tmp_path):
     assert all(torch.equal(own[k], sd[k]) for k in own)
 
 
+@pytest.mark.parametrize("module,name", [
+    ("torch.serialization", "os.system"),            # dotted name: pickle protocol 4 walks attributes
+    ("torch.storage", "io.open"),
+    ("torch._utils", "_import_dotted_name"),         # a real helper of an allowed module that imports anything
+    ("torch.storage", "_load_from_bytes"),           # torch.load with the default (unrestricted) pickle
+    ("posix", "system"), ("builtins", "eval"), ("builtins", "getattr"),
+])
+def test_checkpoint_loader_allow_list_has_no_attribute_walk(tmp_path, module, name):
+    """ADVICE round 2 (high): the allow-list is exact (module, name) pairs resolved with one dict lookup on the module;
+    a crafted 40-byte file that names a callable reachable THROUGH an allowed module must not run it."""
+    from afx import host
+    marker = tmp_path / "pwned"
+    arg = f"touch {marker}" if "system" in name else ("open('%s','w')" % marker if name == "eval" else str(marker))
+
+    def u(s):
+        b = s.encode()
+        return b"\x8c" + bytes([len(b)]) + b
+    payload = b"\x80\x04" + u(module) + u(name) + b"\x93" + u(arg) + b"\x85R."  # STACK_GLOBAL, TUPLE1, REDUCE, STOP
+    assert host._StubPickle._resolve(module, name) is None
+    path = tmp_path / "crafted.pt"
+    path.write_bytes(payload)
+    with pytest.raises(Exception):
+        host.load_ssl_checkpoint(host.Wav2Vec2Trunk(n_layers=1), str(path))
+    assert not marker.exists()
+    # what a real checkpoint needs still resolves to the real objects
+    import collections
+    assert host._StubPickle._resolve("collections", "OrderedDict") is collections.OrderedDict
+    assert host._StubPickle._resolve("torch._utils", "_rebuild_tensor_v2") is torch._utils._rebuild_tensor_v2
+    assert host._StubPickle._resolve("torch", "float16") is torch.float16
+    assert host._StubPickle._resolve("torch", "FloatStorage") is torch.FloatStorage
+
+
 def test_track_routing_and_checkpoint_sweep_like_main(tmp_path):
     """main.py:258-371,406-451: track loop (skip existing score files, comment suffix, InTheWild path derived from
     DF21's) and the --score_all_folder_path sweep (every *.pt, 'module.'-prefixed or not, comment from the file name)."""

@@ -118,6 +118,40 @@ def test_conformer_head_alone_and_small_kernel_size(afx_mod):
     assert (got - ref).abs().max().item() <= SCORE_TOL
 
 
+def test_myconformer_forward_alone(afx_mod):
+    """models/conformer_baseline.py:22-29: ``MyConformer.forward(x)`` as a module of its own -- class token, the cloned
+    Conformer blocks, ``(fc5(token 0), token 0)`` -- through afx_conformer_forward, against the oracle's restatement of
+    the same lines; and the same call on the Conformer blocks of a full student (``model.conformer(tokens)``)."""
+    engine, synth = afx_mod
+    from models.conformer_baseline import MyConformer, MyModel
+    from oracle import conformer as oconf
+    head = synth.conformer_head_state_dict(emb_size=144, heads=4, kernel_size=31, n_encoders=2)
+    own = {k[len("conformer."):]: v for k, v in head.items() if k.startswith("conformer.")}
+    m = MyConformer(emb_size=144, heads=4, kernel_size=31, n_encoders=2).to("cuda").eval()
+    m.load_state_dict(own)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 49, 144, generator=g)
+    ref_out, ref_emb = oconf.my_conformer(own, x, heads=4, prefix="")
+    with torch.no_grad():
+        out, emb = m(x.cuda())
+    assert out.shape == (3, 2) and emb.shape == (3, 144)
+    assert (out.cpu() - ref_out).abs().max().item() <= SCORE_TOL
+    assert rel_l2(emb, ref_emb) < 3e-3
+    with torch.no_grad():
+        out2, _ = m(x.cuda(), "cuda")  # the stray positional argument of MyModel.forward's call (:98, SURVEY Q4)
+    assert torch.equal(out2, out)
+    with pytest.raises(ValueError, match="tokens"):
+        m(torch.zeros(2, 10, 100, device="cuda"))
+    with pytest.raises(RuntimeError, match="eval"):
+        m.train()(x.cuda())
+    # the blocks inside a whole model, called on their own like the reference's `self.conformer(x)` (:63)
+    full = MyModel(device="cuda", ssl_cpkt_path=None, num_layers=1, order="first", n_encoders=2).to("cuda").eval()
+    full.conformer.load_state_dict(own)
+    with torch.no_grad():
+        o3, e3 = full.conformer(x.cuda())
+    assert torch.equal(o3, out) and torch.equal(e3, emb)
+
+
 def test_errors_are_loud(afx_mod):
     engine, synth = afx_mod
     from afx._lib import AfxError
@@ -449,6 +483,13 @@ def test_kd_forward_hooks_by_module_path(afx_mod):
     with torch.no_grad():
         stu(wave.cuda())
     assert mgr.pop_io_dict() == {}
+    # clear() switched the engine's taps off again: the forward above kept no fp32 copies, so the forward is capturable
+    # and a tap refreshed by it would have changed -- the "ssl" tap still holds the hooked forward's values
+    wave2 = synth.waveforms(2, 16000, batch_idx=42)
+    before = stu._afx_engine().tap("ssl").clone()
+    with torch.no_grad():
+        stu(wave2.cuda())
+    assert torch.equal(stu._afx_engine().tap("ssl"), before)
 
 
 def test_checkpoint_files_through_the_gpu_path(afx_mod, tmp_path):
