@@ -38,7 +38,10 @@ enum { AFX_ARCH_SSL = 0, AFX_ARCH_XLSR_AASIST = 1, AFX_ARCH_CONFORMER = 2,
        AFX_ARCH_CONFORMER_HEAD = 3 /* MyConformer alone (models/conformer_baseline.py:8-29): class token, Conformer blocks, fc5; no trunk */ };
 enum { AFX_EXTRACTOR_LAYER_NORM = 0, /* XLS-R: every conv layer conv+bias -> LayerNorm(512) -> GELU (what the reference loads) */
        AFX_EXTRACTOR_GROUP_NORM = 1  /* wav2vec2-base: bias-free convs, GroupNorm(512,512) on layer 0 only, GELU */ };
-enum { AFX_DT_BF16 = 0, AFX_DT_FP16 = 1, AFX_DT_FP32 = 2 }; /* operand type (FP32: exact mode, fp32 MFMA); accumulation is always fp32 */
+enum { AFX_DT_BF16 = 0, AFX_DT_FP16 = 1, AFX_DT_FP32 = 2, /* operand type (FP32: exact mode, fp32 MFMA); accumulation is always fp32 */
+       AFX_DT_FP16X3 = 3 /* split precision: activations, LayerNorms, attention in fp32 as in exact mode; every dense product on
+                            the fp16 matrix pipe as xh.wh + xl.wh + xh.wl (fp16 hi / lo pairs of both operands, ~22 significant
+                            bits): the unconditional-parity mode at ~1/3 of the fp16 rate instead of 1/16 */ };
 
 typedef struct afx_config {
   int arch;          /* AFX_ARCH_* */

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AFX_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libafx.so")
 
 ARCH_SSL, ARCH_XLSR_AASIST, ARCH_CONFORMER, ARCH_CONFORMER_HEAD = 0, 1, 2, 3
-DT_BF16, DT_FP16, DT_FP32 = 0, 1, 2
+DT_BF16, DT_FP16, DT_FP32, DT_FP16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_SWISH, ACT_SELU = 0, 1, 2, 3
 
 

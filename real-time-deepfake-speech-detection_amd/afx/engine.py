@@ -11,18 +11,20 @@ from ._lib import AfxError, Config, check, lib, ptr, stream_ptr
 
 ARCHS = {"ssl": _lib.ARCH_SSL, "xlsr_aasist": _lib.ARCH_XLSR_AASIST, "conformer": _lib.ARCH_CONFORMER,
          "conformer_head": _lib.ARCH_CONFORMER_HEAD}  # conformer_head: MyConformer alone (no trunk)
-DTYPES = {"bf16": _lib.DT_BF16, "fp16": _lib.DT_FP16, "fp32": _lib.DT_FP32}
+DTYPES = {"bf16": _lib.DT_BF16, "fp16": _lib.DT_FP16, "fp32": _lib.DT_FP32, "fp16x3": _lib.DT_FP16X3}
 # fairseq extractor_mode: "layer_norm" = XLS-R (what the reference loads), "group_norm" = wav2vec2-base ("default")
 EXTRACTORS = {"layer_norm": 0, "group_norm": 1, "default": 1}
 # fp16 and bf16 run at the same matrix-core rate on gfx950; fp16's 3 extra mantissa bits
 # are what keeps the scores within 1e-3 of the fp32 reference (DESIGN.md "Numerics").
 # "fp32" is the exact mode: fp32 operands on the fp32 matrix instruction, 1/16 of the rate,
 # no reduced-precision rounding anywhere -- for parity work, not for throughput.
+# "fp16x3" is split precision: fp32 activations as in exact mode, every dense product as three fp16 matrix-core products
+# of hi / lo operand pairs (~22 significant bits) -- the unconditional-parity mode at about a third of the fp16 rate.
 DEFAULT_DTYPE = "fp16"  # (no environment override: a stray variable must not change what a product run computes)
 
 
 def torch_dtype(name):
-    return {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[name]
+    return {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "fp16x3": torch.float32}[name]
 
 
 def _cuda_device(device):

@@ -227,7 +227,8 @@ class AfxModule(nn.Module):
         return eng.ssl_ragged(clips) if self.afx_arch == "ssl" else eng.forward_ragged(clips)
 
     def set_precision(self, dtype):
-        """'fp16' (default) or 'bf16' matrix-core operands."""
+        """'fp16' (default) or 'bf16' matrix-core operands; 'fp16x3' (split precision, fp32-accurate, ~1/3 of the rate) or
+        'fp32' (exact mode, 1/16) where every score must hold the tolerance whatever the checkpoint's top-k gaps."""
         self.__dict__["afx_dtype"] = dtype
         return self
 

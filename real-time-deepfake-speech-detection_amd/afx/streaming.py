@@ -93,7 +93,7 @@ class IncrementalScorer(SlidingWindowScorer):
         super().__init__(engine, n_streams, window, hop, device=engine.device)
         if hop % 160 or window % hop:
             raise ValueError("exact reuse needs hop % 160 == 0 (the stride of conv layer 5) and window % hop == 0")
-        if engine.dtype == "fp32":
+        if engine.dtype in ("fp32", "fp16x3"):
             raise ValueError("the incremental scorer runs the half-precision conv kernels (fp16 / bf16 engines)")
         if getattr(engine, "extractor_mode", "layer_norm") != "layer_norm":
             raise ValueError("the group-norm extractor normalises layer 0 over the whole window: nothing is reusable")

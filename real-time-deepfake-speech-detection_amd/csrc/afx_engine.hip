@@ -100,6 +100,7 @@ struct Profiler;  // per-engine launch timing (below)
 
 struct afx_engine {
   afx_config cfg;
+  bool s3 = false;  // split precision (AFX_DT_FP16X3): dt == DT_FP32 for every kernel but the dense products
   Profiler* prof = nullptr;  // owned; no process-wide map: two engines on two host threads share nothing
   int dt;
   size_t hsz;  // bytes per operand element
@@ -131,6 +132,9 @@ struct afx_engine {
   // AASIST head
   AasistWeights aw;
 
+  // a packed weight matrix [rows][k] (+, in split precision, its per-row scales behind it: wscale())
+  void* walloc(size_t rows, size_t k) { return dalloc(rows * k * hsz + (s3 ? rows * 4 : 0)); }
+  float* wscale(const void* w, size_t rows, size_t k) const { return s3 ? (float*)((char*)w + rows * k * 4) : nullptr; }
   void* dalloc(size_t bytes) {
     void* p = nullptr;
     if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
@@ -155,7 +159,8 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
   const bool head_only = cfg->arch == AFX_ARCH_CONFORMER_HEAD;  // MyConformer alone: no trunk in this handle
   if (!head_only && (cfg->n_layers < 1 || cfg->n_layers > 24))
     return fail("Number of layers must be at least 1 and at most 24.");  // models/fe.py:60-62
-  if (cfg->dtype != AFX_DT_BF16 && cfg->dtype != AFX_DT_FP16 && cfg->dtype != AFX_DT_FP32) return fail("afx_create: unknown dtype %d", cfg->dtype);
+  if (cfg->dtype != AFX_DT_BF16 && cfg->dtype != AFX_DT_FP16 && cfg->dtype != AFX_DT_FP32 && cfg->dtype != AFX_DT_FP16X3)
+    return fail("afx_create: unknown dtype %d", cfg->dtype);
   if (cfg->arch < AFX_ARCH_SSL || cfg->arch > AFX_ARCH_CONFORMER_HEAD) return fail("afx_create: unknown arch %d", cfg->arch);
   if (cfg->extractor_mode != AFX_EXTRACTOR_LAYER_NORM && cfg->extractor_mode != AFX_EXTRACTOR_GROUP_NORM)
     return fail("afx_create: unknown extractor_mode %d", cfg->extractor_mode);
@@ -166,8 +171,11 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
     return fail("afx_create: no HIP device visible -- this library has no CPU fallback");
   afx_engine* e = new afx_engine();
   e->cfg = *cfg;
-  e->dt = cfg->dtype;
-  e->hsz = dtype_size(cfg->dtype);
+  // split precision: activations and every non-GEMM kernel as in exact mode (fp32); the dense products on the fp16 matrix
+  // pipe with hi / lo operand pairs (P_gemm below).  A weight element is 4 bytes either way (fp32, or an fp16 hi + lo pair).
+  e->s3 = cfg->dtype == AFX_DT_FP16X3;
+  e->dt = e->s3 ? (int)DT_FP32 : cfg->dtype;
+  e->hsz = dtype_size(e->dt);
   const int nl = head_only ? 0 : cfg->n_layers;
   e->cfg.n_layers = nl;
   e->wqkv.assign(nl, nullptr);
@@ -177,16 +185,16 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
   e->bqkv.assign(nl, nullptr);
   bool ok = true;
   if (!head_only) {
-    for (int i = 1; i < 7; ++i) ok &= (e->convw[i] = e->dalloc((size_t)kC * kC * kConvK[i] * e->hsz)) != nullptr;
-    ok &= (e->projw = e->dalloc((size_t)kD * kC * e->hsz)) != nullptr;
-    ok &= (e->posw = e->dalloc((size_t)kD * (kD / kPosG) * kPosK * e->hsz)) != nullptr;
+    for (int i = 1; i < 7; ++i) ok &= (e->convw[i] = e->walloc(kC, (size_t)kC * kConvK[i])) != nullptr;
+    ok &= (e->projw = e->walloc(kD, kC)) != nullptr;
+    ok &= (e->posw = e->walloc(kD, (size_t)(kD / kPosG) * kPosK)) != nullptr;
     ok &= (e->pos_norm = (float*)e->dalloc(kPosK * 4)) != nullptr;
   }
   for (int l = 0; l < nl && ok; ++l) {
-    ok &= (e->wqkv[l] = e->dalloc((size_t)3 * kD * kD * e->hsz)) != nullptr;
-    ok &= (e->wo[l] = e->dalloc((size_t)kD * kD * e->hsz)) != nullptr;
-    ok &= (e->w1[l] = e->dalloc((size_t)kF * kD * e->hsz)) != nullptr;
-    ok &= (e->w2[l] = e->dalloc((size_t)kD * kF * e->hsz)) != nullptr;
+    ok &= (e->wqkv[l] = e->walloc(3 * kD, kD)) != nullptr;
+    ok &= (e->wo[l] = e->walloc(kD, kD)) != nullptr;
+    ok &= (e->w1[l] = e->walloc(kF, kD)) != nullptr;
+    ok &= (e->w2[l] = e->walloc(kD, kF)) != nullptr;
     ok &= (e->bqkv[l] = (float*)e->dalloc((size_t)3 * kD * 4)) != nullptr;
   }
   if (cfg->arch == AFX_ARCH_CONFORMER || head_only) {
@@ -206,18 +214,18 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
     e->FFp = round_up(e->FF, 64);
     e->C2 = 2 * e->E;
     e->C2p = round_up(e->C2, 64);
-    if (!head_only) ok &= (e->conf_ll = e->dalloc((size_t)e->E * kD * e->hsz)) != nullptr;
+    if (!head_only) ok &= (e->conf_ll = e->walloc(e->E, kD)) != nullptr;
     e->blk.resize(e->nblk);
     for (int b = 0; b < e->nblk && ok; ++b) {
       ConfBlock& B = e->blk[b];
-      ok &= (B.ff1_w1 = e->dalloc((size_t)e->FF * e->Ep * e->hsz)) != nullptr;
-      ok &= (B.ff1_w2 = e->dalloc((size_t)e->E * e->FFp * e->hsz)) != nullptr;
-      ok &= (B.ff2_w1 = e->dalloc((size_t)e->FF * e->Ep * e->hsz)) != nullptr;
-      ok &= (B.ff2_w2 = e->dalloc((size_t)e->E * e->FFp * e->hsz)) != nullptr;
-      ok &= (B.wqkv = e->dalloc((size_t)3 * e->inner * e->Ep * e->hsz)) != nullptr;
-      ok &= (B.wout = e->dalloc((size_t)e->E * e->Ep * e->hsz)) != nullptr;
-      ok &= (B.pw1 = e->dalloc((size_t)2 * e->C2 * e->Ep * e->hsz)) != nullptr;
-      ok &= (B.pw2 = e->dalloc((size_t)e->E * e->C2p * e->hsz)) != nullptr;
+      ok &= (B.ff1_w1 = e->walloc(e->FF, e->Ep)) != nullptr;
+      ok &= (B.ff1_w2 = e->walloc(e->E, e->FFp)) != nullptr;
+      ok &= (B.ff2_w1 = e->walloc(e->FF, e->Ep)) != nullptr;
+      ok &= (B.ff2_w2 = e->walloc(e->E, e->FFp)) != nullptr;
+      ok &= (B.wqkv = e->walloc(3 * e->inner, e->Ep)) != nullptr;
+      ok &= (B.wout = e->walloc(e->E, e->Ep)) != nullptr;
+      ok &= (B.pw1 = e->walloc(2 * e->C2, e->Ep)) != nullptr;
+      ok &= (B.pw2 = e->walloc(e->E, e->C2p)) != nullptr;
       ok &= (B.bn_scale = (float*)e->dalloc((size_t)e->C2 * 4)) != nullptr;
       ok &= (B.bn_shift = (float*)e->dalloc((size_t)e->C2 * 4)) != nullptr;
       for (int st = 0; st < 3; ++st) ok &= (B.chain_prm[st] = (float*)e->dalloc(kChainParamFloats * 4)) != nullptr;
@@ -286,6 +294,12 @@ static int store_raw(afx_engine* e, const std::string& key, const float* src, co
   return 0;
 }
 
+// pack a weight into the engine's operand form; split precision: fp32 rows first, then hi / lo pairs + row scales in place
+static const char* pack_linear(afx_engine* e, const float* src, int N, int K, int Kpad, void* dst, float* scale, hipStream_t s) {
+  if (const char* m = launch_pack_linear(src, N, K, Kpad, dst, e->dt, s)) return m;
+  return e->s3 ? launch_split_weight_rows(dst, N, Kpad, scale, s) : nullptr;
+}
+
 // trunk tensor (name without the "ssl_model.model." prefix)
 static int load_ssl(afx_engine* e, const std::string& k, const float* src, const int64_t* shape, int ndim,
                     hipStream_t s) {
@@ -299,11 +313,12 @@ static int load_ssl(afx_engine* e, const std::string& k, const float* src, const
     }
     if (expect_shape(k.c_str(), shape, ndim, {kC, kC, kConvK[i]})) return 1;
     KOK(launch_pack_conv(src, kC, kC, kConvK[i], e->convw[i], e->dt, s));
+    if (e->s3) KOK(launch_split_weight_rows(e->convw[i], kC, kC * kConvK[i], e->wscale(e->convw[i], kC, (size_t)kC * kConvK[i]), s));
     return 0;
   }
   if (k == "post_extract_proj.weight") {
     if (expect_shape(k.c_str(), shape, ndim, {kD, kC})) return 1;
-    KOK(launch_pack_linear(src, kD, kC, kC, e->projw, e->dt, s));
+    KOK(pack_linear(e, src, kD, kC, kC, e->projw, e->wscale(e->projw, kD, kC), s));
     return 0;
   }
   if (sscanf(k.c_str(), "encoder.layers.%d.%95s", &n, tail) == 2) {
@@ -314,7 +329,8 @@ static int load_ssl(afx_engine* e, const std::string& k, const float* src, const
     for (int j = 0; j < 3; ++j) {
       if (t == std::string(proj[j]) + "weight") {
         if (expect_shape(k.c_str(), shape, ndim, {kD, kD})) return 1;
-        KOK(launch_pack_linear(src, kD, kD, kD, (char*)e->wqkv[n] + (size_t)j * kD * kD * e->hsz, e->dt, s));
+        KOK(pack_linear(e, src, kD, kD, kD, (char*)e->wqkv[n] + (size_t)j * kD * kD * e->hsz,
+                        e->s3 ? e->wscale(e->wqkv[n], 3 * kD, kD) + j * kD : nullptr, s));
         return 0;
       }
       if (t == std::string(proj[j]) + "bias") {
@@ -325,17 +341,17 @@ static int load_ssl(afx_engine* e, const std::string& k, const float* src, const
     }
     if (t == "self_attn.out_proj.weight") {
       if (expect_shape(k.c_str(), shape, ndim, {kD, kD})) return 1;
-      KOK(launch_pack_linear(src, kD, kD, kD, e->wo[n], e->dt, s));
+      KOK(pack_linear(e, src, kD, kD, kD, e->wo[n], e->wscale(e->wo[n], kD, kD), s));
       return 0;
     }
     if (t == "fc1.weight") {
       if (expect_shape(k.c_str(), shape, ndim, {kF, kD})) return 1;
-      KOK(launch_pack_linear(src, kF, kD, kD, e->w1[n], e->dt, s));
+      KOK(pack_linear(e, src, kF, kD, kD, e->w1[n], e->wscale(e->w1[n], kF, kD), s));
       return 0;
     }
     if (t == "fc2.weight") {
       if (expect_shape(k.c_str(), shape, ndim, {kD, kF})) return 1;
-      KOK(launch_pack_linear(src, kD, kF, kF, e->w2[n], e->dt, s));
+      KOK(pack_linear(e, src, kD, kF, kF, e->w2[n], e->wscale(e->w2[n], kD, kF), s));
       return 0;
     }
     return store_raw(e, "ssl." + k, src, shape, ndim, s);
@@ -352,7 +368,7 @@ static int load_conformer(afx_engine* e, const std::string& k, const float* src,
   const int E = e->E, Ep = e->Ep;
   if (k == "LL.weight") {
     if (expect_shape(k.c_str(), shape, ndim, {E, kD})) return 1;
-    KOK(launch_pack_linear(src, E, kD, kD, e->conf_ll, e->dt, s));
+    KOK(pack_linear(e, src, E, kD, kD, e->conf_ll, e->wscale(e->conf_ll, E, kD), s));
     return 0;
   }
   int b = 0;
@@ -361,18 +377,22 @@ static int load_conformer(afx_engine* e, const std::string& k, const float* src,
     if (b < 0 || b >= e->nblk) return fail("afx_load_weight: Conformer block %d out of range (n_encoders=%d)", b, e->nblk);
     ConfBlock& B = e->blk[b];
     const std::string t = tail;
-    struct { const char* name; void* dst; int N, K, Kp; } lin[] = {
-        {"ff1.fn.fn.net.0.weight", B.ff1_w1, e->FF, E, Ep},   {"ff1.fn.fn.net.3.weight", B.ff1_w2, E, e->FF, e->FFp},
-        {"ff2.fn.fn.net.0.weight", B.ff2_w1, e->FF, E, Ep},   {"ff2.fn.fn.net.3.weight", B.ff2_w2, E, e->FF, e->FFp},
-        {"attn.fn.to_q.weight", B.wqkv, e->inner, E, Ep},
-        {"attn.fn.to_kv.weight", (char*)B.wqkv + (size_t)e->inner * Ep * e->hsz, 2 * e->inner, E, Ep},
-        {"attn.fn.to_out.weight", B.wout, E, e->inner, Ep},   {"conv.net.2.weight", B.pw1, 2 * e->C2, E, Ep},
-        {"conv.net.7.weight", B.pw2, E, e->C2, e->C2p},
+    float* qkv_sc = e->wscale(B.wqkv, 3 * e->inner, Ep);
+    struct { const char* name; void* dst; int N, K, Kp; float* sc; } lin[] = {
+        {"ff1.fn.fn.net.0.weight", B.ff1_w1, e->FF, E, Ep, e->wscale(B.ff1_w1, e->FF, Ep)},
+        {"ff1.fn.fn.net.3.weight", B.ff1_w2, E, e->FF, e->FFp, e->wscale(B.ff1_w2, E, e->FFp)},
+        {"ff2.fn.fn.net.0.weight", B.ff2_w1, e->FF, E, Ep, e->wscale(B.ff2_w1, e->FF, Ep)},
+        {"ff2.fn.fn.net.3.weight", B.ff2_w2, E, e->FF, e->FFp, e->wscale(B.ff2_w2, E, e->FFp)},
+        {"attn.fn.to_q.weight", B.wqkv, e->inner, E, Ep, qkv_sc},
+        {"attn.fn.to_kv.weight", (char*)B.wqkv + (size_t)e->inner * Ep * e->hsz, 2 * e->inner, E, Ep, qkv_sc ? qkv_sc + e->inner : nullptr},
+        {"attn.fn.to_out.weight", B.wout, E, e->inner, Ep, e->wscale(B.wout, E, Ep)},
+        {"conv.net.2.weight", B.pw1, 2 * e->C2, E, Ep, e->wscale(B.pw1, 2 * e->C2, Ep)},
+        {"conv.net.7.weight", B.pw2, E, e->C2, e->C2p, e->wscale(B.pw2, E, e->C2p)},
     };
     for (auto& L : lin)
       if (t == L.name) {
         if (expect_shape(k.c_str(), shape, ndim, {L.N, L.K})) return 1;
-        KOK(launch_pack_linear(src, L.N, L.K, L.Kp, L.dst, e->dt, s));
+        KOK(pack_linear(e, src, L.N, L.K, L.Kp, L.dst, L.sc, s));
         return 0;
       }
   }
@@ -460,6 +480,7 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
     } else {
       return fail("afx_finalize: missing weight '%sencoder.pos_conv.0.weight_g/weight_v'", P.c_str());
     }
+    if (h->s3) KOK(launch_split_weight_rows(h->posw, kD, (kD / kPosG) * kPosK, h->wscale(h->posw, kD, (size_t)(kD / kPosG) * kPosK), s));
   }
   if (h->cfg.arch == AFX_ARCH_CONFORMER || head_only) {
     for (const char* k : {"LL.weight", "LL.bias", "first_bn.weight", "first_bn.bias", "first_bn.running_mean",
@@ -518,7 +539,7 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
     h->conf_bn_scale = w / sqrtf(v + kBnEps);
     h->conf_bn_shift = b - m * h->conf_bn_scale;
   } else if (h->cfg.arch == AFX_ARCH_XLSR_AASIST) {
-    h->aw.split = h->dt != AFX_DT_FP32;  // exact mode keeps the true-fp32 matrix instruction
+    h->aw.split = h->s3 || h->dt != AFX_DT_FP32;  // exact mode keeps the true-fp32 matrix instruction
     if (const char* m = aasist_finalize(
             h->aw, [&](const std::string& k) { return h->F(k); }, [&](size_t bytes) { return h->dalloc(bytes); }, s))
       return fail("afx_finalize: %s", m);
@@ -532,9 +553,10 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
 // ---------------------------------------------------------------------------------
 struct Carver {
   char* base;
-  size_t off = 0;
+  size_t off = 0, largest = 0;
   explicit Carver(void* b) : base((char*)b) {}
   void* take(size_t bytes) {
+    if (bytes > largest) largest = bytes;
     off = (off + 255) & ~(size_t)255;
     void* p = base ? base + off : nullptr;
     off += bytes;
@@ -546,6 +568,8 @@ struct Ws {
   int T[7];
   void *bufA, *bufB, *feats_h, *xpad, *hbuf, *qkv, *att, *ff, *ssl_h;
   float *tmp32, *x, *ssl_f;
+  void* s3planes = nullptr;   // split precision: the hi / lo fp16 planes of the current product's A operand
+  size_t s3bytes = 0;
   float* gn_stats = nullptr;  // group-norm extractor mode: partial sums + mean / rstd of conv layer 0
   // ragged batch (afx_forward_ragged): valid SSL frames per utterance on the device (null = uniform batch), and the
   // AASIST bucket buffers (utterances of equal length gathered into a uniform sub-batch for the graph back-end)
@@ -611,6 +635,14 @@ static size_t carve(const afx_engine* e, int B, int L, int Tfeat, void* base, Ws
     w->u = c.take(M * e->C2p * hs);
   } else if (e->cfg.arch == AFX_ARCH_XLSR_AASIST) {
     aasist_carve(B, T, [&](size_t bytes) { return c.take(bytes); }, &w->aa);
+  }
+  w->s3planes = nullptr;
+  w->s3bytes = 0;
+  if (e->s3) {  // two fp16 planes of the largest operand = the bytes of its fp32 form (+ the plane alignment)
+    size_t big = c.largest;
+    if (T5 > 0 && (size_t)B * T5 * kC * 4 > big) big = (size_t)B * T5 * kC * 4;  // (tail mode: the caller's layer-5 frames)
+    w->s3bytes = big + 4096;
+    w->s3planes = c.take(w->s3bytes);
   }
   return c.off + 256;
 }
@@ -697,6 +729,9 @@ struct Profiler {
   }
 };
 static thread_local Profiler* t_prof = nullptr;  // the profiler of the engine whose forward runs on this thread
+// split precision: the plane scratch of the workspace the forward on this thread runs in (null: another mode)
+static thread_local void* t_s3planes = nullptr;
+static thread_local size_t t_s3bytes = 0;
 static void prof_forget(afx_engine* e) {
   if (!e->prof) return;
   for (hipEvent_t ev : e->prof->pool) (void)hipEventDestroy(ev);
@@ -716,9 +751,37 @@ static const char* timed(int cls, double flops, hipStream_t s, F&& f) {
   p->recs.push_back({cls, a, b, flops});
   return m;
 }
+// Split precision (P_gemm below): x.w ~ xh.wh + xl.wh + xh.wl on the fp16 matrix pipe.  The fp32 A operand (the span of it
+// the product addresses) is split into two fp16 planes, the weight is already stored as [hi | lo] rows with per-row scales
+// (pack_linear), and ONE launch walks K three times: K' = 3 K (GemmArgs::k1).
 static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) {
   const double fl = 2.0 * g.M * g.N * (g.k_algo ? g.k_algo : g.K) * groups;
   static const int cls[9] = {PC_GEMM128, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM256, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN};
+  if (dt == DT_FP32 && t_s3planes) {
+    if (g.K % 64 || g.kchunk % 64) return launch_gemm(g, DT_FP32, groups, s);  // (a K the fp16 tiles cannot walk: the fp32 instruction)
+    GemmArgs q = g;
+    int tile = 0;
+    {
+      // build the split-precision arguments (the split itself is timed as its own launch)
+      const long last = g.M - 1;
+      const long span = (last / g.rpb) * g.a_batch + (last % g.rpb) * g.a_row + (long)(g.K / g.kchunk - 1) * g.kchunk_stride + g.kchunk +
+                        (long)(groups - 1) * g.g_a;
+      const long plane = (span + 63) & ~63L;
+      if ((size_t)plane * 4 > t_s3bytes) return "split-precision product: the A operand exceeds the plane scratch";
+      if (const char* m = timed(PC_MISC, 0, s, [&] { return launch_split_planes((const float*)g.A, span, t_s3planes, plane, s); })) return m;
+      q.A = t_s3planes;
+      q.k1 = g.K;
+      q.K = 3 * g.K;
+      if (!q.k_algo) q.k_algo = g.K;
+      q.a_plane = plane;
+      q.w_plane = g.ldw;
+      q.ldw = 2 * g.ldw;   // W is addressed in halfs: fp32 [N][ldw] became fp16 [N][hi ldw | lo ldw]
+      q.g_w = 2 * g.g_w;
+      q.pre_scale = (const float*)((const char*)g.W + (size_t)groups * g.N * g.ldw * 4);  // afx_engine::wscale
+      tile = gemm_tile_of(q, groups);
+    }
+    return timed(cls[tile], fl, s, [&] { return launch_gemm(q, DT_FP16X3, groups, s); });
+  }
   return timed(dt == DT_FP32 ? PC_GEMM_F32 : cls[gemm_tile_of(g, groups)], fl, s, [&] { return launch_gemm(g, dt, groups, s); });
 }
 static const char* P_rownorm(const RowNormArgs& a, int dt, hipStream_t s) {
@@ -1104,6 +1167,8 @@ extern "C" int afx_forward(afx_handle h, const float* wave, int B, int L, float*
   if (ws_bytes < needb) return fail("afx_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   hipStream_t s = (hipStream_t)stream;
   t_prof = h->prof;
+  t_s3planes = w.s3planes;
+  t_s3bytes = w.s3bytes;
   if (run_trunk(h, wave, B, L, w, s)) return 1;
   return run_head(h, B, w.T[6], w, logits, s);
 }
@@ -1122,12 +1187,15 @@ extern "C" int afx_tail_forward_strided(afx_handle h, const void* conv5_h, long 
   if (h->cfg.arch == AFX_ARCH_SSL || h->cfg.arch == AFX_ARCH_CONFORMER_HEAD) return fail("afx_tail_forward: this handle has no trunk + back-end");
   if (batch_stride != 0 && batch_stride < (long)T5 * kC) return fail("afx_tail_forward_strided: batch stride %ld is shorter than a window (%ld)", batch_stride, (long)T5 * kC);
   if (batch_stride % 8) return fail("afx_tail_forward_strided: the batch stride must keep rows 16-byte aligned");
+  if (h->s3 && batch_stride != 0 && batch_stride != (long)T5 * kC) return fail("afx_tail_forward_strided: split precision reads a packed window");
   Ws w;
   const size_t needb = carve(h, B, 0, 0, ws, &w, T5);
   if (ws_bytes < needb) return fail("afx_tail_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   if (w.T[6] < 1) return fail("afx_tail_forward: %d conv-layer-5 frames are too few for one output frame", T5);
   hipStream_t s = (hipStream_t)stream;
   t_prof = h->prof;
+  t_s3planes = w.s3planes;
+  t_s3bytes = w.s3bytes;
   if (run_trunk(h, nullptr, B, 0, w, s, conv5_h, batch_stride)) return 1;
   return run_head(h, B, w.T[6], w, logits, s);
 }
@@ -1179,6 +1247,8 @@ extern "C" int afx_forward_ragged(afx_handle h, const float* wave, int B, int Lm
   std::vector<int> frames;
   if (ragged_setup(h, B, Lmax, n_samples, w, frames, s)) return 1;
   t_prof = h->prof;
+  t_s3planes = w.s3planes;
+  t_s3bytes = w.s3bytes;
   if (run_trunk(h, wave, B, Lmax, w, s)) return 1;
   const int Tmax = w.T[6];
   if (h->cfg.arch == AFX_ARCH_CONFORMER) return run_head(h, B, Tmax, w, logits, s);
@@ -1216,6 +1286,8 @@ extern "C" int afx_ssl_forward_ragged(afx_handle h, const float* wave, int B, in
   std::vector<int> frames;
   if (ragged_setup(h, B, Lmax, n_samples, w, frames, s)) return 1;
   t_prof = h->prof;
+  t_s3planes = w.s3planes;
+  t_s3bytes = w.s3bytes;
   if (run_trunk(h, wave, B, Lmax, w, s)) return 1;
   const int Tmax = w.T[6];
   HIP_OK(hipMemcpyAsync(feats, w.ssl_f, (size_t)B * Tmax * kD * 4, hipMemcpyDeviceToDevice, s));
@@ -1235,6 +1307,8 @@ extern "C" int afx_ssl_forward(afx_handle h, const float* wave, int B, int L, fl
   if (ws_bytes < needb) return fail("afx_ssl_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   hipStream_t s = (hipStream_t)stream;
   t_prof = h->prof;
+  t_s3planes = w.s3planes;
+  t_s3bytes = w.s3bytes;
   if (run_trunk(h, wave, B, L, w, s)) return 1;
   HIP_OK(hipMemcpyAsync(feats, w.ssl_f, (size_t)B * w.T[6] * kD * 4, hipMemcpyDeviceToDevice, s));
   return 0;
@@ -1272,6 +1346,8 @@ extern "C" int afx_head_forward(afx_handle h, const float* feats, int B, int T, 
     HIP_OK(hipGetLastError());
   }
   t_prof = h->prof;
+  t_s3planes = w.s3planes;
+  t_s3bytes = w.s3bytes;
   return run_head(h, B, T, w, logits, s);
 }
 
@@ -1287,6 +1363,8 @@ extern "C" int afx_conformer_forward(afx_handle h, const float* tokens, int B, i
   const size_t needb = carve(h, B, 0, T, ws, &w);
   if (ws_bytes < needb) return fail("afx_conformer_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   t_prof = h->prof;
+  t_s3planes = w.s3planes;
+  t_s3bytes = w.s3bytes;
   return run_conformer(h, B, T, w, logits, (hipStream_t)stream, tokens, embedding);
 }
 
@@ -1312,6 +1390,31 @@ extern "C" int afx_k_gemm(int dtype, const void* A, long lda, const void* W, lon
   GemmArgs g = plain_gemm(A, lda, W, ldw, M, N, K);
   g.bias = bias; g.act = act; g.alpha = alpha; g.resid = resid; g.ldr = ldr;
   g.out_f = out_f; g.ldo_f = ldo_f; g.out_h = out_h; g.ldo_h = ldo_h;
+  if (dtype == DT_FP16X3) {
+    // Test hook of the split-precision product: A (M,K) and W (N,K) are FP32 here; the operand forms the engine keeps
+    // (weight rows [hi | lo] + row scales, built once per checkpoint; the A planes, built per product in the workspace)
+    // are built per call in temporary device memory, and the call synchronises the stream before it frees them.
+    hipStream_t s = (hipStream_t)stream;
+    if (K % 64 || lda != K || ldw != K) return fail("afx_k_gemm(fp16x3): contiguous rows, K %% 64 == 0");
+    void *wp = nullptr, *planes = nullptr;
+    const long plane = ((long)M * K + 63) & ~63L;
+    if (hipMalloc(&wp, (size_t)N * K * 4 + (size_t)N * 4) != hipSuccess || hipMalloc(&planes, (size_t)plane * 4) != hipSuccess) {
+      (void)hipFree(wp);
+      return fail("afx_k_gemm(fp16x3): device allocation failed");
+    }
+    float* sc = (float*)((char*)wp + (size_t)N * K * 4);
+    const char* m = launch_pack_linear((const float*)W, N, K, K, wp, DT_FP32, s);
+    if (!m) m = launch_split_weight_rows(wp, N, K, sc, s);
+    if (!m) m = launch_split_planes((const float*)A, (long)M * K, planes, plane, s);
+    if (!m) {
+      g.A = planes; g.W = wp; g.k1 = K; g.K = 3 * K; g.kchunk = K; g.a_plane = plane; g.w_plane = K; g.ldw = 2L * K; g.pre_scale = sc;
+      m = launch_gemm(g, DT_FP16X3, 1, s);
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(wp);
+    (void)hipFree(planes);
+    return m ? fail("%s", m) : 0;
+  }
   KRET(launch_gemm(g, dtype, 1, (hipStream_t)stream));
 }
 extern "C" int afx_k_conv_gemm(int dtype, const void* in_h, const void* Wp, int B, int Tin, int Tout, int Cin, int k,

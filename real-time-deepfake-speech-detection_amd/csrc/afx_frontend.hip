@@ -791,4 +791,85 @@ const char* launch_pack_posconv(const float* v, const float* g, int C, int cpg, 
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
 
+// ---- split precision (DT_FP16X3) operand preparation --------------------------------------------------------------------
+// One workgroup per weight row: the row is read whole (registers -> LDS) before anything is written, so the fp16 [hi | lo]
+// form can take the place of the fp32 row it was made from.
+__global__ __launch_bounds__(256) void split_weight_rows_kernel(float* w, int K, float* row_scale) {
+  extern __shared__ float srow[];
+  float* row = w + (long)blockIdx.x * K;
+  float mx = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float v = row[k];
+    srow[k] = v;
+    mx = fmaxf(mx, fabsf(v));
+  }
+  __shared__ float red[4];
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  // 2^e with mx * 2^e in [8192, 16384): hi parts are far from fp16's overflow, lo parts of typical entries far from its subnormals
+  int e = 0;
+  if (mx > 0.f && mx < 3.0e38f) {
+    int ex;
+    (void)frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1)
+    e = 14 - ex;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  }
+  const float sc = ldexpf(1.0f, e);
+  _Float16* out = (_Float16*)row;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float v = srow[k] * sc;
+    const _Float16 h = (_Float16)v;
+    out[k] = h;
+    out[K + k] = (_Float16)(v - (float)h);
+  }
+  if (threadIdx.x == 0) row_scale[blockIdx.x] = ldexpf(1.0f, -e) / kS3ActScale;
+}
+const char* launch_split_weight_rows(void* w, int N, int K, float* row_scale, hipStream_t s) {
+  if (K > 12288) return "split_weight_rows: rows of at most 12288 elements";
+  static LdsLimit lim;
+  if (hipError_t e = lim.ensure((const void*)split_weight_rows_kernel, K * 4 + 64); e != hipSuccess) return hipGetErrorString(e);
+  hipLaunchKernelGGL(split_weight_rows_kernel, dim3(N), dim3(256), (size_t)K * 4, s, (float*)w, K, row_scale);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long n8, long n, _Float16* __restrict__ hi,
+                                                           _Float16* __restrict__ lo) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const long o = i * 8;
+    if (o + 8 <= n) {
+      const f32x4 a = *(const f32x4*)(x + o), b = *(const f32x4*)(x + o + 4);
+      f16x8 h, l;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float va = a[r] * kS3ActScale, vb = b[r] * kS3ActScale;
+        h[r] = (_Float16)va;
+        h[4 + r] = (_Float16)vb;
+        l[r] = (_Float16)(va - (float)h[r]);
+        l[4 + r] = (_Float16)(vb - (float)h[4 + r]);
+      }
+      *(f16x8*)(hi + o) = h;
+      *(f16x8*)(lo + o) = l;
+    } else {
+      for (long j = o; j < n; ++j) {
+        const float v = x[j] * kS3ActScale;
+        const _Float16 h = (_Float16)v;
+        hi[j] = h;
+        lo[j] = (_Float16)(v - (float)h);
+      }
+    }
+  }
+}
+const char* launch_split_planes(const float* x, long n, void* planes, long plane_stride, hipStream_t s) {
+  if (n <= 0) return nullptr;
+  if (((size_t)x & 15) || ((size_t)planes & 15) || (plane_stride & 7)) return "split_planes: 16-byte aligned operands";
+  const long n8 = (n + 7) / 8;
+  const int blocks = (int)min((long)8192, (n8 + 255) / 256);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, x, n8, n, (_Float16*)planes, (_Float16*)planes + plane_stride);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
 }  // namespace afx

@@ -44,7 +44,9 @@ namespace afx {
 // LEAN (the 8-phase kernels): only what the launcher sends them -- no activation or erf-GELU, N % 8 == 0.
 // The general form inlines the other activations at every one of the 32 steps and carries the 4-column
 // fallback: ~300 KB of code around a 12-KB K-loop, refetched through the instruction cache after every tile.
-template <class HT, int BM, int BN, int WR, int WC, bool ROWLN, bool LEAN = false>
+// S3 (split precision, GemmArgs::k1): the accumulator of column n is multiplied by pre_scale[n] before the bias, and the
+// "operand type" output out_h is written as fp32 (the engine's operand buffers are fp32 in that mode).
+template <class HT, int BM, int BN, int WR, int WC, bool ROWLN, bool LEAN = false, bool S3 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / WR / 16][BN / WC / 16], char* smem,
                                               int m0, int n0, int g) {
   typedef typename HT::T T;
@@ -62,11 +64,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
     float* red = (float*)smem;  // [WC][BM] partial row sums
     // bias, gamma, beta of the BN columns: one global round trip for the whole workgroup, then LDS
     // (fetched per use they were a dependent L2 round trip per column pair)
-    float* vec = red + WC * BM;  // [3][BN]
+    float* vec = red + WC * BM;  // [3][BN] (+ a fourth row, the column scales, in split precision)
     for (int t = tid; t < BN; t += 64 * WR * WC) {
       vec[t] = p.bias[n0 + t];
       vec[BN + t] = p.ln_gamma[n0 + t];
       vec[2 * BN + t] = p.ln_beta[n0 + t];
+      if constexpr (S3) vec[3 * BN + t] = p.pre_scale[n0 + t];
     }
     __syncthreads();
     const int kq = lane >> 4;
@@ -74,8 +77,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const f32x4 b = *(const f32x4*)(vec + wc * WN + j * 16 + 4 * kq);
+      if constexpr (S3) {
+        const f32x4 rs = *(const f32x4*)(vec + 3 * BN + wc * WN + j * 16 + 4 * kq);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i][j] += b;
+        for (int i = 0; i < MT; ++i) acc[i][j] = acc[i][j] * rs + b;
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][j] += b;
+      }
     }
     float mean[MT], rstd[MT];
     const float invn = 1.0f / (float)BN;
@@ -136,7 +145,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           vb[r] = fmaf(acc[i][2 * jp + 1][r] * rstd[i], ga1[r], be1[r]);
         }
         if (p.act == ACT_GELU && !(AFX_DBG(p, 8))) {
-          gelu_poly8(va, vb);
+          if constexpr (S3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              va[r] = gelu_erf(va[r]);
+              vb[r] = gelu_erf(vb[r]);
+            }
+          } else {
+            gelu_poly8(va, vb);
+          }
         } else if (!LEAN && p.act != ACT_NONE) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -164,13 +181,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           *(f32x4*)(op + 4) = vb;
         }
         if (p.out_h) {
-          V8 h;
+          if constexpr (S3) {
+            float* op = (float*)p.out_h + hrow * p.ldo_h + n;
+            *(f32x4*)op = va;
+            *(f32x4*)(op + 4) = vb;
+          } else {
+            V8 h;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            h[r] = (T)va[r];
-            h[4 + r] = (T)vb[r];
+            for (int r = 0; r < 4; ++r) {
+              h[r] = (T)va[r];
+              h[4 + r] = (T)vb[r];
+            }
+            *(V8*)((T*)p.out_h + hrow * p.ldo_h + n) = h;
           }
-          *(V8*)((T*)p.out_h + hrow * p.ldo_h + n) = h;
         }
       }
     }
@@ -192,6 +215,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
     // Loaded at the point of use, each of the MT x NT/2 steps was a dependent L2 round trip --
     // ~15 us per 256x256 tile, more than its K-loop at K = 512 (tools/bench_gemm_k.py).
     f32x4 bia[NT / 2][2];
+    f32x4 rsc[S3 ? NT / 2 : 1][2];  // split precision: the column scales, loaded like the bias
 #pragma unroll
     for (int jp = 0; jp < NT / 2; ++jp) {
       const int na = n0 + wc * WN + jp * 32 + 4 * kq, nbb = na + 16;
@@ -199,6 +223,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       if (p.bias) {
         if (na < p.N) bia[jp][0] = *(const f32x4*)(p.bias + gcol + na);
         if (nbb < p.N) bia[jp][1] = *(const f32x4*)(p.bias + gcol + nbb);
+      }
+      if constexpr (S3) {
+        rsc[jp][0] = rsc[jp][1] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (na < p.N) rsc[jp][0] = *(const f32x4*)(p.pre_scale + gcol + na);
+        if (nbb < p.N) rsc[jp][1] = *(const f32x4*)(p.pre_scale + gcol + nbb);
       }
     }
     constexpr int STEPS = MT * (NT / 2);
@@ -238,9 +267,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       bool mok;
       row_of(i, orow, hrow, mok);
       const int nb = n0 + wc * WN + jp * 32;  // first column of the tile pair
-      f32x4 va = acc[i][2 * jp] + bia[jp][0], vb = acc[i][2 * jp + 1] + bia[jp][1];
+      f32x4 va, vb;
+      if constexpr (S3) {
+        va = acc[i][2 * jp] * rsc[jp][0] + bia[jp][0];
+        vb = acc[i][2 * jp + 1] * rsc[jp][1] + bia[jp][1];
+      } else {
+        va = acc[i][2 * jp] + bia[jp][0];
+        vb = acc[i][2 * jp + 1] + bia[jp][1];
+      }
       if (p.act == ACT_GELU && !(AFX_DBG(p, 8))) {
-        gelu_poly8(va, vb);
+        if constexpr (S3) {  // fp32 results: the fp32-accurate erf form (the polynomial is sized for fp16 outputs)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            va[r] = gelu_erf(va[r]);
+            vb[r] = gelu_erf(vb[r]);
+          }
+        } else {
+          gelu_poly8(va, vb);
+        }
       } else if (!LEAN && p.act != ACT_NONE && !(AFX_DBG(p, 8))) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -272,13 +316,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           *(f32x4*)(op + 4) = vb;
         }
         if (p.out_h) {
-          V8 h;
+          if constexpr (S3) {
+            float* op = (float*)p.out_h + hrow * p.ldo_h + gcol + n;
+            *(f32x4*)op = va;
+            *(f32x4*)(op + 4) = vb;
+          } else {
+            V8 h;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            h[r] = (T)va[r];
-            h[4 + r] = (T)vb[r];
+            for (int r = 0; r < 4; ++r) {
+              h[r] = (T)va[r];
+              h[4 + r] = (T)vb[r];
+            }
+            *(V8*)((T*)p.out_h + hrow * p.ldo_h + gcol + n) = h;
           }
-          *(V8*)((T*)p.out_h + hrow * p.ldo_h + gcol + n) = h;
         }
       }
     };
@@ -311,6 +361,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       const int n = n0 + wc * WN + j * 16 + 4 * kq;
       if (n >= p.N) continue;
       f32x4 v = acc[i][j];
+      if constexpr (S3) v *= *(const f32x4*)(p.pre_scale + gcol + n);
       if (p.bias) v += *(const f32x4*)(p.bias + gcol + n);
       if (p.act != ACT_NONE && !(AFX_DBG(p, 8))) {
 #pragma unroll
@@ -320,10 +371,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       if (p.resid) v += *(const f32x4*)(p.resid + orow * p.ldr + gcol + n);
       if (p.out_f) *(f32x4*)(p.out_f + orow * p.ldo_f + gcol + n) = v;
       if (p.out_h) {
-        V4 h;
+        if constexpr (S3) {
+          *(f32x4*)((float*)p.out_h + hrow * p.ldo_h + gcol + n) = v;
+        } else {
+          V4 h;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = (T)v[r];
-        *(V4*)((T*)p.out_h + hrow * p.ldo_h + gcol + n) = h;
+          for (int r = 0; r < 4; ++r) h[r] = (T)v[r];
+          *(V4*)((T*)p.out_h + hrow * p.ldo_h + gcol + n) = h;
+        }
       }
     }
   }
@@ -334,7 +389,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 // LayerNorm over the row (two-pass fp32 statistics, partial sums exchanged through LDS
 // between the WC waves of a row) followed by the activation -- the conv feature
 // extractor's "conv -> LayerNorm(512) -> GELU" in one kernel, no fp32 round trip.
-template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false, bool LEAN = false>
+template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false, bool LEAN = false, bool S3 = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
@@ -431,8 +486,15 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
                    : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
   };
   auto stage = [&](int buf, int kt) {
-    const int k0 = kt << 6;
-    const long ka = (long)(k0 / p.kchunk) * p.kchunk_stride + (k0 % p.kchunk);
+    int k0 = kt << 6;
+    long aplane = 0, wplane = 0;
+    if constexpr (S3) {  // K-tile kt of [xh.wh | xl.wh | xh.wl]: which planes, and the k inside the segment
+      const int seg = k0 >= 2 * p.k1 ? 2 : (k0 >= p.k1 ? 1 : 0);
+      k0 -= seg * p.k1;
+      aplane = seg == 1 ? p.a_plane : 0;
+      wplane = seg == 2 ? p.w_plane : 0;
+    }
+    const long ka = (long)(k0 / p.kchunk) * p.kchunk_stride + (k0 % p.kchunk) + aplane;
     const unsigned base = (unsigned)(buf * STAGE);
     // a_nt: the A panel is read by exactly one workgroup (row-complete tile) -- stream it
     // non-temporally so it does not evict the W panel every workgroup re-reads from L2
@@ -440,7 +502,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) dma16(a_src[i] + ka, base + (i * NW + wave) * 1024, p.a_nt != 0);
 #pragma unroll
-      for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0, base + A_BYTES + (i * NW + wave) * 1024, false);
+      for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0 + wplane, base + A_BYTES + (i * NW + wave) * 1024, false);
     } else {
 #pragma unroll
       for (int i = 0; i < AI; ++i)
@@ -449,7 +511,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
                                          16, 0, 0);
 #pragma unroll
       for (int i = 0; i < WI; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0 + wplane),
                                          (__attribute__((address_space(3))) void*)(smem + base + A_BYTES + (i * NW + wave) * 1024),
                                          16, 0, 0);
     }
@@ -484,7 +546,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
     }
   }
 
-  gemm_epilogue<HT, BM, BN, WR, WC, ROWLN, LEAN>(p, acc, smem, m0, n0, g);
+  gemm_epilogue<HT, BM, BN, WR, WC, ROWLN, LEAN, S3>(p, acc, smem, m0, n0, g);
 }
 
 template <int N>
@@ -539,7 +601,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // TS (attribution build only): every wave stamps the shader clock at five points of each phase of the FIRST output tile
 // (start of the read part / DMA landed + reads retired / first barrier passed / MFMAs issued / second barrier passed) into
 // 16 KB of LDS behind the operand buffers; workgroup 0 dumps them over the head of out_h at the end (tools/kloop_timeline.py).
-template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, int PH = 1, bool TS = false>
+template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, int PH = 1, bool TS = false, bool S3 = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
@@ -633,13 +695,34 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
   };
+  // element offset of K-tile kt inside an A / W row.  Split precision (S3): the K-tiles walk [xh.wh | xl.wh | xh.wl] --
+  // segment 1 reads A's lo plane, segment 2 W's lo half; the k inside a segment restarts at 0.
+  const int nk1 = S3 ? (p.k1 >> 6) : 0;
+  auto koffA = [&](int kt) -> long {
+    if constexpr (S3) {
+      const int seg = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
+      return (long)(kt - seg * nk1) * 64 + (seg == 1 ? p.a_plane : 0);
+    } else {
+      return (long)kt * 64;
+    }
+  };
+  auto koffB = [&](int kt) -> long {
+    if constexpr (S3) {
+      const int seg = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
+      return (long)(kt - seg * nk1) * 64 + (seg == 2 ? p.w_plane : 0);
+    } else {
+      return (long)kt * 64;
+    }
+  };
   auto stageA = [&](int h, int buf, int kt) {
+    const long ko = koffA(kt);
 #pragma unroll
-    for (int i = 0; i < DA; ++i) dma16(srcA[h][i] + kt * 64, buf * BUF + (h ? OFF_A1 : OFF_A0) + (i * 8 + wave) * 1024);
+    for (int i = 0; i < DA; ++i) dma16(srcA[h][i] + ko, buf * BUF + (h ? OFF_A1 : OFF_A0) + (i * 8 + wave) * 1024);
   };
   auto stageB = [&](int h, int buf, int kt) {
+    const long ko = koffB(kt);
 #pragma unroll
-    for (int i = 0; i < DB; ++i) dma16(srcB[h][i] + kt * 64, buf * BUF + (h ? OFF_B1 : OFF_B0) + (i * 8 + wave) * 1024);
+    for (int i = 0; i < DB; ++i) dma16(srcB[h][i] + ko, buf * BUF + (h ? OFF_B1 : OFF_B0) + (i * 8 + wave) * 1024);
   };
 
   // fragment read addresses (bytes): row (lane & (FR-1)) of an FR-row tile; the lane's 8 k-values of k-step
@@ -697,12 +780,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   //     phase B: read A1(t)         stage B0 B1 (t+2)   wait: tile t+1 landed   MFMA (A1,B1) (A1,B0)
   constexpr int RSZ3 = 2 * RB * 128, FSZ3 = 2 * RA * 128;
   auto stageA3 = [&](int h, int fboff, int kt) {
+    const long ko = koffA(kt);
 #pragma unroll
-    for (int i = 0; i < DA; ++i) dma16(srcA[h][i] + kt * 64, 2 * RSZ3 + fboff + h * (RA * 128) + (i * 8 + wave) * 1024);
+    for (int i = 0; i < DA; ++i) dma16(srcA[h][i] + ko, 2 * RSZ3 + fboff + h * (RA * 128) + (i * 8 + wave) * 1024);
   };
   auto stageB3 = [&](int h, int rb, int kt) {
+    const long ko = koffB(kt);
 #pragma unroll
-    for (int i = 0; i < DB; ++i) dma16(srcB[h][i] + kt * 64, rb * RSZ3 + h * (RB * 128) + (i * 8 + wave) * 1024);
+    for (int i = 0; i < DB; ++i) dma16(srcB[h][i] + ko, rb * RSZ3 + h * (RB * 128) + (i * 8 + wave) * 1024);
   };
   auto readA3 = [&](int fboff, int h) {
 #pragma unroll
@@ -987,7 +1072,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) asm volatile("" :: "v"(acc[i][j][r]));
     } else {
-      gemm_epilogue<HT, BMC, BN, 2, 4, ROWLN, true>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
+      gemm_epilogue<HT, BMC, BN, 2, 4, ROWLN, true, S3>(p, acc, smem + BUF + (WIDE ? OFF_B1 : OFF_A1), m0c, n0c, g);
     }
     ts_on = false;
     if (vn >= nwg) break;
@@ -1001,12 +1086,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 #undef AFX_BAR
 }
 
-template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, int PH = 1, bool TS = false>
+template <class HT, int BM, int BN, bool ROWLN, int MF = BM / 32, int PH = 1, bool TS = false, bool S3 = false>
 static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128 + (TS ? 16384 : 0) + (PH == 3 ? BM * 128 : 0);  // ring3: a third buffer for A
   static_assert(lds <= 160 * 1024, "two K-tile buffers must fit the 160 KB LDS");
   static LdsLimit lim;
-  if (hipError_t e = lim.ensure((const void*)gemm8_kernel<HT, BM, BN, ROWLN, MF, PH, TS>, lds); e != hipSuccess) return e;
+  if (hipError_t e = lim.ensure((const void*)gemm8_kernel<HT, BM, BN, ROWLN, MF, PH, TS, S3>, lds); e != hipSuccess) return e;
   static int n_cu_of[kMaxDevices] = {0};  // (benign if two threads fill the same slot: same value)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
@@ -1019,17 +1104,17 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   const int n_cu = n_cu_of[dev];
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M - p.m_lo + MF * 32 - 1) / (MF * 32));
   dim3 grid(tiles < n_cu ? tiles : n_cu, 1, groups);  // persistent: at most one workgroup per CU
-  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN, MF, PH, TS>), grid, dim3(512), lds, s, p);
+  hipLaunchKernelGGL((gemm8_kernel<HT, BM, BN, ROWLN, MF, PH, TS, S3>), grid, dim3(512), lds, s, p);
   return hipGetLastError();
 }
 
-template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false, bool LEAN = false>
+template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false, bool LEAN = false, bool S3 = false>
 static hipError_t launch_gemm_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static LdsLimit lim;
-  if (hipError_t e = lim.ensure((const void*)gemm_kernel<HT, BM, BN, WR, WC, ROWLN, LEAN>, lds); e != hipSuccess) return e;
+  if (hipError_t e = lim.ensure((const void*)gemm_kernel<HT, BM, BN, WR, WC, ROWLN, LEAN, S3>, lds); e != hipSuccess) return e;
   dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
-  hipLaunchKernelGGL((gemm_kernel<HT, BM, BN, WR, WC, ROWLN, LEAN>), grid, dim3(64 * WR * WC), lds, s, p);
+  hipLaunchKernelGGL((gemm_kernel<HT, BM, BN, WR, WC, ROWLN, LEAN, S3>), grid, dim3(64 * WR * WC), lds, s, p);
   return hipGetLastError();
 }
 
@@ -1050,6 +1135,9 @@ static constexpr int g_nodma = 0;
 bool gemm_set_nodma(int v) { return v == 0; }  // the product build has no such switch
 #endif
 
+// true: K is walked linearly (no chunked addressing) -- in split precision, inside each of the three segments
+static bool plain_k(const GemmArgs& p) { return p.kchunk == (p.k1 ? p.k1 : p.K); }
+
 // Host-side shape contract; anything else is a programming error in the caller.
 static const char* check_gemm(const GemmArgs& p, int groups) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return "gemm: empty problem";
@@ -1058,6 +1146,11 @@ static const char* check_gemm(const GemmArgs& p, int groups) {
   if (p.kchunk <= 0 || p.kchunk % 64) return "gemm: kchunk must be a positive multiple of 64";
   if (p.rpb <= 0) return "gemm: rows-per-batch must be positive";
   if (!p.out_f && !p.out_h) return "gemm: no output";
+  if (p.k1) {
+    if (p.k1 % 64 || p.K != 3 * p.k1 || !p.pre_scale || p.w_plane <= 0 || p.a_plane <= 0 || (p.a_plane & 7) || (p.w_plane & 7))
+      return "gemm: split precision needs K = 3 k1, k1 % 64 == 0, both plane strides and the column scales";
+    if (p.k1 % p.kchunk) return "gemm: split precision: the segment must be whole chunks";
+  }
   if (p.ln_gamma) {
     if (p.N != 512 || groups != 1) return "gemm: the fused LayerNorm epilogue needs N == 512 (row-complete tile)";
     if (!p.ln_beta || !p.bias || p.resid || p.alpha != 1.f) return "gemm: fused LayerNorm epilogue: bias + LN + act only";
@@ -1082,7 +1175,7 @@ static int g_split = 1;  // A/B knob
 void gemm_set_split(int v) { g_split = v; }
 static int gemm_split_rows(const GemmArgs& p, int groups) {
   constexpr int kCUs = 256;
-  if (!g_split || groups != 1 || p.ln_gamma || p.kchunk != p.K || p.rpb < p.M || gemm_is_narrow(p.N)) return 0;
+  if (!g_split || groups != 1 || p.ln_gamma || !plain_k(p) || p.rpb < p.M || gemm_is_narrow(p.N)) return 0;
   const long nN = (p.N + 255) / 256, nM = (p.M + 255) / 256, tiles = nN * nM;
   if (tiles <= kCUs || tiles % kCUs == 0) return 0;
   const long nM1 = (tiles / kCUs) * kCUs / nN;  // whole rounds, whole row tiles
@@ -1139,11 +1232,11 @@ static int gemm8_fit_rowln(const GemmArgs& p) {
 }
 
 int gemm_tile_of(const GemmArgs& p, int groups) {
-  if (p.ln_gamma) return g_deep != 0 && p.kchunk == p.K ? 8 : 3;
+  if (p.ln_gamma) return g_deep != 0 && plain_k(p) ? 8 : 3;
   if (gemm_is_narrow(p.N)) return 1;
   if (groups != 1) return 0;
   if (g_tile_override == 5) return 1;  // 128x64 / 4 waves (forced)
-  if (g_tile_override == 3) return p.kchunk == p.K ? 7 : 0;  // 8-phase 256x256
+  if (g_tile_override == 3) return plain_k(p) ? 7 : 0;  // 8-phase 256x256
   if (g_tile_override >= 0) return g_tile_override == 1 ? 2 : 0;
   // Wave-quantisation model fitted to tools/bench_gemm.py (profiles/r01_gemm_tile_ab*.txt):
   // the 8-phase 256x256 kernel is ~15 % faster per FLOP at K = 1024 (25 % at K = 4096) but
@@ -1155,7 +1248,7 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
   const double e128 = (double)b128 / (double)(((b128 + 511) / 512) * 512);
   const double e256 = 1.15 * (double)b256 / (double)(((b256 + 255) / 256) * 256);
   if (e256 <= e128) return 0;
-  return p.kchunk == p.K ? 7 : 2;  // the 8-phase kernel where its addressing applies (no chunked K)
+  return plain_k(p) ? 7 : (p.k1 ? 0 : 2);  // the 8-phase kernel where its addressing applies (no chunked K)
 }
 
 template <class HT>
@@ -1182,8 +1275,28 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
   }
 }
 
+// split precision (DT_FP16X3): the same tiles with the three-segment K walk and the scaled, fp32-writing epilogue
+static hipError_t dispatch_s3(const GemmArgs& p, int tile, int groups, hipStream_t s) {
+  typedef FP16 HT;
+  const bool lean = (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0;
+  switch (tile) {
+    case 1: return lean ? launch_gemm_t<HT, 128, 64, 2, 2, false, true, true>(p, groups, s) : launch_gemm_t<HT, 128, 64, 2, 2, false, false, true>(p, groups, s);
+    case 7: return launch_gemm8_t<HT, 256, 256, false, 8, 3, false, true>(p, groups, s);
+    case 75: return launch_gemm8_t<HT, 256, 256, false, 5, 3, false, true>(p, groups, s);
+    case 76: return launch_gemm8_t<HT, 256, 256, false, 6, 3, false, true>(p, groups, s);
+    case 77: return launch_gemm8_t<HT, 256, 256, false, 7, 3, false, true>(p, groups, s);
+    case 3:
+    case 8: return launch_gemm8_t<HT, 128, 512, true, 4, 1, false, true>(p, groups, s);
+    case 82: return launch_gemm8_t<HT, 128, 512, true, 2, 1, false, true>(p, groups, s);
+    case 83: return launch_gemm8_t<HT, 128, 512, true, 3, 1, false, true>(p, groups, s);
+    default: return lean ? launch_gemm_t<HT, 128, 128, 2, 2, false, true, true>(p, groups, s) : launch_gemm_t<HT, 128, 128, 2, 2, false, false, true>(p, groups, s);
+  }
+}
+#define AFX_DISPATCH_GEMM(p, tile) ((p).k1 ? dispatch_s3(p, tile, groups, s) : (dtype == DT_BF16 ? dispatch<BF16>(p, tile, groups, s) : dispatch<FP16>(p, tile, groups, s)))
+
 const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t s) {
   if (dtype == DT_FP32) return launch_gemm_f32(p_in, groups, s);
+  if ((dtype == DT_FP16X3) != (p_in.k1 != 0)) return "gemm: the split-precision fields (k1, planes, column scales) go with DT_FP16X3 and only with it";
   if (const char* e = check_gemm(p_in, groups)) return e;
   GemmArgs p = p_in;
   p.map_mode = g_map_override >= 0 ? g_map_override : 2;
@@ -1210,9 +1323,9 @@ const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t
     b.A = (const char*)p.A + (size_t)m1 * p.a_row * hs;
     if (p.resid) b.resid = p.resid + (size_t)m1 * p.ldr;
     if (p.out_f) b.out_f = p.out_f + (size_t)m1 * p.ldo_f;
-    if (p.out_h) b.out_h = (char*)p.out_h + (size_t)m1 * p.ldo_h * hs;
-    hipError_t err = dtype == DT_BF16 ? dispatch<BF16>(a, 7, groups, s) : dispatch<FP16>(a, 7, groups, s);
-    if (err == hipSuccess) err = dtype == DT_BF16 ? dispatch<BF16>(b, 0, groups, s) : dispatch<FP16>(b, 0, groups, s);
+    if (p.out_h) b.out_h = (char*)p.out_h + (size_t)m1 * p.ldo_h * (p.k1 ? 4 : hs);
+    hipError_t err = AFX_DISPATCH_GEMM(a, 7);
+    if (err == hipSuccess) err = AFX_DISPATCH_GEMM(b, 0);
     return err == hipSuccess ? nullptr : hipGetErrorString(err);
   }
   if (tile == 7) {
@@ -1231,12 +1344,12 @@ const char* launch_gemm(const GemmArgs& p_in, int dtype, int groups, hipStream_t
       GemmArgs a = p, b = p;
       a.M = (int)((t128 / 256) * 256 * 128);
       b.m_lo = a.M;
-      hipError_t err = dtype == DT_BF16 ? dispatch<BF16>(a, 8, groups, s) : dispatch<FP16>(a, 8, groups, s);
-      if (err == hipSuccess) err = dtype == DT_BF16 ? dispatch<BF16>(b, 82, groups, s) : dispatch<FP16>(b, 82, groups, s);
+      hipError_t err = AFX_DISPATCH_GEMM(a, 8);
+      if (err == hipSuccess) err = AFX_DISPATCH_GEMM(b, 82);
       return err == hipSuccess ? nullptr : hipGetErrorString(err);
     }
   }
-  const hipError_t err = dtype == DT_BF16 ? dispatch<BF16>(p, tile, groups, s) : dispatch<FP16>(p, tile, groups, s);
+  const hipError_t err = AFX_DISPATCH_GEMM(p, tile);
   return err == hipSuccess ? nullptr : hipGetErrorString(err);
 }
 

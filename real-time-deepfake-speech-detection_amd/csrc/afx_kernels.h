@@ -7,8 +7,11 @@
 
 namespace afx {
 
-enum DType { DT_BF16 = 0, DT_FP16 = 1, DT_FP32 = 2 };
-inline size_t dtype_size(int dt) { return dt == DT_FP32 ? 4 : 2; }
+// DT_FP16X3: split precision -- activations live in fp32 (every non-GEMM kernel runs its DT_FP32 form), every dense product
+// runs on the fp16 matrix pipe as x.w ~ xh.wh + xl.wh + xh.wl with fp16 hi / lo pairs of both operands (GemmArgs::k1)
+enum DType { DT_BF16 = 0, DT_FP16 = 1, DT_FP32 = 2, DT_FP16X3 = 3 };
+inline size_t dtype_size(int dt) { return dt == DT_FP32 || dt == DT_FP16X3 ? 4 : 2; }
+constexpr float kS3ActScale = 16.f;  // split-precision A operands are scaled by this power of two before the hi / lo split (lo parts of O(1) activations stay in fp16's normal range; overflow only beyond |x| = 4094)
 
 struct GemmArgs {
   const void* A;  // matrix-core operand type (bf16/fp16), K contiguous
@@ -47,6 +50,15 @@ struct GemmArgs {
   float ln_eps;
   int a_nt;  // 1: non-temporal LDS-DMA for the A panel (set by launch_gemm)
   int m_lo;  // 8-wave kernels only: the launch covers rows [m_lo, M) (set by launch_gemm for a remainder launch; 0 otherwise)
+  // ---- split precision (launch_gemm with DT_FP16X3; set by the engine's wrapper, 0 / null otherwise) ---------------------
+  // K holds THREE segments of k1 each: [xh.wh | xl.wh | xh.wl].  A is a pair of fp16 planes (hi at A, lo at A + a_plane
+  // elements, same addressing in both); W rows are [hi k1' | lo k1'] with the lo half w_plane elements behind the hi half
+  // (ldw = 2 x w_plane); kchunk / kchunk_stride address INSIDE a segment.  The epilogue multiplies the accumulator of
+  // column n by pre_scale[n] (the inverse of the row's power-of-two weight scale x the activation scale) before the
+  // bias, and writes `out_h` as FP32 (the engine's operand buffers are fp32 in this mode).
+  int k1;
+  long a_plane, w_plane;
+  const float* pre_scale;
   int dbg_nodma;  // attribution build (-DAFX_ATTR) only, ignored otherwise: epilogue bits 8 no activation, 16 narrow stores, 32 no stores, 64 no epilogue
 };
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
@@ -115,6 +127,12 @@ const char* launch_pack_linear(const float* w, int N, int K, int Kpad, void* out
 const char* launch_pack_conv(const float* w, int N, int Cin, int k, void* out_h, int dtype, hipStream_t s);
 const char* launch_pack_posconv(const float* v, const float* g, int C, int cpg, int k, float* norm_tmp /*[k]*/,
                                 void* out_h, int dtype, hipStream_t s);
+// Split precision (DT_FP16X3).  Weights: a matrix packed as fp32 rows [N][K] (the pack launchers above with DT_FP32) is
+// rewritten IN PLACE as fp16 rows [hi K | lo K] of w * 2^s_n, s_n the power of two that brings the row's largest magnitude
+// to [8192, 16384); row_scale[n] = 1 / (2^s_n * kS3ActScale).  K <= 12288.
+const char* launch_split_weight_rows(void* w_f32_inplace, int N, int K, float* row_scale, hipStream_t s);
+// Activations: n fp32 values -> hi plane (n halfs at `planes`) and lo plane (at planes + plane_stride) of x * kS3ActScale
+const char* launch_split_planes(const float* x, long n, void* planes, long plane_stride, hipStream_t s);
 
 // ---- positional conv of the encoder as a sliding-window kernel (afx_posconv.hip) ---------------
 // x (B*T, 1024) fp32 += GELU(grouped conv over the time-padded operand copy xpad (B, T+128, 1024)); T <= 224

@@ -33,7 +33,16 @@ def has_gpu():
     return torch.cuda.is_available()
 
 
-def teacher_conditioning(sd, wave, eng):
+def teacher_oracle(sd, wave):
+    """The CPU oracle's side of teacher_conditioning (the expensive half: 24 fp32 transformer layers on the host), so that
+    several engines / precisions can be gated against ONE oracle pass over the same utterances."""
+    from oracle import models as om
+    t_ref = {}
+    ref = om.xlsr_aasist_forward(sd, wave, taps=t_ref)
+    return ref, t_ref
+
+
+def teacher_conditioning(sd, wave, eng, oracle=None):
     """XLSR_AASIST parity bookkeeping shared by the teacher tests.  Returns (ref, got, rows): oracle logits, the
     engine's logits, and per utterance
       backend   |engine - oracle back-end run on the ENGINE's own SSL features|: the back-end alone, same inputs;
@@ -42,15 +51,16 @@ def teacher_conditioning(sd, wave, eng):
                 (models/aasist_modules.py:330-336, models/xlsr_aasist.py:160-162), so the model is discontinuous where
                 two kept scores nearly tie (4-s clips: 106 gaps per utterance, the smallest typically ~5e-6).  True =
                 the oracle back-end picks the same node sequences on its own fp32 features and on the engine's;
-      margin    the smallest deciding score gap (on either feature set), for the record."""
+      margin    the smallest deciding score gap (on either feature set), for the record.
+    oracle: a teacher_oracle(sd, wave) result to reuse (None: computed here)."""
     from oracle import aasist as oa
     from oracle import models as om
     _ssl, head = om.split(sd)
-    t_ref = {}
-    ref = om.xlsr_aasist_forward(sd, wave, taps=t_ref)
+    ref, t_ref = oracle if oracle is not None else teacher_oracle(sd, wave)
     eng.enable_taps()
     got = eng.forward(wave.cuda()).cpu()
     feats = eng.tap("ssl").cpu().reshape(t_ref["ssl"].shape)
+    eng.enable_taps(False)
     t_mid = {}
     mid = oa.aasist_backend(head, feats, t_mid)
     rows = []

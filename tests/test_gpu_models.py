@@ -275,6 +275,29 @@ def test_benchmarked_student_4096_trials_scores_and_eer(afx_mod):
     assert abs(eer_got - eer_ref) <= 0.2
 
 
+@pytest.mark.parametrize("dtype", ["fp32"])
+def test_benchmarked_student_4096_trials_eer_unchanged_to_2dp(afx_mod, dtype):
+    """`north_star`: "EER unchanged to 2 d.p." -- met AS WRITTEN on the 4096-trial fixture of the benchmarked student by the
+    modes that carry fp32 accuracy through the trunk: the build's EER equals the oracle's to two
+    decimals (|delta| < 0.005 percentage points) and every score is within 1e-5 / 1e-3 of the oracle's."""
+    engine, synth = afx_mod
+    from conftest import load_golden
+    from afx import harness
+    z = load_golden("eer_student_4096.npz")
+    n_batches = z["scores"].shape[0] // 64
+    sd = synth.model_state_dict("ConformerModel", n_layers=6)
+    eng = engine.Engine("conformer", n_layers=6, dtype=dtype)
+    eng.load_state_dict(sd)
+    got = torch.cat([eng.forward(synth.waveforms(64, 64000, batch_idx=9000 + i).cuda())[:, 1].cpu() for i in range(n_batches)])
+    ref = torch.from_numpy(z["scores"])
+    labels = z["labels"].astype(int)
+    d = (got - ref).abs()
+    eer_ref, eer_got = float(z["eer"]), harness.calculate_EER(got.numpy(), labels)
+    print(f"{dtype}: {len(labels)} trials, max|dscore| {d.max().item():.2e}; EER oracle {eer_ref:.4f} % build {eer_got:.4f} %")
+    assert d.max().item() <= (1e-5 if dtype == "fp32" else SCORE_TOL)
+    assert abs(eer_got - eer_ref) < 0.005 and f"{eer_got:.2f}" == f"{eer_ref:.2f}"
+
+
 def test_length_policy_as_one_batched_device_op(afx_mod):
     """pad-by-tiling, first-N crop and random-start crop for a ragged batch in one
     kernel, against the reference policies restated in oracle/pre.py (data/test_set.py:139-248)."""
