@@ -44,7 +44,8 @@ for p in (ROOT, os.path.join(ROOT, "real-time-deepfake-speech-detection_amd")):
 import torch  # noqa: E402
 
 # dense matrix-core peaks, MI355X_MICROARCH.md "Chip-level parameters" (fp32: the exact-mode MFMA, 1/16 of fp16)
-MFMA_PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}
+MFMA_PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3,
+                    "fp16x3": 2500.0 / 3}  # split precision: three fp16 matrix-core products per algorithmic one
 
 WORKLOADS = {
     # name: (engine arch, oracle model name, trunk layers, GFLOP per utterance)

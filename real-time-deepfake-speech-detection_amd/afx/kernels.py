@@ -10,7 +10,8 @@ ACTS = {None: ACT_NONE, "gelu": ACT_GELU, "swish": ACT_SWISH, "selu": ACT_SELU}
 
 
 def gemm(dtype, A, W, bias=None, act=None, alpha=1.0, resid=None, out_f=True, out_h=False):
-    """A (M,K) half, W (N,K) half -> fp32 and/or half (M,N)."""
+    """A (M,K) half, W (N,K) half -> fp32 and/or half (M,N).  dtype "fp16x3" (split precision): A and W are FP32 and the
+    "operand type" output is fp32 too; the entry point builds the hi / lo operand forms per call (test hook)."""
     M, K = A.shape
     N = W.shape[0]
     of = torch.empty(M, N, dtype=torch.float32, device=A.device) if out_f else None

@@ -78,7 +78,7 @@ logits = np.zeros((B, 2), np.float32)
 SSL, AAS, CONF, HEAD = 0, 1, 2, 3
 
 for arch, prefix in ((AAS, "xlsr_aasist"), (CONF, "conformer"), (SSL, "conformer")):
-    for dtype in (1, 0, 2):  # fp16, bf16, fp32 (exact mode walks other launch branches)
+    for dtype in (1, 0, 2, 3):  # fp16, bf16, fp32 (exact mode walks other launch branches), fp16x3 (split precision)
         h = create(arch, dtype=dtype)
         fails(lib.afx_forward(h, ptr(wave), B, Ls, ptr(logits), ptr(ws_for(16)), 16, None), "not finalized")
         load(h, prefix)
@@ -123,10 +123,13 @@ for arch, prefix in ((AAS, "xlsr_aasist"), (CONF, "conformer"), (SSL, "conformer
             nh = lib.afx_head_workspace_bytes(h, B, T)
             ok(lib.afx_head_forward(h, ptr(feats), B, T, ptr(logits), ptr(ws_for(nh)), nh, None), "head forward")
             T5 = 99
-            c5 = np.zeros((B, 2 * T5, 512), np.float16 if dtype != 2 else np.float32)
+            c5 = np.zeros((B, 2 * T5, 512), np.float16 if dtype < 2 else np.float32)
             nt = lib.afx_tail_workspace_bytes(h, B, T5)
             ok(lib.afx_tail_forward(h, ptr(c5), B, T5, ptr(logits), ptr(ws_for(nt)), nt, None), "tail forward")
-            ok(lib.afx_tail_forward_strided(h, ptr(c5), 2 * T5 * 512, B, T5, ptr(logits), ptr(ws_for(nt)), nt, None), "strided tail")
+            if dtype != 3:
+                ok(lib.afx_tail_forward_strided(h, ptr(c5), 2 * T5 * 512, B, T5, ptr(logits), ptr(ws_for(nt)), nt, None), "strided tail")
+            else:
+                fails(lib.afx_tail_forward_strided(h, ptr(c5), 2 * T5 * 512, B, T5, ptr(logits), ptr(ws_for(nt)), nt, None), "packed window")
             fails(lib.afx_tail_forward_strided(h, ptr(c5), 8, B, T5, ptr(logits), ptr(ws_for(nt)), nt, None), "shorter than a window")
             if arch == CONF:
                 tok = np.zeros((B, T, 144), np.float32)
@@ -190,6 +193,8 @@ for m_ in (1, 300, 12736):
         Wn, on = np.zeros((n_, K), np.float16), np.zeros((m_, n_), np.float32)
         ok(lib.afx_k_gemm(1, ptr(Am), K, ptr(Wn), K, m_, n_, K, None, 0, 1.0, None, 0, ptr(on), n_, None, 0, None), "k_gemm")
 fails(lib.afx_k_gemm(1, ptr(A), K, ptr(Wt), K, M, N, 100, None, 0, 1.0, None, 0, ptr(of), N, None, 0, None), "multiple of 64")
+A32, W32 = np.zeros((M, K), np.float32), np.zeros((N, K), np.float32)
+ok(lib.afx_k_gemm(3, ptr(A32), K, ptr(W32), K, M, N, K, None, 0, 1.0, None, 0, ptr(of), N, None, 0, None), "k_gemm fp16x3")
 fails(lib.afx_k_gemm(1, ptr(A), K, ptr(Wt), K, M, N, K, None, 0, 1.0, None, 0, None, N, None, 0, None), "no output")
 assert lib.afx_shim_launch_count() > 500
 print("ASAN_DRIVE_OK launches", lib.afx_shim_launch_count())

@@ -53,6 +53,42 @@ def test_gemm_epilogues(K, dtype, M, N, K_):
     _close(of, F.silu(ref + bias), 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("M,N,K_", [(300, 256, 192), (77, 144, 192), (1000, 512, 1536), (3184, 1024, 1024), (12736, 3072, 1024), (515, 64, 128)])
+def test_split_precision_gemm_is_fp32_accurate(K, M, N, K_):
+    """dtype "fp16x3": x.w ~ xh.wh + xl.wh + xh.wl on the fp16 matrix pipe (fp16 hi / lo pairs of both operands, power-of-two
+    row scales on the weights, x 16 on the activations) -- ONE launch whose K walks the three segments.  Against an fp64
+    reference of the FP32 operands: the error must be at fp32 level (a dropped segment, a wrong plane or a wrong scale is
+    off by 1e-3 .. 1), on every tile instance the dispatcher can pick for these shapes, with operand magnitudes from 1e-3
+    to 1e+2 in one matrix (the lo parts of small entries fall into fp16's subnormals: bounded absolute error)."""
+    from afx._lib import check, lib
+    g = torch.Generator().manual_seed(M + 3 * N + K_)
+    A = torch.randn(M, K_, generator=g)
+    A[:, : K_ // 4] *= 30.0      # outlier channels (transformer activations have them)
+    A[:, K_ // 2:] *= 1e-2       # and small ones
+    W = torch.randn(N, K_, generator=g) / math.sqrt(K_)
+    W[: N // 3] *= 1e-2          # rows of very different scale: each gets its own power of two
+    W[N // 3: N // 2] *= 50.0
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ref64 = A.double() @ W.double().t()
+    scale = (A.double().abs() @ W.double().abs().t())  # the magnitude the rounding errors are relative to
+    for tile in (-1, 0, 3, 5):
+        try:
+            check(lib().afx_debug_set(b"gemm_tile", tile))
+            of, oh = K.gemm("fp16x3", A.cuda(), W.cuda(), out_f=True, out_h=True)
+        finally:
+            check(lib().afx_debug_set(b"gemm_tile", -1))
+        assert oh.dtype == torch.float32 and torch.equal(of, oh)
+        rel = ((of.cpu().double() - ref64).abs() / scale).max().item()
+        assert rel < 3e-6, f"tile {tile}: max error {rel:.2e} of sum |a||w|"  # fp32 GEMM: ~1e-7; fp16 operands: ~5e-4
+    of, _ = K.gemm("fp16x3", A.cuda(), W.cuda(), bias=bias.cuda(), act="gelu", alpha=0.5, resid=resid.cuda())
+    want = resid.double() + 0.5 * F.gelu(ref64 + bias.double())
+    assert ((of.cpu().double() - want).abs() / (1.0 + scale)).max().item() < 3e-6
+    # the true-fp32 matrix instruction on the same operands is no closer to the fp64 result than a few times this
+    f32, _ = K.gemm("fp32", A.cuda(), W.cuda())
+    print(f"M {M} N {N} K {K_}: split precision {rel:.2e}, fp32 MFMA {((f32.cpu().double() - ref64).abs() / scale).max().item():.2e} (of sum |a||w|)")
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("tile", [0, 1, 3])
 def test_gemm_tile_variants_agree_with_reference(K, dtype, tile):

@@ -275,7 +275,7 @@ def test_benchmarked_student_4096_trials_scores_and_eer(afx_mod):
     assert abs(eer_got - eer_ref) <= 0.2
 
 
-@pytest.mark.parametrize("dtype", ["fp32"])
+@pytest.mark.parametrize("dtype", ["fp32", "fp16x3"])
 def test_benchmarked_student_4096_trials_eer_unchanged_to_2dp(afx_mod, dtype):
     """`north_star`: "EER unchanged to 2 d.p." -- met AS WRITTEN on the 4096-trial fixture of the benchmarked student by the
     modes that carry fp32 accuracy through the trunk: the build's EER equals the oracle's to two
@@ -294,7 +294,7 @@ def test_benchmarked_student_4096_trials_eer_unchanged_to_2dp(afx_mod, dtype):
     d = (got - ref).abs()
     eer_ref, eer_got = float(z["eer"]), harness.calculate_EER(got.numpy(), labels)
     print(f"{dtype}: {len(labels)} trials, max|dscore| {d.max().item():.2e}; EER oracle {eer_ref:.4f} % build {eer_got:.4f} %")
-    assert d.max().item() <= (1e-5 if dtype == "fp32" else SCORE_TOL)
+    assert d.max().item() <= (1e-5 if dtype == "fp32" else 5e-5)
     assert abs(eer_got - eer_ref) < 0.005 and f"{eer_got:.2f}" == f"{eer_ref:.2f}"
 
 

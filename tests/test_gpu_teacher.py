@@ -65,7 +65,7 @@ def test_config3_teacher_fp16_batch16_every_utterance(oracle48):
     assert elsewhere <= 3e-2, elsewhere
 
 
-@pytest.mark.parametrize("dtype", ["fp32"])
+@pytest.mark.parametrize("dtype", ["fp32", "fp16x3"])
 def test_config3_teacher_unconditional_parity_modes(oracle48, dtype):
     """The answer to "scores within 1e-3 on EVERY utterance" for config 3: the SAME 48 utterances,
     24 layers and lively head as the fp16 gate above, in the modes that carry fp32 accuracy through the trunk -- every
