@@ -58,10 +58,14 @@ PMC_FILES = {"conformer_student": "pmc_traffic.json", "xlsr_aasist": "pmc_traffi
 MFMA_FILES = {"conformer_student": "pmc_mfma.json", "xlsr_aasist": "pmc_mfma_teacher.json"}
 
 
-def time_steps(step, steps, warmup, use_dist, dist):
-    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+def time_steps(step, steps, warmup, use_dist, dist, join=None):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.
+    join: called after the K-th step, inside the timed region (a step that leaves work on a side stream: the current
+    stream waits for it, so the closing event and the synchronize see every step complete)."""
     for _ in range(warmup):
         step()
+    if join:
+        join()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -72,6 +76,8 @@ def time_steps(step, steps, warmup, use_dist, dist):
     out = None
     for _ in range(steps):
         out = step()
+    if join:
+        join()
     ev1.record()
     torch.cuda.synchronize()
     if use_dist:
@@ -189,6 +195,7 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32", "fp16x3"],
                     help="fp16 (default; no environment override) / bf16 matrix-core operands, fp32 = exact mode, fp16x3 = split precision")
     ap.add_argument("--cpu-sample", type=int, default=8, help="utterances timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-overlap", action="store_true", help="teacher: back-end on the trunk's stream (no head / trunk overlap across steps)")
     ap.add_argument("--no-config3", action="store_true", help="skip the teacher (BASELINE configs[2]/[3]) side measurement")
     ap.add_argument("--allow-parity-miss", action="store_true", help="report, do not fail, when the parity sample misses 1e-3")
     args = ap.parse_args()
@@ -211,18 +218,27 @@ def main():
     from afx.dist import all_gather_scores
 
     def make_step(w):
+        """One step = one forward of the hot path over the resident batch (+ the RCCL score all-gather when N > 1).  The
+        teacher's steps are issued the way the scoring loop issues them (afx.harness.produce_evaluation_file): graph
+        back-end of step i on the engine's side stream under the trunk of step i+1, scores read after the last step."""
         idx = torch.arange(rank * w["B"], (rank + 1) * w["B"], dtype=torch.int32, device="cuda")
+        overlapped = w["arch"] == "xlsr_aasist" and not args.no_overlap
 
         def step():
-            scores = w["eng"].forward(w["wave"])[:, 1]
-            if use_dist:
-                return all_gather_scores(idx, scores, world)
+            if not overlapped:
+                scores = w["eng"].forward(w["wave"])[:, 1]
+                return all_gather_scores(idx, scores, world) if use_dist else (idx, scores)
+            scores = w["eng"].forward_overlapped(w["wave"])[:, 1]
+            if use_dist:  # the collective follows the head on ITS stream: the next trunk does not wait for it
+                with torch.cuda.stream(w["eng"]._side):
+                    return all_gather_scores(idx, scores, world)
             return idx, scores
-        return step
+        return step, (w["eng"].join if overlapped else None)
 
     w = build(args.workload, args.dtype, args.batch, args.seconds, rank)
     arch, oname, n_layers, gflop, B, L, sd, eng, wave = (w[k] for k in ("arch", "oname", "n_layers", "gflop", "B", "L", "sd", "eng", "wave"))
-    elapsed, dev_ms, out = time_steps(make_step(w), args.steps, args.warmup, use_dist, dist)
+    w_step, w_join = make_step(w)
+    elapsed, dev_ms, out = time_steps(w_step, args.steps, args.warmup, use_dist, dist, join=w_join)
     if use_dist:
         assert out[0].numel() == world * B
     ms_per_step = elapsed / args.steps * 1e3
@@ -280,7 +296,8 @@ def main():
         del eng, wave, w
         torch.cuda.empty_cache()
         t = build("xlsr_aasist", args.dtype, None, 4.0, rank)
-        el, dms, _ = time_steps(make_step(t), args.steps, args.warmup, use_dist, dist)
+        t_step, t_join = make_step(t)
+        el, dms, _ = time_steps(t_step, args.steps, args.warmup, use_dist, dist, join=t_join)
         t_roof, t_break = roofline_of(t, "xlsr_aasist", args.dtype, args.steps)
         result["config3"] = {
             "workload": f"xlsr_aasist: XLSR_AASIST (24-layer XLS-R trunk), batch {t['B']} per GPU, 4 s clips @ 16 kHz, random-init weights"
@@ -289,6 +306,7 @@ def main():
             "global_batch": world * t["B"], "ms_per_step": round(el / args.steps * 1e3, 3),
             "device_ms_per_step": round(dms, 3), "model_tflops": round(world * t["B"] * args.steps / el * t["gflop"] / 1e3, 1),
             "dtype": args.dtype, "roofline": t_roof, "kernel_ms_per_step": t_break,
+            "issue": "back-end of step i on a side stream under the trunk of step i+1 (the scoring loop's form)" if t_join else "one stream",
         }
         if rank == 0 and world == 1 and args.cpu_sample > 0:
             # the same 8-utterance oracle sample as the headline.  Reported per utterance: with default-init heads the

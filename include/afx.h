@@ -81,6 +81,13 @@ size_t afx_workspace_bytes(afx_handle h, int B, int L);  /* scratch needed by on
  * (clips up to about 37 s); beyond either bound the call fails with a message, it never truncates. */
 int afx_forward(afx_handle h, const float* wave, int B, int L, float* logits, void* ws, size_t ws_bytes,
                 void* stream);
+/* The same forward in two calls, for scoring loops that overlap the back-end of one batch with the trunk of the next
+ * (main.py:199-221 scores batch after batch; nothing orders batch i's head before batch i+1's trunk but the one stream):
+ * afx_trunk_forward(ws) on stream A leaves the SSL features inside `ws`; afx_head_from_workspace(ws) on stream B -- after an
+ * event the caller records behind the trunk -- runs the back-end on them.  Two workspaces alternate; a workspace is reused
+ * for a trunk only after its head has finished.  Same kernels, same results as afx_forward, bit for bit. */
+int afx_trunk_forward(afx_handle h, const float* wave, int B, int L, void* ws, size_t ws_bytes, void* stream);
+int afx_head_from_workspace(afx_handle h, int B, int L, float* logits, void* ws, size_t ws_bytes, void* stream);
 /* SSL features only: feats device (B,T,1024) fp32 == extract_feat() of models/fe.py:17-21 */
 int afx_ssl_forward(afx_handle h, const float* wave, int B, int L, float* feats, void* ws, size_t ws_bytes,
                     void* stream);

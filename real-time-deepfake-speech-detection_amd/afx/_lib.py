@@ -41,6 +41,8 @@ SIGNATURES = {
     "afx_head_workspace_bytes": (_Z, [_P, _I, _I]),
     "afx_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
     "afx_ssl_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
+    "afx_trunk_forward": (_I, [_P, _P, _I, _I, _P, _Z, _P]),
+    "afx_head_from_workspace": (_I, [_P, _I, _I, _P, _P, _Z, _P]),
     "afx_head_forward": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
     "afx_ragged_workspace_bytes": (_Z, [_P, _I, _I]),
     "afx_forward_ragged": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int), _P, _P, _Z, _P]),

@@ -123,6 +123,50 @@ class Engine:
             check(l.afx_forward(self._h, ptr(x), B, L, ptr(out), ptr(ws), ws.numel(), self._stream()))
         return out
 
+    # ---- scoring-loop form: the back-end of batch i on a side stream under the trunk of batch i+1 -------------------
+    def forward_overlapped(self, wave):
+        """``forward(wave)`` split over two streams: the trunk on torch's current stream, the back-end on the engine's side
+        stream, two workspaces alternating -- the head of this batch runs while the NEXT call's trunk does (the AASIST
+        head is a tenth of the teacher's time on a third of the chip's CUs).  Same kernels and bits as ``forward``.
+        The returned logits are produced on the SIDE stream: call ``join()`` before reading them on the current stream
+        (afx.harness.produce_evaluation_file does, once, after its last batch)."""
+        x = self._wave(wave)
+        B, L = x.shape
+        l = lib()
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=self.device)
+                self._ov = [dict(ws=None, head_done=None), dict(ws=None, head_done=None)]
+                self._ov_i = 0
+            slot = self._ov[self._ov_i]
+            self._ov_i ^= 1
+            nbytes = l.afx_workspace_bytes(self._h, B, L)
+            if slot["ws"] is None or slot["ws"].numel() < nbytes:
+                if slot["head_done"] is not None:
+                    slot["head_done"].synchronize()
+                slot["ws"] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            elif slot["head_done"] is not None:
+                cur.wait_event(slot["head_done"])  # this workspace's previous head (two calls ago) must be done with it
+            ws = slot["ws"]
+            check(l.afx_trunk_forward(self._h, ptr(x), B, L, ptr(ws), ws.numel(), C.c_void_p(cur.cuda_stream)))
+            trunk_done = torch.cuda.Event()
+            trunk_done.record(cur)
+            out = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+            self._side.wait_event(trunk_done)
+            out.record_stream(self._side)
+            check(l.afx_head_from_workspace(self._h, B, L, ptr(out), ptr(ws), ws.numel(), C.c_void_p(self._side.cuda_stream)))
+            slot["head_done"] = torch.cuda.Event()
+            slot["head_done"].record(self._side)
+            self._last_head = slot["head_done"]
+        return out
+
+    def join(self):
+        """Make torch's current stream wait for every back-end forward_overlapped has put on the side stream."""
+        ev = getattr(self, "_last_head", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
     def ssl(self, wave):
         x = self._wave(wave)
         B, L = x.shape

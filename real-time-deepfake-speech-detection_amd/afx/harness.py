@@ -162,12 +162,17 @@ def produce_evaluation_file(dataset, model, device, save_path, batch_size, num_w
     current forward (the reference's ``batch_x.to(device)`` is blocking)."""
     model.eval()
     names, chunks = [], []
+    # models with a graph back-end (XLSR_AASIST) run it on a side stream under the next batch's trunk: the scores are only
+    # read after the last batch, so nothing waits for a head inside the loop
+    overlapped = getattr(model, "afx_arch", None) == "xlsr_aasist" and hasattr(model, "forward_overlapped")
     with torch.no_grad():
         loader = ((utt_id, batch_x) for utt_id, batch_x, _label in _loader(dataset, batch_size, num_workers))
         for utt_id, x in prefetch_to_device(loader, device):
-            out = model(x)
+            out = model.forward_overlapped(x) if overlapped else model(x)
             chunks.append(out[:, 1])  # bonafide score (main.py:211-212)
             names.extend(utt_id)
+        if overlapped:
+            model.join_overlapped()
     scores = torch.cat(chunks).cpu().numpy().ravel().tolist() if chunks else []
     write_score_file(save_path, names, scores)
     return names, scores

@@ -226,6 +226,19 @@ class AfxModule(nn.Module):
         eng = self._afx_engine()
         return eng.ssl_ragged(clips) if self.afx_arch == "ssl" else eng.forward_ragged(clips)
 
+    def forward_overlapped(self, x):
+        """``self(x)`` with the back-end of this batch on a side stream under the NEXT call's trunk (Engine.forward_overlapped);
+        the logits must not be read on the current stream before ``join_overlapped()``.  For scoring loops that collect
+        scores and read them once at the end (afx.harness.produce_evaluation_file); ``self(x)`` itself stays one stream."""
+        x = x.squeeze(-1) if x.ndim == 3 else x
+        self._afx_check(x)
+        return self._afx_engine().forward_overlapped(x)
+
+    def join_overlapped(self):
+        eng = self.__dict__.get("_afx_eng")
+        if eng is not None:
+            eng.join()
+
     def set_precision(self, dtype):
         """'fp16' (default) or 'bf16' matrix-core operands; 'fp16x3' (split precision, fp32-accurate, ~1/3 of the rate) or
         'fp32' (exact mode, 1/16) where every score must hold the tolerance whatever the checkpoint's top-k gaps."""

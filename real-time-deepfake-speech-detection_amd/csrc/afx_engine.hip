@@ -1173,6 +1173,33 @@ extern "C" int afx_forward(afx_handle h, const float* wave, int B, int L, float*
   return run_head(h, B, w.T[6], w, logits, s);
 }
 
+// The forward in two halves, so that a scoring loop can run the back-end of batch i on a second stream under the trunk of
+// batch i+1 (the AASIST head is 11 % of the teacher's time on at most 132 workgroups: alone it leaves half the chip idle):
+// afx_trunk_forward leaves the SSL features in the workspace, afx_head_from_workspace runs the back-end on them.  The caller
+// orders the two calls (an event between the streams) and alternates two workspaces; same kernels, same bits as afx_forward.
+extern "C" int afx_trunk_forward(afx_handle h, const float* wave, int B, int L, void* ws, size_t ws_bytes, void* stream) {
+  if (check_call(h, wave, B, L, ws, ws, true)) return 1;
+  Ws w;
+  const size_t needb = carve(h, B, L, 0, ws, &w);
+  if (ws_bytes < needb) return fail("afx_trunk_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
+  t_prof = h->prof;
+  t_s3planes = w.s3planes;
+  t_s3bytes = w.s3bytes;
+  return run_trunk(h, wave, B, L, w, (hipStream_t)stream);
+}
+extern "C" int afx_head_from_workspace(afx_handle h, int B, int L, float* logits, void* ws, size_t ws_bytes, void* stream) {
+  if (check_call(h, ws, B, L, logits, ws, true)) return 1;
+  if (h->cfg.arch == AFX_ARCH_SSL) return fail("afx_head_from_workspace: this handle has no back-end");
+  Ws w;
+  const size_t needb = carve(h, B, L, 0, ws, &w);
+  if (ws_bytes < needb) return fail("afx_head_from_workspace: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
+  if (w.T[6] < 1) return fail("afx_head_from_workspace: %d samples are too few for one output frame", L);
+  t_prof = h->prof;
+  t_s3planes = w.s3planes;
+  t_s3bytes = w.s3bytes;
+  return run_head(h, B, w.T[6], w, logits, (hipStream_t)stream);
+}
+
 // The path from the output of conv layer 5 on (conv layer 6, feature LayerNorm, projection, positional conv,
 // transformer layers, head): what a streaming caller runs every hop after it has produced only the NEW frames of
 // conv layers 0-5 (afx/streaming.py).  Same kernels, same order as afx_forward from that point on.

@@ -206,3 +206,39 @@ def test_teacher_to_student_layer_copy_like_main_kd():
         want_sd.update({pre_s + k[len(pre_t):]: v for k, v in tsd.items() if k.startswith(pre_t)})
     ref = omodels.conformer_forward(want_sd, wave)
     assert (got - ref).abs().max().item() <= 1e-3
+
+
+def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_path):
+    """main.py:199-221 scores batch after batch and reads the scores at the end; afx.harness.produce_evaluation_file issues
+    the AASIST back-end of batch i on a side stream under the trunk of batch i+1 (afx_trunk_forward /
+    afx_head_from_workspace, two workspaces alternating).  Same kernels on the same data: every score must equal the
+    one-stream forward's bit for bit, over more batches than workspaces, a ragged last batch and changing batch sizes."""
+    from afx import engine, harness, synth
+    from models.xlsr_aasist import My_XLSR_AASIST
+    sd = synth.model_state_dict("XLSR_AASIST", n_layers=2, head_scale=1.5)
+    eng = engine.Engine("xlsr_aasist", n_layers=2, dtype="fp16")
+    eng.load_state_dict(sd)
+    waves = [synth.waveforms(b, 16000, batch_idx=700 + i).cuda() for i, b in enumerate([5, 5, 5, 3, 7, 5, 1])]
+    want = [eng.forward(w).clone() for w in waves]
+    for _ in range(2):  # twice: the second pass starts from slots that have a pending head
+        got = [eng.forward_overlapped(w) for w in waves]
+        eng.join()
+        for g, w_ in zip(got, want):
+            assert torch.equal(g, w_)
+    assert torch.equal(eng.forward(waves[0]), want[0])  # and the one-stream call is unaffected afterwards
+
+    class Toy(torch.utils.data.Dataset):
+        def __len__(self):
+            return 13
+
+        def __getitem__(self, i):
+            return f"utt{i}", synth.waveforms(1, 16000, batch_idx=900 + i)[0], 0
+    model = My_XLSR_AASIST(device="cuda", ssl_cpkt_path=None, num_layers=2, order="first").to("cuda").eval()
+    model.load_state_dict(sd)
+    names, scores = harness.produce_evaluation_file(Toy(), model, "cuda", str(tmp_path / "s.txt"), batch_size=4, num_workers=0)
+    with torch.no_grad():
+        ref = torch.cat([model(torch.stack([Toy()[i][1] for i in range(j, min(j + 4, 13))]).cuda())[:, 1] for j in range(0, 13, 4)]).cpu()
+    assert names == [f"utt{i}" for i in range(13)]
+    assert torch.equal(torch.tensor(scores, dtype=torch.float32), ref)
+    assert (tmp_path / "s.txt").read_text().splitlines()[0].startswith("utt0 ")
+
