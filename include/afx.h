@@ -116,6 +116,20 @@ int afx_tail_forward(afx_handle h, const void* conv5_h, int B, int T5, float* lo
  * passes a view, no copy per hop */
 int afx_tail_forward_strided(afx_handle h, const void* conv5_h, long batch_stride, int B, int T5, float* logits, void* ws,
                              size_t ws_bytes, void* stream);
+/* ---- KV-cached streaming mode (BASELINE config 5 as named: "250 ms chunks with cached SSL-encoder KV state") ----------
+ * NOT A REFERENCE FUNCTION: the reference's trunk is bidirectional over the clip, an encoder that sees every frame once
+ * -- when its chunk arrives -- is a different model (block-causal: a chunk's frames attend to the chunk and to the cached
+ * keys / values of the 15 chunks before it, the positional conv sees no frame beyond the chunk).  Parity target: the
+ * build's own offline restatement oracle/streaming.py.  An afx_kv holds the per-stream state of
+ * n_streams lock-stepped streams (K / V rings of every layer, the positional conv's left context, the feature window);
+ * afx_kv_step consumes the NEW frames of conv layer 6 of every stream, (n_streams, n, 512) fp32 with 1 <= n <= 16, and
+ * returns the back-end's logits on the window that ends with this chunk. */
+typedef struct afx_kv afx_kv;
+int afx_kv_create(afx_handle h, int n_streams, afx_kv** out);
+void afx_kv_destroy(afx_kv* kv);
+size_t afx_kv_state_bytes(const afx_kv* kv);
+size_t afx_kv_workspace_bytes(const afx_kv* kv, int n_frames);
+int afx_kv_step(afx_kv* kv, const float* feats6, int n_frames, float* logits, void* ws, size_t ws_bytes, void* stream);
 /* back-end alone from given SSL features (B,T,1024) fp32 -> logits (B,2) */
 int afx_head_forward(afx_handle h, const float* feats, int B, int T, float* logits, void* ws, size_t ws_bytes,
                      void* stream);

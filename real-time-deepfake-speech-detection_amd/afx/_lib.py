@@ -52,6 +52,11 @@ SIGNATURES = {
     "afx_tail_forward_strided": (_I, [_P, _P, _L, _I, _I, _P, _P, _Z, _P]),
     "afx_conformer_forward": (_I, [_P, _P, _I, _I, _P, _P, _P, _Z, _P]),
     "afx_engine_set": (_I, [_P, C.c_char_p, _I]),
+    "afx_kv_create": (_I, [_P, _I, C.POINTER(_P)]),
+    "afx_kv_destroy": (None, [_P]),
+    "afx_kv_state_bytes": (_Z, [_P]),
+    "afx_kv_workspace_bytes": (_Z, [_P, _I]),
+    "afx_kv_step": (_I, [_P, _P, _I, _P, _P, _Z, _P]),
     "afx_enable_taps": (_I, [_P, _I]),
     "afx_tap": (_I, [_P, C.c_char_p, _P, _Z, C.POINTER(_Z), _P]),
     "afx_profile_begin": (_I, [_P]),

@@ -244,6 +244,10 @@ class Engine:
                                              self._stream()))
         return out
 
+    def kv_state(self, n_streams):
+        """Per-stream state of the KV-cached streaming mode (afx_kv_create): see ``KVState``."""
+        return KVState(self, n_streams)
+
     def conformer(self, tokens):
         """MyConformer.forward (models/conformer_baseline.py:22-29): tokens (B,T,emb) fp32 -> (logits (B,2), embedding (B,emb))."""
         self._on_device(tokens, "tokens")
@@ -313,3 +317,42 @@ class Engine:
             out = torch.empty(n.value, dtype=torch.float32, device=self.device)
             check(lib().afx_tap(self._h, name.encode(), ptr(out), n.value, C.byref(n), self._stream()))
         return out
+
+
+class KVState:
+    """State of ``n_streams`` lock-stepped streams in the KV-cached streaming mode (BASELINE config 5 as named; a labelled,
+    NON-reference mode -- include/afx.h, oracle/streaming.py): the K / V rings of every transformer layer, the positional
+    conv's left context and the feature window live in the library object; ``step`` consumes the new conv-layer-6 frames
+    of every stream and returns the back-end's logits on the window that ends with this chunk."""
+
+    def __init__(self, engine, n_streams):
+        self.engine, self.S = engine, int(n_streams)
+        self._k = C.c_void_p()
+        with torch.cuda.device(engine.device):
+            check(lib().afx_kv_create(engine._h, self.S, C.byref(self._k)))
+        self.state_bytes = lib().afx_kv_state_bytes(self._k)
+
+    def __del__(self):
+        k = getattr(self, "_k", None)
+        if k is not None and k.value and lib is not None:
+            try:
+                lib().afx_kv_destroy(k)
+            except Exception:
+                pass
+            self._k = None
+
+    def step(self, feats6):
+        """feats6: (S, n, 512) fp32, the n (1..16) NEW frames of conv layer 6 -> logits (S, 2)."""
+        eng = self.engine
+        eng._on_device(feats6, "conv-layer-6 frames")
+        f = feats6.to(torch.float32).contiguous()
+        if f.ndim != 3 or f.shape[0] != self.S or f.shape[2] != 512:
+            raise ValueError(f"expected ({self.S}, n, 512) frames, got {tuple(f.shape)}")
+        n = f.shape[1]
+        l = lib()
+        with torch.cuda.device(eng.device):
+            ws = eng._workspace(max(l.afx_kv_workspace_bytes(self._k, n), 256))
+            out = torch.empty(self.S, 2, dtype=torch.float32, device=eng.device)
+            check(l.afx_kv_step(self._k, ptr(f), n, ptr(out), ptr(ws), ws.numel(), eng._stream()))
+        return out
+

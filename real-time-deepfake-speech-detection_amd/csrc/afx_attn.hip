@@ -27,10 +27,22 @@ constexpr int ATT_VT_STRIDE = 232;  // halfs per V^T row: 464 B, conflict-free d
 // NW waves per workgroup: the 16-query tiles of a head are dealt to the waves round-robin, so the compute phase is
 // ceil(tiles / NW) tiles long -- 13 tiles (T = 199): 4 with four waves, 2 with seven (and 1 when the tiles are split over
 // two workgroups, B x H < 256); the staging loop is spread over all threads.
-template <class HT, int KS, int NW>  // KS = number of 32-key steps actually computed
+// RING (the KV-cached streaming mode, afx_kv_step -- NOT a reference function): `qkv` is a per-stream ring of KS*32 slots
+// (q | k | v rows as the QKV product wrote them) in 16-slot groups, one group per 250-ms chunk; group gidx holds ring.cnt[gidx]
+// valid frames (the rest of its slots, and groups never written, are masked).  Attention has no positional term, so the
+// order of the keys in the ring does not matter: the ONE query tile ring.q_tile (the newest chunk's group) attends to every
+// valid slot -- its own chunk and the cached K / V of the chunks before it.  Output row = slot - 16 q_tile of a 16-row
+// block per stream.
+struct MhsaRing {
+  int q_tile;
+  unsigned char cnt[16];
+};
+template <class HT, int KS, int NW, bool RING = false>  // KS = number of 32-key steps actually computed
 __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typename HT::T* __restrict__ qkv,
                                                    typename HT::T* __restrict__ out, int T, int H, float scale,
-                                                   const int* __restrict__ lens) {
+                                                   const int* __restrict__ lens, MhsaRing ring) {
+  constexpr int ATT_KEYS = KS <= 7 ? afx::ATT_KEYS : KS * 32;             // (shadow the file-level capacity: 8 steps = 256 slots)
+  constexpr int ATT_VT_STRIDE = KS <= 7 ? afx::ATT_VT_STRIDE : KS * 32 + 8;  // 264 halfs = 132 words: conflict-free as 116 is
   typedef typename HT::T Tt;
   typedef typename HT::V8 V8;
   typedef typename HT::V4 V4;
@@ -66,7 +78,8 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typ
       kreg[it] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
       for (int i = 0; i < 8; ++i) vreg[it][i] = (Tt)0.f;
-      if (key < T && !(MHSA_DBG & 1)) {
+      const bool live = RING ? (key & 15) < ring.cnt[(key >> 4) & 15] : key < T;
+      if (live && !(MHSA_DBG & 1)) {
         kreg[it] = *(const u32x4*)(kbase + (long)key * ld + c * 8);
         vreg[it] = *(const V8*)(vbase + (long)key * ld + c * 8);
       }
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typ
       }
     }
   }
-  for (int i = tid; i < KEYS; i += 64 * NW) mask_lds[i] = i < T ? 0.f : -1e30f;
+  for (int i = tid; i < KEYS; i += 64 * NW) mask_lds[i] = (RING ? (i & 15) < ring.cnt[(i >> 4) & 15] : i < T) ? 0.f : -1e30f;
   __syncthreads();
   if (MHSA_DBG & 2) return;
 
@@ -90,8 +103,8 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typ
   // at small batches B x H workgroups do not fill the chip (B = 16: 256 of them for 256 CUs x 2 slots)
   const int nqt_all = (T + 15) >> 4;
   const int per_z = (nqt_all + (int)gridDim.z - 1) / (int)gridDim.z;
-  const int qt_first = (int)blockIdx.z * per_z;
-  const int nqt = min(nqt_all, qt_first + per_z);
+  const int qt_first = RING ? ring.q_tile : (int)blockIdx.z * per_z;
+  const int nqt = RING ? ring.q_tile + 1 : min(nqt_all, qt_first + per_z);
   auto load_q = [&](int qt, V8 (&f)[2]) {
     int qrow = qt * 16 + ql;
     qrow = qrow < T ? qrow : T - 1;
@@ -226,7 +239,8 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typ
           hv[r] = (Tt)va[r];
           hv[4 + r] = (Tt)vb[r];
         }
-        *(V8*)(out + ((long)b * Trow + q) * (H * 64) + h * 64 + np * 32 + cb) = hv;
+        const long orow = RING ? (long)b * 16 + (q - 16 * ring.q_tile) : (long)b * Trow + q;
+        *(V8*)(out + orow * (H * 64) + h * 64 + np * 32 + cb) = hv;
       }
     }
   }
@@ -410,13 +424,32 @@ static void launch_mhsa_t(const void* qkv, void* out, int B, int T, int H, float
   if (T > ATT_KEYS || g_mhsa_force_long)
     hipLaunchKernelGGL((mhsa_long_kernel<HT>), dim3(H, B, (T + 63) / 64), blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
   else if (T <= 64)
-    hipLaunchKernelGGL((mhsa_kernel<HT, 2, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
+    hipLaunchKernelGGL((mhsa_kernel<HT, 2, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens, MhsaRing{});
   else if (T <= 128)
-    hipLaunchKernelGGL((mhsa_kernel<HT, 4, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
+    hipLaunchKernelGGL((mhsa_kernel<HT, 4, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens, MhsaRing{});
   else if (g_mhsa_waves == 4)
-    hipLaunchKernelGGL((mhsa_kernel<HT, 7, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
+    hipLaunchKernelGGL((mhsa_kernel<HT, 7, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens, MhsaRing{});
   else
-    hipLaunchKernelGGL((mhsa_kernel<HT, 7, 7>), grid, dim3(448), 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
+    hipLaunchKernelGGL((mhsa_kernel<HT, 7, 7>), grid, dim3(448), 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens, MhsaRing{});
+}
+
+// KV-cached streaming attention (see MhsaRing): ring (S, 256 slots, 3 H 64) operand type, out (S, 16, H 64); cnt[16] = valid
+// frames per 16-slot group, q_tile = the group of the newest chunk.
+const char* launch_mhsa_ring(const void* ring, void* out, int S, int H, int q_tile, const int* cnt, int dtype, hipStream_t s) {
+  if (S <= 0 || S > 65535 || H <= 0 || q_tile < 0 || q_tile > 15) return "mhsa_ring: bad shape";
+  if (dtype != DT_FP16 && dtype != DT_BF16) return "mhsa_ring: half-precision operands only";
+  MhsaRing r;
+  r.q_tile = q_tile;
+  for (int i = 0; i < 16; ++i) {
+    if (cnt[i] < 0 || cnt[i] > 16) return "mhsa_ring: a group holds at most 16 frames";
+    r.cnt[i] = (unsigned char)cnt[i];
+  }
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((mhsa_kernel<BF16, 8, 4, true>), dim3(H, S, 1), dim3(256), 0, s, (const BF16::T*)ring, (BF16::T*)out, 256, H, 0.125f, nullptr, r);
+  else
+    hipLaunchKernelGGL((mhsa_kernel<FP16, 8, 4, true>), dim3(H, S, 1), dim3(256), 0, s, (const FP16::T*)ring, (FP16::T*)out, 256, H, 0.125f, nullptr, r);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
 
 const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t s, const int* lens) {

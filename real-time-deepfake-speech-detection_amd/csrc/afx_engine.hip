@@ -5,6 +5,7 @@
 // copies inside afx_forward (it can be captured into a hipGraph by the caller).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1146,6 +1147,188 @@ static int run_head(afx_engine* e, int B, int T, Ws& w, float* logits, hipStream
     return 0;
   }
   return fail("afx_forward: this handle is an SSL feature extractor; use afx_ssl_forward");
+}
+
+__global__ void f32_to_half_kernel(const float* in, uint16_t* out, size_t n, int is_bf16);  // (defined below)
+
+// ---------------------------------------------------------------------------------
+// KV-cached streaming mode (BASELINE config 5 as named: "250 ms chunks with cached SSL-encoder KV state").
+// NOT A REFERENCE FUNCTION.  The reference's trunk is bidirectional over the clip (full self-attention, a centred
+// k = 128 positional conv, models/fe.py:17-21), so an encoder that sees every frame ONCE, when its chunk arrives, is
+// a different model; SURVEY.md section 7 scopes it as a labelled mode whose parity target is this build's own offline
+// restatement of the same function (oracle/streaming.py), not the reference.  The function, per chunk c of n_c frames
+// (the frames of conv layer 6 that became computable with the chunk's samples):
+//   * conv feature extractor, feature LayerNorm, projection: frame-local -- exact;
+//   * positional conv: frame t of chunk c sees projected frames [t - 64, end of chunk c] (left context cached, the
+//     right context beyond the chunk is zero, as beyond a clip's end);
+//   * every transformer layer: the chunk's frames are the queries; keys / values are the chunk itself and the cached
+//     K / V of the 15 chunks before it (16 chunks = 4 s of context), written once when their chunk passed;
+//   * final LayerNorm; the back-end (AASIST / Conformer head) scores the window of the last <= 200 feature frames.
+// State per stream: 24 x 256 x 3072 halfs of [q | k | v] rows (16-slot groups, one per chunk), 64 projected frames, the
+// feature window.  The whole step runs on new frames only: S x n_c rows through the products, one query tile per
+// (stream, head) in the attention.
+// ---------------------------------------------------------------------------------
+constexpr int kKvGroups = 16, kKvSlots = 256, kKvHist = 64, kKvFeat = 208, kKvWindow = 200;
+struct afx_kv {
+  afx_engine* e;
+  int S;
+  long hop = 0;
+  int cnt[kKvGroups];
+  int nfeat = 0, pp = 0;
+  void* rings = nullptr;   // (layers, S, 256, 3072) operand type
+  void* hist = nullptr;    // (S, 64, 1024) operand type: the newest projected frames (positional conv's left context)
+  float* feat[2] = {nullptr, nullptr};  // (S, 208, 1024) fp32, right-aligned window, ping-pong
+};
+struct KvWs {
+  void *feats_h, *xpad, *hbuf, *att, *ff;
+  float *xp, *x;
+  Ws head;
+};
+static size_t kv_carve(const afx_engine* e, int S, int n, int Th, void* base, KvWs* k) {
+  Carver c(base);
+  const size_t hs = dtype_size(e->dt), M = (size_t)S * n, Tp = kKvHist + n;
+  k->feats_h = c.take(M * kC * hs);
+  k->xpad = c.take((size_t)S * (Tp + kPosK) * kD * hs);
+  k->xp = (float*)c.take((size_t)S * Tp * kD * 4);
+  k->x = (float*)c.take(M * kD * 4);
+  k->hbuf = c.take(M * kD * hs);
+  k->att = c.take((size_t)S * 16 * kD * hs);
+  k->ff = c.take(M * kF * hs);
+  c.off = (c.off + 255) & ~(size_t)255;
+  const size_t head_bytes = carve(e, S, 0, Th, base ? (char*)base + c.off : nullptr, &k->head);
+  return c.off + head_bytes + 256;
+}
+extern "C" int afx_kv_create(afx_handle h, int n_streams, afx_kv** out) {
+  if (!h || !out || n_streams <= 0) return fail("afx_kv_create: bad argument");
+  if (!h->finalized) return fail("afx_kv_create: weights not finalized");
+  if (h->cfg.arch != AFX_ARCH_XLSR_AASIST && h->cfg.arch != AFX_ARCH_CONFORMER) return fail("afx_kv_create: a handle with a trunk and a back-end");
+  if (h->dt == DT_FP32) return fail("afx_kv_create: the KV-cached mode runs the half-precision kernels (fp16 / bf16 engines)");
+  if (h->cfg.extractor_mode != AFX_EXTRACTOR_LAYER_NORM || h->cfg.pre_emphasis) return fail("afx_kv_create: layer_norm extractor without fused pre-emphasis");
+  afx_kv* k = new afx_kv();
+  k->e = h;
+  k->S = n_streams;
+  for (int i = 0; i < kKvGroups; ++i) k->cnt[i] = 0;
+  const size_t hs = h->hsz, ring = (size_t)h->cfg.n_layers * n_streams * kKvSlots * 3 * kD * hs, hist = (size_t)n_streams * kKvHist * kD * hs,
+               feat = (size_t)n_streams * kKvFeat * kD * 4;
+  bool ok = hipMalloc(&k->rings, ring) == hipSuccess && hipMalloc(&k->hist, hist) == hipSuccess &&
+            hipMalloc((void**)&k->feat[0], feat) == hipSuccess && hipMalloc((void**)&k->feat[1], feat) == hipSuccess;
+  // the history starts as silence-before-the-stream (zero left padding); ring slots are masked until written
+  ok = ok && hipMemset(k->rings, 0, ring) == hipSuccess && hipMemset(k->hist, 0, hist) == hipSuccess &&
+       hipMemset(k->feat[0], 0, feat) == hipSuccess && hipMemset(k->feat[1], 0, feat) == hipSuccess;
+  if (!ok) {
+    (void)hipFree(k->rings); (void)hipFree(k->hist); (void)hipFree(k->feat[0]); (void)hipFree(k->feat[1]);
+    delete k;
+    return fail("afx_kv_create: device allocation failed (%zu bytes per stream)", (ring + hist + 2 * feat) / n_streams);
+  }
+  *out = k;
+  return 0;
+}
+extern "C" void afx_kv_destroy(afx_kv* k) {
+  if (!k) return;
+  (void)hipFree(k->rings); (void)hipFree(k->hist); (void)hipFree(k->feat[0]); (void)hipFree(k->feat[1]);
+  delete k;
+}
+extern "C" size_t afx_kv_state_bytes(const afx_kv* k) {
+  if (!k) return 0;
+  return (size_t)k->e->cfg.n_layers * k->S * kKvSlots * 3 * kD * k->e->hsz + (size_t)k->S * kKvHist * kD * k->e->hsz + 2 * (size_t)k->S * kKvFeat * kD * 4;
+}
+extern "C" size_t afx_kv_workspace_bytes(const afx_kv* k, int n_frames) {
+  if (!k || n_frames <= 0 || n_frames > 16) return 0;
+  KvWs w;
+  return kv_carve(k->e, k->S, n_frames, kKvWindow, nullptr, &w);
+}
+// feats6: device (S, n, 512) fp32 -- the n NEW frames of conv layer 6 (conv + LayerNorm + GELU applied: what the conv stack
+// hands the feature LayerNorm), 1 <= n <= 16.  logits: device (S, 2): the back-end's logits on the window that ends with this chunk.
+extern "C" int afx_kv_step(afx_kv* k, const float* feats6, int n, float* logits, void* ws, size_t ws_bytes, void* stream) {
+  if (n < 1 || n > 16) return fail("afx_kv_step: a chunk brings 1..16 frames (got %d)", n);
+  if (!k || !feats6 || !logits || !ws) return fail("afx_kv_step: null argument");
+  afx_engine* e = k->e;
+  const int S = k->S, dt = e->dt, M = S * n, Tp = kKvHist + n, group = (int)(k->hop % kKvGroups);
+  const int Th = std::min(k->nfeat + n, kKvWindow);
+  if (e->cfg.arch == AFX_ARCH_XLSR_AASIST && Th < 6) return fail("afx_kv_step: the AASIST head needs at least 6 frames in the window");
+  KvWs w;
+  const size_t needb = kv_carve(e, S, n, Th, ws, &w);
+  if (ws_bytes < needb) return fail("afx_kv_step: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
+  hipStream_t s = (hipStream_t)stream;
+  t_prof = e->prof;
+  t_s3planes = nullptr;
+  const size_t hs = e->hsz;
+  k->cnt[group] = n;
+  // feature LayerNorm -> operand type
+  {
+    RowNormArgs a = plain_norm(feats6, kC, M, kC, e->F("ssl.layer_norm.weight"), e->F("ssl.layer_norm.bias"));
+    a.out_h = w.feats_h; a.ldo_h = kC;
+    KOK(launch_rownorm(a, dt, s));
+  }
+  // positional conv operand: [64 zero rows | 64 cached projected frames | the chunk | 64 zero rows] per stream
+  const size_t xrow = (size_t)kD * hs, xpad_pitch = (size_t)(Tp + kPosK) * xrow;
+  HIP_OK(hipMemcpy2DAsync((char*)w.xpad + kPosPad * xrow, xpad_pitch, k->hist, kKvHist * xrow, kKvHist * xrow, S, hipMemcpyDeviceToDevice, s));
+  {
+    GemmArgs g = plain_gemm(w.feats_h, kC, e->projw, kC, M, kD, kC);
+    g.rpb = n; g.a_batch = (long)n * kC; g.a_row = kC;
+    g.bias = e->F("ssl.post_extract_proj.bias");
+    g.out_f = w.xp; g.ldo_f = kD; g.o_batch_rows = Tp; g.o_row_off = kKvHist;
+    g.out_h = w.xpad; g.ldo_h = kD; g.oh_batch_rows = Tp + kPosK; g.oh_row_off = kPosPad + kKvHist;
+    KOK(launch_gemm(g, dt, 1, s));
+    KOK(timed(PC_MISC, 0, s, [&] { return launch_zero_pad_rows(w.xpad, S, Tp, kD, kPosPad, kPosK - kPosPad, dt, s, nullptr); }));
+  }
+  {
+    PosConvArgs pc;
+    memset(&pc, 0, sizeof pc);
+    pc.xpad = w.xpad; pc.xpad_batch = (long)(Tp + kPosK) * kD; pc.W = e->posw; pc.bias = e->F("ssl.encoder.pos_conv.0.bias");
+    pc.x = w.xp; pc.B = S; pc.T = Tp;
+    KOK(timed(PC_POSCONV, 2.0 * S * Tp * kD * (kD / kPosG) * kPosK, s, [&] { return launch_posconv(pc, dt, s); }));
+  }
+  // the newest 64 projected frames become the next chunk's left context; the chunk's rows leave the padded layout
+  HIP_OK(hipMemcpy2DAsync(k->hist, kKvHist * xrow, (char*)w.xpad + (size_t)(kPosPad + n) * xrow, xpad_pitch, kKvHist * xrow, S, hipMemcpyDeviceToDevice, s));
+  HIP_OK(hipMemcpy2DAsync(w.x, (size_t)n * kD * 4, w.xp + (size_t)kKvHist * kD, (size_t)Tp * kD * 4, (size_t)n * kD * 4, S, hipMemcpyDeviceToDevice, s));
+  for (int l = 0; l < e->cfg.n_layers; ++l) {
+    const std::string P = "ssl.encoder.layers." + std::to_string(l) + ".";
+    void* ring = (char*)k->rings + (size_t)l * S * kKvSlots * 3 * kD * hs;
+    RowNormArgs n1 = plain_norm(w.x, kD, M, kD, e->F(P + "self_attn_layer_norm.weight"), e->F(P + "self_attn_layer_norm.bias"));
+    n1.out_h = w.hbuf; n1.ldo_h = kD;
+    KOK(launch_rownorm(n1, dt, s));
+    // q | k | v of the chunk go straight into its 16-slot group of the ring (row remap of the epilogue): K / V are cached by being written
+    GemmArgs q = plain_gemm(w.hbuf, kD, e->wqkv[l], kD, M, 3 * kD, kD);
+    q.rpb = n; q.a_batch = (long)n * kD; q.a_row = kD;
+    q.bias = e->bqkv[l];
+    q.out_h = ring; q.ldo_h = 3 * kD; q.oh_batch_rows = kKvSlots; q.oh_row_off = group * 16;
+    KOK(launch_gemm(q, dt, 1, s));
+    KOK(timed(PC_MHSA, 4.0 * S * kH * 16.0 * kKvSlots * 64, s, [&] { return launch_mhsa_ring(ring, w.att, S, kH, group, k->cnt, dt, s); }));
+    GemmArgs o = plain_gemm(w.att, kD, e->wo[l], kD, M, kD, kD);
+    o.rpb = n; o.a_batch = 16L * kD; o.a_row = kD; o.o_batch_rows = n;
+    o.bias = e->F(P + "self_attn.out_proj.bias"); o.resid = w.x; o.ldr = kD; o.out_f = w.x; o.ldo_f = kD;
+    KOK(launch_gemm(o, dt, 1, s));
+    RowNormArgs n2 = plain_norm(w.x, kD, M, kD, e->F(P + "final_layer_norm.weight"), e->F(P + "final_layer_norm.bias"));
+    n2.out_h = w.hbuf; n2.ldo_h = kD;
+    KOK(launch_rownorm(n2, dt, s));
+    GemmArgs f1 = plain_gemm(w.hbuf, kD, e->w1[l], kD, M, kF, kD);
+    f1.bias = e->F(P + "fc1.bias"); f1.act = ACT_GELU; f1.out_h = w.ff; f1.ldo_h = kF;
+    KOK(launch_gemm(f1, dt, 1, s));
+    GemmArgs f2 = plain_gemm(w.ff, kF, e->w2[l], kF, M, kD, kF);
+    f2.bias = e->F(P + "fc2.bias"); f2.resid = w.x; f2.ldr = kD; f2.out_f = w.x; f2.ldo_f = kD;
+    KOK(launch_gemm(f2, dt, 1, s));
+  }
+  // final LayerNorm: the chunk's features join the right-aligned window (old frames move up by n in the other buffer)
+  float *cur = k->feat[k->pp], *nxt = k->feat[k->pp ^ 1];
+  const size_t frow = (size_t)kD * 4, fpitch = (size_t)kKvFeat * frow;
+  HIP_OK(hipMemcpy2DAsync(nxt, fpitch, (char*)cur + (size_t)n * frow, fpitch, (size_t)(kKvFeat - n) * frow, S, hipMemcpyDeviceToDevice, s));
+  {
+    RowNormArgs nf = plain_norm(w.x, kD, M, kD, e->F("ssl.encoder.layer_norm.weight"), e->F("ssl.encoder.layer_norm.bias"));
+    nf.out_f = nxt; nf.ldo_f = kD; nf.rpb = n; nf.o_batch_rows = kKvFeat; nf.o_row_off = kKvFeat - n;
+    KOK(launch_rownorm(nf, dt, s));
+  }
+  k->pp ^= 1;
+  k->nfeat = std::min(k->nfeat + n, kKvFeat);
+  // back-end on the window of the last Th frames
+  HIP_OK(hipMemcpy2DAsync(w.head.ssl_f, (size_t)Th * frow, (char*)nxt + (size_t)(kKvFeat - Th) * frow, fpitch, (size_t)Th * frow, S, hipMemcpyDeviceToDevice, s));
+  if (e->cfg.arch == AFX_ARCH_CONFORMER) {
+    hipLaunchKernelGGL(f32_to_half_kernel, dim3(1024), dim3(256), 0, s, w.head.ssl_f, (uint16_t*)w.head.ssl_h, (size_t)S * Th * kD, dt == AFX_DT_BF16 ? 1 : 0);
+    HIP_OK(hipGetLastError());
+  }
+  k->hop += 1;
+  if (e->taps_on && tap(e, "ssl", w.head.ssl_f, (size_t)S * Th * kD, false, s)) return 1;
+  return run_head(e, S, Th, w.head, logits, s);
 }
 
 #undef launch_gemm

@@ -131,6 +131,22 @@ for arch, prefix in ((AAS, "xlsr_aasist"), (CONF, "conformer"), (SSL, "conformer
             else:
                 fails(lib.afx_tail_forward_strided(h, ptr(c5), 2 * T5 * 512, B, T5, ptr(logits), ptr(ws_for(nt)), nt, None), "packed window")
             fails(lib.afx_tail_forward_strided(h, ptr(c5), 8, B, T5, ptr(logits), ptr(ws_for(nt)), nt, None), "shorter than a window")
+            if dtype in (0, 1):  # KV-cached streaming mode: state object, 20 chunks (the 16-group ring wraps, the window fills)
+                kv = P()
+                ok(lib.afx_kv_create(h, B, C.byref(kv)), "kv create")
+                assert lib.afx_kv_state_bytes(kv) > 0
+                for hop in range(20):
+                    nfr = 12 + (hop % 2)
+                    f6 = np.zeros((B, nfr, 512), np.float32)
+                    nk = lib.afx_kv_workspace_bytes(kv, nfr)
+                    ok(lib.afx_kv_step(kv, ptr(f6), nfr, ptr(logits), ptr(ws_for(nk)), nk, None), "kv step")
+                f6 = np.zeros((B, 17, 512), np.float32)
+                fails(lib.afx_kv_step(kv, ptr(f6), 17, ptr(logits), ptr(ws_for(nk)), nk, None), "1..16 frames")
+                fails(lib.afx_kv_step(kv, ptr(f6), 12, ptr(logits), ptr(ws_for(64)), 64, None), "workspace too small")
+                lib.afx_kv_destroy(kv)
+            elif dtype == 2:
+                kv = P()
+                fails(lib.afx_kv_create(h, B, C.byref(kv)), "half-precision")
             if arch == CONF:
                 tok = np.zeros((B, T, 144), np.float32)
                 emb = np.zeros((B, 144), np.float32)

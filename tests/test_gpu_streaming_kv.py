@@ -1,0 +1,88 @@
+"""KV-cached streaming mode (BASELINE config 5 as named) against its OWN offline restatement -- a labelled, non-reference
+mode (afx/streaming.py::KVCachedScorer, include/afx.h afx_kv_*, oracle/streaming.py): block-causal
+attention over the cached keys / values of the last 16 chunks, new frames only through the trunk.  Asserted at EVERY hop:
+the scores of the GPU path equal the fp32 CPU restatement's within the 1e-3 score tolerance, from the first chunk (empty
+caches, a 12-frame window) through ring wrap-around (more than 16 chunks) and the full 200-frame window."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("arch,name,kw", [("conformer", "ConformerModel", dict(n_encoders=2)), ("xlsr_aasist", "XLSR_AASIST", {})])
+def test_kv_cached_streaming_equals_its_offline_block_causal_restatement(arch, name, kw):
+    """Every hop, every stream.  Conformer head: |dscore| <= 1e-3.  AASIST head: the same three-part statement as the offline
+    teacher's (tests/test_gpu_teacher.py) -- feature window within 1e-3 relative L2 of the restatement's (fp16 operand rounding),
+    the back-end on the GPU's own window equal to the oracle back-end to 1e-5, and end to end within 1e-3 wherever the
+    reference's GraphPool keeps its (discontinuous) top-k decisions under that rounding; a coarse bound elsewhere."""
+    from afx import engine, synth
+    from afx.streaming import KVCachedScorer
+    from oracle import aasist as oa
+    from oracle import models as om
+    from oracle import streaming as ostream
+    n_layers, S, hop, hops = 2, 3, 4000, 21  # 21 chunks: the 16-group ring wraps, the 200-frame window fills and slides
+    sd = synth.model_state_dict(name, n_layers=n_layers, **kw)
+    eng = engine.Engine(arch, n_layers=n_layers, dtype="fp16", **({"conf_blocks": 2} if arch == "conformer" else {}))
+    eng.load_state_dict(sd)
+    stream = torch.cat([synth.waveforms(S, hop, batch_idx=3000 + i) for i in range(hops)], dim=1)  # (S, hops * hop)
+    wins = []
+    want, sizes = ostream.block_causal_scores(sd, stream, hop, windows=wins)
+    assert sizes[:4] == [12, 12, 13, 12] and sum(sizes) == 262
+    _ssl, head = om.split(sd)
+    sc = KVCachedScorer(eng, sd, S, window=64000, hop=hop)
+    eng.enable_taps()
+    got, kept, worst_kept, worst_other, worst_feat, worst_backend = [], 0, 0.0, 0.0, 0.0, 0.0
+    for i in range(hops):
+        s = sc.push(stream[:, i * hop:(i + 1) * hop].cuda())
+        assert s is not None and s.shape == (S,)
+        got.append(s.cpu())
+        d = (got[-1] - want[i][:, 1]).abs()
+        f = eng.tap("ssl").cpu().reshape(wins[i].shape)
+        worst_feat = max(worst_feat, max(((f[j] - wins[i][j]).norm() / wins[i][j].norm()).item() for j in range(S)))
+        if arch == "conformer":
+            kept += S
+            worst_kept = max(worst_kept, d.max().item())
+            continue
+        t_ref, t_mid = {}, {}
+        oa.aasist_backend(head, wins[i], t_ref)
+        mid = oa.aasist_backend(head, f, t_mid)
+        worst_backend = max(worst_backend, (got[-1] - mid[:, 1]).abs().max().item())
+        for j in range(S):
+            same = all(torch.equal(t_ref["pool_idx"][p][j], t_mid["pool_idx"][p][j]) for p in t_ref["pool_idx"])
+            kept += same
+            if same:
+                worst_kept = max(worst_kept, d[j].item())
+            else:
+                worst_other = max(worst_other, d[j].item())
+    eng.enable_taps(False)
+    assert sc.frames == 262
+    print(f"{arch}: {hops} hops x {S} streams vs the offline block-causal restatement: feature window rel L2 <= {worst_feat:.1e}; "
+          f"|dscore| <= {worst_kept:.1e} on the {kept} of {hops * S} (hop, stream) pairs that keep every top-k decision, "
+          f"<= {worst_other:.1e} elsewhere; back-end alone <= {worst_backend:.1e}; state {sc.kv.state_bytes / S / 1e6:.1f} MB per stream")
+    assert worst_feat <= 1e-3
+    assert worst_kept <= 1e-3
+    assert worst_backend <= 1e-5 and worst_other <= 3e-2
+    assert kept >= (hops * S if arch == "conformer" else hops * S // 2)
+    # a second scorer over the same stream gives the same bits (no state leaks between objects), and the streams of one
+    # batch do not see each other: stream 1 alone scores as it did in the batch
+    sc2 = KVCachedScorer(eng, sd, 1, window=64000, hop=hop)
+    for i in range(hops):
+        s1 = sc2.push(stream[1:2, i * hop:(i + 1) * hop].cuda()).cpu()
+        assert torch.equal(s1[0], got[i][1]), i
+
+
+def test_kv_mode_refuses_what_it_cannot_do():
+    from afx import engine, synth
+    from afx._lib import AfxError
+    sd = synth.model_state_dict("ConformerModel", n_layers=1, n_encoders=1)
+    ex = engine.Engine("conformer", n_layers=1, dtype="fp32", conf_blocks=1)
+    ex.load_state_dict(sd)
+    with pytest.raises(AfxError, match="half-precision"):
+        ex.kv_state(2)
+    eng = engine.Engine("conformer", n_layers=1, dtype="fp16", conf_blocks=1)
+    eng.load_state_dict(sd)
+    kv = eng.kv_state(2)
+    with pytest.raises(AfxError, match="1..16 frames"):
+        kv.step(torch.zeros(2, 17, 512, device="cuda"))
+    with pytest.raises(ValueError):
+        kv.step(torch.zeros(3, 12, 512, device="cuda"))

@@ -151,3 +151,21 @@ def test_pre_emphasis_eer_and_tiling_known_answers():
     np.testing.assert_array_equal(pre.adjust_duration(_t(z["short"]), 24).numpy(), z["tiled"])
     assert pre.adjust_duration(torch.arange(100.0), 24).shape[0] == 24
     assert pre.pad_tile(np.arange(10.0), 25).shape[0] == 25
+
+
+def test_block_causal_restatement_reduces_to_the_offline_trunk_for_a_single_chunk():
+    """oracle/streaming.py (the KV-cached streaming mode's own oracle, NOT reference parity) differs from the trunk oracle
+    only in its visibility rule: with ONE chunk that covers a whole (short) clip and nothing cached, a frame sees the whole
+    clip and the positional conv's zero padding is the clip's own -- the block-causal function must then BE the offline one.
+    Also: the chunk schedule of 250-ms hops (12, 12, 13, 12, 13, ... frames; 200 frames per 16 chunks in steady state)."""
+    from afx import synth  # (conftest puts the package on sys.path)
+    from oracle import models, streaming
+    sizes = streaming.chunk_sizes(84000, 4000)
+    assert sizes[:6] == [12, 12, 13, 12, 13, 12] and sum(sizes) == 262 and sum(sizes[3:19]) == 200
+    for name, kw in (("ConformerModel", dict(n_encoders=1)), ("XLSR_AASIST", {})):
+        sd = synth.model_state_dict(name, n_layers=1, **kw)
+        wave = synth.waveforms(2, 5000, batch_idx=1)  # 15 frames: one chunk of at most 16
+        out, sz = streaming.block_causal_scores(sd, wave, 5000)
+        ref = models.conformer_forward(sd, wave) if name == "ConformerModel" else models.xlsr_aasist_forward(sd, wave)
+        assert sz == [15] and (out[0] - ref).abs().max().item() < 2e-6
+

@@ -13,6 +13,9 @@ from afx import engine, synth  # noqa: E402
 wl = os.environ.get("AFX_WORKLOAD", "conformer_student")
 arch, oname, nl, B = {"conformer_student": ("conformer", "ConformerModel", 6, 64),
                       "xlsr_aasist": ("xlsr_aasist", "XLSR_AASIST", 24, 16)}[wl]
+if os.environ.get("AFX_GEMM_MAP"):  # A/B of the workgroup -> tile order (0 linear, 1 XCD-contiguous, 2 + grouped: the default)
+    from afx._lib import check, lib
+    check(lib().afx_debug_set(b"gemm_map", int(os.environ["AFX_GEMM_MAP"])))
 sd = synth.model_state_dict(oname, n_layers=nl)
 eng = engine.Engine(arch, n_layers=nl, dtype=os.environ.get("AFX_DTYPE", "fp16"))
 eng.load_state_dict(sd)
