@@ -709,10 +709,10 @@ extern "C" int afx_tap(afx_handle h, const char* name, float* out, size_t cap, s
 // launch of the forward is bracketed by hipEvents on the launch stream and summed per
 // class afterwards.  Off by default: the normal forward records nothing.
 // ---------------------------------------------------------------------------------
-enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN, PC_GEMM_K2, PC_GEMM_F32, PC_CONV0, PC_POSCONV, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV, PC_CONF_CHAIN,
+enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN, PC_GEMM_F32, PC_CONV0, PC_POSCONV, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV, PC_CONF_CHAIN,
                  PC_MISC, PC_AASIST, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm_kernel<128x128>", "gemm_kernel<128x64>", "gemm_kernel<256x256>",
-                                           "gemm_kernel<128x512,rowLN>", "gemm8_kernel<256x256>", "gemm8_kernel<128x512,rowLN>", "gemm_k2_kernel<128x128>", "gemm_f32_kernel<128x128>", "conv0_kernel", "posconv_kernel", "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel",
+                                           "gemm_kernel<128x512,rowLN>", "gemm8_kernel<256x256>", "gemm8_kernel<128x512,rowLN>", "gemm_f32_kernel<128x128>", "conv0_kernel", "posconv_kernel", "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel",
                                            "conf_dwconv_kernel", "conf_chain_kernel", "misc", "aasist_head"};
 struct ProfRec { int cls; hipEvent_t a, b; double flops; };
 struct Profiler {
@@ -757,7 +757,7 @@ static const char* timed(int cls, double flops, hipStream_t s, F&& f) {
 // (pack_linear), and ONE launch walks K three times: K' = 3 K (GemmArgs::k1).
 static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) {
   const double fl = 2.0 * g.M * g.N * (g.k_algo ? g.k_algo : g.K) * groups;
-  static const int cls[11] = {PC_GEMM128, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM256, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN, PC_GEMM_K2, PC_GEMM64};
+  static const int cls[9] = {PC_GEMM128, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM256, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN};
   if (dt == DT_FP32 && t_s3planes) {
     if (g.K % 64 || g.kchunk % 64) return launch_gemm(g, DT_FP32, groups, s);  // (a K the fp16 tiles cannot walk: the fp32 instruction)
     GemmArgs q = g;
@@ -1706,10 +1706,6 @@ extern "C" int afx_debug_set(const char* key, int value) {
   }
   if (!strcmp(key, "gemm_ph4")) {
     gemm_set_ph4(value);
-    return 0;
-  }
-  if (!strcmp(key, "gemm_k2")) {
-    gemm_set_k2(value);
     return 0;
   }
   if (!strcmp(key, "gemm_fit")) {

@@ -549,168 +549,6 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   gemm_epilogue<HT, BM, BN, WR, WC, ROWLN, LEAN, S3>(p, acc, smem, m0, n0, g);
 }
 
-// =======================================================================================
-// Two-chain tile kernel for the small-M products whose K is long and whose N is short (the teacher's out-proj and FC2 at
-// M = 16 x 199: 25 x 8 tiles of 128 x 128 -- too few rows for the 8-wave 256 x 256 tile, and on 128 x 64 tiles a
-// workgroup walks all 16 / 64 K-tiles alone at ~0.7 us each).  The product is DEFINED as two accumulation chains -- chain 0
-// over the first half of K, chain 1 over the second -- summed once at the end.  KG = 2: eight waves, two groups of four, each
-// group stages and multiplies ITS half of K (own double-buffered LDS stages, common barriers), group 1 hands its accumulators
-// to group 0 through LDS (64 KB), group 0 adds and runs the epilogue: half the K-tiles per workgroup at twice the waves per
-// CU.  KG = 1: the same two chains one after the other in one 4-wave group (second accumulator set) -- the form for
-// batches too small to fill the chip with 128 x 128 tiles; it gives the SAME BITS as KG = 2 (same chains, same final add),
-// so a clip scores identically alone and in a batch as long as both pick this family (launch_gemm).
-// =======================================================================================
-template <class HT, int BM, int BN, int WR, int WC, int KG>
-__global__ __launch_bounds__(64 * WR * WC * KG) void gemm_k2_kernel(GemmArgs p) {
-  typedef typename HT::T T;
-  typedef typename HT::V8 V8;
-  constexpr int NWG = WR * WC;  // waves per K-group
-  constexpr int WM = BM / WR, WN = BN / WC;
-  constexpr int MT = WM / 16, NT = WN / 16;
-  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
-  constexpr int AI = BM / (8 * NWG), WI = BN / (8 * NWG);
-  static_assert(AI >= 1 && WI >= 1, "tile too small for the wave count");
-  static_assert(KG == 1 || MT * NT * 64 * NWG * 16 <= 2 * KG * STAGE, "the hand-over of group 1's accumulators fits the operand stages");
-  extern __shared__ __attribute__((aligned(16))) char smem_all[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = wave_all / NWG, wave = wave_all % NWG;  // K-group, wave inside it
-  const int wr = wave / WC, wc = wave % WC;
-  char* smem = smem_all + kg * 2 * STAGE;  // this group's two stages
-  int pm, pn;
-  {
-    const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
-    const int nwg = nM * nN;
-    int L = blockIdx.x;
-    if (p.map_mode >= 1) {
-      const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
-      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-    }
-    if (p.map_mode == 2) {
-      constexpr int GM = 8;
-      const int width = GM * nN, grp = L / width, first = grp * GM;
-      const int gsz = nM - first < GM ? nM - first : GM;
-      pm = first + (L % width) % gsz;
-      pn = (L % width) / gsz;
-    } else {
-      pm = L / nN;
-      pn = L % nN;
-    }
-  }
-  const int m0 = pm * BM, n0 = pn * BN;
-  const T* a_src[AI];
-  const T* w_src[WI];
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int row = (i * NWG + wave) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    int m = m0 + row;
-    m = m < p.M ? m : p.M - 1;
-    a_src[i] = (const T*)p.A + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < WI; ++i) {
-    const int row = (i * NWG + wave) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    int n = n0 + row;
-    n = n < p.N ? n : p.N - 1;
-    w_src[i] = (const T*)p.W + (long)n * p.ldw + c * 8;
-  }
-  const int nkh = (p.K >> 6) >> 1;  // K-tiles per chain (launch_gemm guarantees K % 128 == 0)
-  auto stage = [&](int buf, int ktile) {  // ktile: absolute K-tile index
-    const long k0 = (long)ktile << 6;
-    const unsigned base = (unsigned)(buf * STAGE);
-#pragma unroll
-    for (int i = 0; i < AI; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(smem + base + (i * NWG + wave) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < WI; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(smem + base + A_BYTES + (i * NWG + wave) * 1024), 16, 0, 0);
-  };
-  const int frow = lane & 15, fsw = (frow >> 1) & 7;
-  const int a_off = (wr * WM + frow) * 128;
-  const int w_off = A_BYTES + (wc * WN + frow) * 128;
-  f32x4 acc[MT][NT], acc1[KG == 1 ? MT : 1][KG == 1 ? NT : 1];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mma_tile = [&](const char* sb, f32x4 (&a)[MT][NT]) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int slot = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
-      V8 af[MT], wf[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) a[i][j] = HT::mfma(wf[j], af[i], a[i][j]);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  };
-  if constexpr (KG == 2) {
-    const int kbase = kg * nkh;  // this group's chain
-    stage(0, kbase);
-    for (int kt = 0; kt < nkh; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (kt + 1 < nkh) stage((kt + 1) & 1, kbase + kt + 1);
-      mma_tile(smem + (kt & 1) * STAGE, acc);
-    }
-    __syncthreads();  // every wave is done with its LDS stages: they become the hand-over buffer
-    f32x4* red = (f32x4*)smem_all;
-    const int t4 = tid - kg * 64 * NWG;  // thread index inside the group: both groups hold the same (wr, wc, lane) -> the same outputs
-    if (kg == 1) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) red[(i * NT + j) * (64 * NWG) + t4] = acc[i][j];
-    }
-    __syncthreads();
-    if (kg == 1) return;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] += red[(i * NT + j) * (64 * NWG) + t4];  // chain 0 + chain 1
-  } else {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nk = 2 * nkh;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-      if (kt < nkh) mma_tile(smem + (kt & 1) * STAGE, acc);
-      else mma_tile(smem + (kt & 1) * STAGE, acc1);
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] += acc1[i][j];  // chain 0 + chain 1
-  }
-  gemm_epilogue<HT, BM, BN, WR, WC, false, true, false>(p, acc, smem_all, m0, n0, 0);
-}
-
-template <class HT, int BM, int BN, int KG>
-static hipError_t launch_gemm_k2_t(const GemmArgs& p, hipStream_t s) {
-  constexpr int lds = 2 * KG * (BM + BN) * 128;
-  static LdsLimit lim;
-  if (hipError_t e = lim.ensure((const void*)gemm_k2_kernel<HT, BM, BN, 2, 2, KG>, lds); e != hipSuccess) return e;
-  dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, 1);
-  hipLaunchKernelGGL((gemm_k2_kernel<HT, BM, BN, 2, 2, KG>), grid, dim3(256 * KG), lds, s, p);
-  return hipGetLastError();
-}
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 10, "extend the table");
@@ -1393,24 +1231,8 @@ static int gemm8_fit_rowln(const GemmArgs& p) {
   return best;
 }
 
-// The two-chain family (gemm_k2_kernel): products with a long K and a short N at row counts that cannot fill the chip with
-// 256-wide tiles.  9 = eight waves, two K-groups, 128 x 128; 10 = the same chains in one 4-wave group, 128 x 64.
-static int g_k2 = 1;  // A/B knob: 0 = off (single-chain tiles everywhere)
-void gemm_set_k2(int v) { g_k2 = v; }
-static int gemm_k2_tile(const GemmArgs& p, int groups) {
-  if (!g_k2 || groups != 1 || p.ln_gamma || p.k1 || !plain_k(p) || p.K < 1024 || p.K % 128 || p.N > 1024 || p.N % 128) return -1;
-  if ((p.act != ACT_NONE && p.act != ACT_GELU) || (p.N & 7)) return -1;  // lean epilogue only
-  const long b128 = (long)((p.M + 127) / 128) * (p.N / 128);
-  if (b128 >= 384) return -1;        // enough rows for the single-chain 8-wave tiles
-  return b128 >= 96 ? 9 : 10;        // 128 x 128 tiles on at least 96 CUs, else spread over 128 x 64 tiles
-}
-
 int gemm_tile_of(const GemmArgs& p, int groups) {
   if (p.ln_gamma) return g_deep != 0 && plain_k(p) ? 8 : 3;
-  if (g_tile_override < 0) {
-    const int k2 = gemm_k2_tile(p, groups);
-    if (k2 >= 0) return k2;
-  }
   if (gemm_is_narrow(p.N)) return 1;
   if (groups != 1) return 0;
   if (g_tile_override == 5) return 1;  // 128x64 / 4 waves (forced)
@@ -1449,8 +1271,6 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 8: return g_ph4 ? launch_gemm8_t<HT, 128, 512, true, 4, 0>(p, groups, s) : launch_gemm8_t<HT, 128, 512, true>(p, groups, s);
     case 82: return launch_gemm8_t<HT, 128, 512, true, 2>(p, groups, s);
     case 83: return launch_gemm8_t<HT, 128, 512, true, 3>(p, groups, s);
-    case 9: return launch_gemm_k2_t<HT, 128, 128, 2>(p, s);
-    case 10: return launch_gemm_k2_t<HT, 128, 64, 1>(p, s);
     default: return lean ? launch_gemm_t<HT, 128, 128, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 128, 2, 2>(p, groups, s);
   }
 }

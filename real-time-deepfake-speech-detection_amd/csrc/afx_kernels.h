@@ -70,7 +70,6 @@ void gemm_set_tile(int t);      // A/B knob: -1 default, 0: 128x128 tile, 1: 256
 void gemm_set_a_nt(int v);      // A/B knob: -1 auto, 0/1 non-temporal A-panel loads
 void gemm_set_conv_split(int v);  // A/B knob: 1 (default) = multi-round conv layers as whole rounds of 128-row tiles + a 64-row remainder launch
 void gemm_set_ph4(int v);       // A/B knob: 1 = 4-phase K-tile of the 8-wave kernels (default 0: two phases of 32 MFMAs)
-void gemm_set_k2(int v);        // A/B knob: 1 (default) = two-chain tiles for long-K / short-N products at small row counts
 void gemm_set_fit(int v);       // A/B knob: 1 (default) = 8-phase tile height fitted to one round of the CUs (160..256 rows)
 void gemm_set_split(int v);     // A/B knob: 1 (default) = whole rounds on the 8-phase kernel + 128x128 remainder rows
 void mhsa_set_zsplit(int v);       // A/B knob: workgroups per (utterance, head) of the one-pass trunk attention (0 = automatic)
