@@ -130,6 +130,8 @@ class Engine:
         head is a tenth of the teacher's time on a third of the chip's CUs).  Same kernels and bits as ``forward``.
         The returned logits are produced on the SIDE stream: call ``join()`` before reading them on the current stream
         (afx.harness.produce_evaluation_file does, once, after its last batch)."""
+        if self._taps:  # taps are engine-owned copies written by whichever forward runs: one stream only
+            return self.forward(wave)
         x = self._wave(wave)
         B, L = x.shape
         l = lib()
@@ -308,7 +310,9 @@ class Engine:
 
     # ---- debug taps ----------------------------------------------------------------
     def enable_taps(self, on=True):
+        self.join()  # (a back-end still running on the side stream finishes before the tap state changes)
         check(lib().afx_enable_taps(self._h, 1 if on else 0))
+        self._taps = bool(on)
 
     def tap(self, name):
         n = C.c_size_t(0)

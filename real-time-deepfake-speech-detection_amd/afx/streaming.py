@@ -192,6 +192,8 @@ class KVCachedScorer(IncrementalScorer):
         self.cw6 = K.pack_conv(self.dt, f32(sd[pre + "0.weight"]))
         self.cb6, self.lg6, self.lb6 = f32(sd[pre + "0.bias"]), f32(sd[pre + "2.1.weight"]), f32(sd[pre + "2.1.bias"])
         self.carry6 = torch.empty(n_streams, 0, 512, dtype=K.torch_dtype(self.dt), device=engine.device)
+        # (this mode never re-scores a window: the sample ring and the layer-5 window of the exact-reuse scorer are not kept)
+        self.ring = self._batch = self._l5_buf = None
         self.kv = engine.kv_state(n_streams)
         self.frames = 0  # conv-layer-6 frames consumed so far (per stream)
 

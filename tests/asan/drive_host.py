@@ -90,6 +90,11 @@ for arch, prefix in ((AAS, "xlsr_aasist"), (CONF, "conformer"), (SSL, "conformer
             ok(lib.afx_forward(h, ptr(wave), B, Ls, ptr(logits), ptr(ws), n, None), "forward")
             fails(lib.afx_forward(h, ptr(wave), B, Ls, ptr(logits), ptr(ws), n - 4096, None), "workspace too small")
             fails(lib.afx_forward(h, ptr(wave), B, 300, ptr(logits), ptr(ws), n, None), "too few")
+            # the forward in two calls (back-end of one batch under the next batch's trunk: two workspaces)
+            ws2 = ws_for(n)
+            ok(lib.afx_trunk_forward(h, ptr(wave), B, Ls, ptr(ws2), n, None), "trunk forward")
+            ok(lib.afx_head_from_workspace(h, B, Ls, ptr(logits), ptr(ws2), n, None), "head from workspace")
+            fails(lib.afx_head_from_workspace(h, B, Ls, ptr(logits), ptr(ws2), n - 4096, None), "workspace too small")
             # taps: engine-owned fp32 copies of intermediates (memcpy / conversion launches inside the workspace bounds)
             ok(lib.afx_enable_taps(h, 1), "taps on")
             ok(lib.afx_forward(h, ptr(wave), B, Ls, ptr(logits), ptr(ws), n, None), "forward with taps")
