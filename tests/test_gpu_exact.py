@@ -96,14 +96,17 @@ def test_fp32_transformer_attention(K, T):
     _close(got, ref, 1e-5, 1e-5)
 
 
-def test_fp32_trunk_stage_by_stage():
+@pytest.mark.parametrize("dtype", ["fp32", "fp16x3"])
+def test_fp32_trunk_stage_by_stage(dtype):
+    """Exact mode and split precision (fp16x3: the same fp32 activations, every dense product as three fp16 matrix-core
+    products): every stage of the trunk at fp32 accuracy."""
     from afx import engine, synth
     from oracle import ssl_trunk
     sd = synth.ssl_state_dict(2)
     wave = synth.waveforms(2, 64000)
     taps = {}
     ref = ssl_trunk.ssl_forward({k[len(synth.SSL_PREFIX):]: v for k, v in sd.items()}, wave, taps=taps)
-    eng = engine.Engine("ssl", n_layers=2, dtype="fp32")
+    eng = engine.Engine("ssl", n_layers=2, dtype=dtype)
     eng.load_state_dict(sd)
     eng.enable_taps()
     got = eng.ssl(wave.cuda())
@@ -114,17 +117,18 @@ def test_fp32_trunk_stage_by_stage():
     assert (got.cpu() - ref).abs().max().item() < 5e-4
 
 
-def test_fp32_conformer_student_logits():
+@pytest.mark.parametrize("dtype", ["fp32", "fp16x3"])
+def test_fp32_conformer_student_logits(dtype):
     from afx import engine, synth
     from oracle import models
     sd = synth.model_state_dict("ConformerModel", n_layers=6)
     wave = synth.waveforms(4, 64000)
     ref = models.conformer_forward(sd, wave)
-    eng = engine.Engine("conformer", n_layers=6, dtype="fp32")
+    eng = engine.Engine("conformer", n_layers=6, dtype=dtype)
     eng.load_state_dict(sd)
     got = eng.forward(wave.cuda()).cpu()
     err = (got - ref).abs().max().item()
-    print(f"conformer student, exact mode: max|dlogit| {err:.2e}")
+    print(f"conformer student, {dtype}: max|dlogit| {err:.2e}")
     assert err <= 1e-5
 
 

@@ -604,6 +604,28 @@ def test_ragged_batch_scores_each_clip_as_if_alone(afx_mod, arch, tmp_path):
     assert torch.allclose(torch.tensor(scores), got[:, 1], atol=0, rtol=0)
 
 
+def test_ragged_bit_identity_holds_across_tile_families(afx_mod):
+    """The same statement at a batch large enough that its dense products run on OTHER tile instances than a clip's alone
+    (48 clips: QKV / FC1 / out-proj / FC2 on the 8-wave 256-wide tiles; one clip alone: 128 x 64 tiles) -- every tile instance
+    accumulates a row's K in the same order, so a clip's logits still equal the logits it gets alone, bit for bit.  (A second
+    summation order for some batch sizes -- e.g. a K-split tile, measured in round 3 -- would end this)"""
+    engine, synth = afx_mod
+    sd = synth.model_state_dict("XLSR_AASIST", n_layers=2)
+    eng = engine.Engine("xlsr_aasist", n_layers=2, dtype="fp16")
+    eng.load_state_dict(sd)
+    lens = [64000 if i % 3 else 30000 + 997 * i for i in range(48)]
+    clips = [synth.waveforms(1, n, batch_idx=1800 + i)[0] for i, n in enumerate(lens)]
+    got = eng.forward_ragged([c.cuda() for c in clips]).cpu()
+    for b in (0, 1, 7, 20, 33, 47):
+        alone = eng.forward(clips[b][None].cuda()).cpu()[0]
+        assert torch.equal(got[b], alone), f"clip {b}: {(got[b] - alone).abs().max().item():.2e}"
+    # and a uniform batch of 48 against the same clips in batches of 3
+    wave = synth.waveforms(48, 32000, batch_idx=77).cuda()
+    whole = eng.forward(wave)
+    parts = torch.cat([eng.forward(wave[i:i + 3]) for i in range(0, 48, 3)])
+    assert torch.equal(whole, parts)
+
+
 def test_ragged_ssl_features(afx_mod):
     engine, synth = afx_mod
     sd = synth.ssl_state_dict(2)
@@ -618,7 +640,7 @@ def test_ragged_ssl_features(afx_mod):
         assert bool((feats[b, frames[b]:] == 0).all())
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-3), ("fp32", 2e-5)])
+@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-3), ("fp32", 2e-5), ("fp16x3", 2e-5)])
 def test_group_norm_extractor_mode(afx_mod, dtype, tol):
     """The wav2vec2-base feature extractor `north_star` names beside XLS-R's (fairseq extractor_mode="default":
     bias-free convs, GroupNorm(512,512) = per-utterance-and-channel normalisation over time on layer 0 only, GELU;
