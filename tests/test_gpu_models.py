@@ -608,12 +608,16 @@ def test_ragged_bit_identity_holds_across_tile_families(afx_mod):
     """The same statement at a batch large enough that its dense products run on OTHER tile instances than a clip's alone
     (48 clips: QKV / FC1 / out-proj / FC2 on the 8-wave 256-wide tiles; one clip alone: 128 x 64 tiles) -- every tile instance
     accumulates a row's K in the same order, so a clip's logits still equal the logits it gets alone, bit for bit.  (A second
-    summation order for some batch sizes -- e.g. a K-split tile, measured in round 3 -- would end this)"""
+    summation order for some batch sizes -- e.g. a K-split tile, measured in round 3 -- would end this)
+    The one condition: the batch's longest clip and the clip alone must select the same FORM of the trunk attention -- the
+    one-pass kernel up to 224 frames (4.49 s), the key-blocked one beyond (running max / sum: another rounding).  A batch that
+    holds a longer clip scores its short clips through the blocked form: equal to alone within fp32 rounding, not bit for bit."""
     engine, synth = afx_mod
     sd = synth.model_state_dict("XLSR_AASIST", n_layers=2)
     eng = engine.Engine("xlsr_aasist", n_layers=2, dtype="fp16")
     eng.load_state_dict(sd)
-    lens = [64000 if i % 3 else 30000 + 997 * i for i in range(48)]
+    lens = [64000 if i % 3 else 20000 + 907 * i for i in range(48)]  # 62 ... 199 frames
+    assert max(lens) == 64000
     clips = [synth.waveforms(1, n, batch_idx=1800 + i)[0] for i, n in enumerate(lens)]
     got = eng.forward_ragged([c.cuda() for c in clips]).cpu()
     for b in (0, 1, 7, 20, 33, 47):
@@ -624,6 +628,12 @@ def test_ragged_bit_identity_holds_across_tile_families(afx_mod):
     whole = eng.forward(wave)
     parts = torch.cat([eng.forward(wave[i:i + 3]) for i in range(0, 48, 3)])
     assert torch.equal(whole, parts)
+    # one 5-s clip (249 frames) in the batch: every clip goes through the key-blocked attention
+    mixed = [synth.waveforms(1, 80000, batch_idx=1900)[0]] + clips[:5]
+    gm = eng.forward_ragged([c.cuda() for c in mixed]).cpu()
+    for b in (1, 2, 3):
+        alone = eng.forward(mixed[b][None].cuda()).cpu()[0]
+        assert (gm[b] - alone).abs().max().item() <= 2e-6
 
 
 def test_ragged_ssl_features(afx_mod):
