@@ -81,7 +81,9 @@ class Engine:
         """sd: name -> tensor (reference checkpoint names).  Tensors are moved to
         the device as contiguous fp32 and copied / repacked by the library."""
         l, dev = lib(), self.device
+        self.join()  # (a back-end still running on the side stream reads the weights this call repacks)
         with torch.cuda.device(dev):
+            torch.cuda.current_stream(dev).synchronize()
             s = self._stream()
             for name, t in sd.items():
                 if not torch.is_tensor(t) or not t.dtype.is_floating_point:
