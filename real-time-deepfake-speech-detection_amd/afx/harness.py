@@ -306,15 +306,18 @@ def _produce_evaluation_file_distributed(dataset, model, device, save_path, batc
     idx = adist.shard_indices(len(dataset), rank, world)
     model.eval()
     scores = torch.zeros(idx.numel(), dtype=torch.float32, device=device)
-    names = {}
-    pos = 0
+    names, outs = {}, []
+    overlapped = getattr(model, "afx_arch", None) == "xlsr_aasist" and hasattr(model, "forward_overlapped")
     with torch.no_grad():
         loader = (((i, utt), x) for i, utt, x, _label in _loader(_Shard(dataset, idx.tolist()), batch_size, num_workers))
         for (i, utt), x in prefetch_to_device(loader, device):
-            out = model(x)
-            scores[pos:pos + out.shape[0]] = out[:, 1]
-            pos += out.shape[0]
+            outs.append(model.forward_overlapped(x) if overlapped else model(x))  # (graph back-end under the next batch's trunk)
             names.update(zip((int(v) for v in (i.tolist() if torch.is_tensor(i) else i)), utt))
+        if overlapped:
+            model.join_overlapped()
+    if outs:
+        got = torch.cat([o[:, 1] for o in outs])
+        scores[: got.numel()] = got
     gi, gs = adist.all_gather_scores(idx.to(device=device, dtype=torch.int32), scores, world, group)
     mi, ms = adist.merge_scores(gi, gs)
     all_names = [None] * world
