@@ -960,7 +960,10 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     q.bias = e->bqkv[l];
     q.out_h = w.qkv; q.ldo_h = 3 * kD;
     KOK(launch_gemm(q, dt, 1, s));
-    KOK(timed(PC_MHSA, 4.0 * B * kH * (double)Tt * Tt * 64, s, [&] { return launch_mhsa(w.qkv, w.att, B, Tt, kH, dt, s, w.lens); }));
+    KOK(timed(PC_MHSA, 4.0 * B * kH * (double)Tt * Tt * 64, s, [&] {
+      if (e->s3 && Tt <= 224) return launch_mhsa_split((const float*)w.qkv, (float*)w.att, B, Tt, kH, s, w.lens);  // split precision: the matrix-core form
+      return launch_mhsa(w.qkv, w.att, B, Tt, kH, dt, s, w.lens);
+    }));
     KOK(resid_product(w.att, kD, e->wo[l], kD, e->F(P + "self_attn.out_proj.bias")));
     RowNormArgs n2 = plain_norm(w.x, kD, M, kD, e->F(P + "final_layer_norm.weight"), e->F(P + "final_layer_norm.bias"));
     n2.out_h = w.hbuf; n2.ldo_h = kD;
@@ -1780,6 +1783,7 @@ extern "C" int afx_k_rownorm(int dtype, const float* x, long ldx, int rows, int 
   KRET(launch_rownorm(a, dtype, (hipStream_t)stream));
 }
 extern "C" int afx_k_mhsa(int dtype, const void* qkv, void* out, int B, int T, int H, void* stream) {
+  if (dtype == DT_FP16X3) KRET(launch_mhsa_split((const float*)qkv, (float*)out, B, T, H, (hipStream_t)stream));  // fp32 rows in / out
   KRET(launch_mhsa(qkv, out, B, T, H, dtype, (hipStream_t)stream));
 }
 extern "C" int afx_k_conf_attn(int dtype, const float* q, long ldq, const float* kv, long ldkv, const float* rel,

@@ -151,6 +151,8 @@ const char* launch_posconv(const PosConvArgs& p, int dtype, hipStream_t s);
 // lens (device int32[B], or null): ragged batch -- utterance b has lens[b] valid frames of its T rows (key-padding mask)
 const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t s, const int* lens = nullptr);
 
+// the same attention with fp32 rows in / out and split-precision products on the fp16 matrix pipe (dtype "fp16x3"); T <= 224
+const char* launch_mhsa_split(const float* qkv, float* out, int B, int T, int H, hipStream_t s, const int* lens = nullptr);
 // KV-cached streaming attention (afx_kv_step; not a reference function): ring (S, 256, 3*H*64) rows [q | k | v] in 16-slot
 // groups, cnt[16] valid frames per group, the queries are group q_tile's slots; out (S, 16, H*64)
 const char* launch_mhsa_ring(const void* ring, void* out, int S, int H, int q_tile, const int* cnt, int dtype, hipStream_t s);

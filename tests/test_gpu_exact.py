@@ -85,15 +85,21 @@ def test_fp32_frontend_and_rownorm(K):
     _close(of, F.layer_norm(x, (1024,), g2, b2))
 
 
-@pytest.mark.parametrize("T", [199, 12, 224])
-def test_fp32_transformer_attention(K, T):
+@pytest.mark.parametrize("dtype", ["fp32", "fp16x3"])
+@pytest.mark.parametrize("T", [199, 12, 224, 100])
+def test_fp32_transformer_attention(K, T, dtype):
+    """Exact mode's fp32 VALU attention and the split-precision matrix-core form of "fp16x3" (hi / lo pairs of Q, K, P and V:
+    three fp16 products each) against an fp64 softmax(QK^T / 8) V on the same fp32 rows, with operand magnitudes a trained
+    model has (scores up to a few tens: a rounded operand would move them by 1e-2)."""
     B, H = 2, 16
     g = torch.Generator().manual_seed(T)
     qkv = torch.randn(B * T, 3 * H * 64, generator=g)
-    got = K.mhsa("fp32", qkv.cuda(), B, T, H).cpu().view(B, T, H, 64)
-    q, k, v = qkv.view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
-    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v).permute(0, 2, 1, 3)
-    _close(got, ref, 1e-5, 1e-5)
+    qkv[:, : H * 64] *= 3.0  # larger queries: sharper softmax
+    got = K.mhsa(dtype, qkv.cuda(), B, T, H).cpu().view(B, T, H, 64)
+    assert got.dtype == torch.float32
+    q, k, v = qkv.double().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v).permute(0, 2, 1, 3).float()
+    _close(got, ref, 2e-5, 2e-5)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16x3"])
