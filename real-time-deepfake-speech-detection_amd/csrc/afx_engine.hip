@@ -733,6 +733,33 @@ static thread_local Profiler* t_prof = nullptr;  // the profiler of the engine w
 // split precision: the plane scratch of the workspace the forward on this thread runs in (null: another mode)
 static thread_local void* t_s3planes = nullptr;
 static thread_local size_t t_s3bytes = 0;
+// Operand buffers whose ONLY readers are dense products may receive their producer's result directly as the product's A
+// operand (fp16 hi / lo planes in place of the fp32 values: same bytes) -- the LayerNorm, the GELU epilogue and the attention
+// write the planes themselves and the separate split launch disappears.  t_s3ok: the buffers of this forward that qualify;
+// t_s3reg: which of them currently hold planes, and their plane stride in elements.
+struct S3Reg { const void* p; long stride; };
+static thread_local const void* t_s3ok[6] = {nullptr};
+static thread_local S3Reg t_s3reg[6] = {};
+static void s3_begin(std::initializer_list<const void*> ok) {
+  int i = 0;
+  for (const void* p : ok) t_s3ok[i++] = p;
+  for (; i < 6; ++i) t_s3ok[i] = nullptr;
+  for (S3Reg& r : t_s3reg) r = S3Reg{nullptr, 0};
+}
+static bool s3_ok(const void* p) {
+  if (!p || !t_s3planes) return false;
+  for (const void* q : t_s3ok) if (q == p) return true;
+  return false;
+}
+static void s3_set(const void* p, long stride) {  // stride 0: the buffer holds fp32 values again
+  for (S3Reg& r : t_s3reg) if (r.p == p) { r.stride = stride; return; }
+  if (!stride) return;
+  for (S3Reg& r : t_s3reg) if (!r.p) { r = S3Reg{p, stride}; return; }
+}
+static long s3_planes_of(const void* p) {
+  for (const S3Reg& r : t_s3reg) if (r.p == p) return r.stride;
+  return 0;
+}
 static void prof_forget(afx_engine* e) {
   if (!e->prof) return;
   for (hipEvent_t ev : e->prof->pool) (void)hipEventDestroy(ev);
@@ -759,33 +786,51 @@ static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) 
   const double fl = 2.0 * g.M * g.N * (g.k_algo ? g.k_algo : g.K) * groups;
   static const int cls[9] = {PC_GEMM128, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM256, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN};
   if (dt == DT_FP32 && t_s3planes) {
-    if (g.K % 64 || g.kchunk % 64) return launch_gemm(g, DT_FP32, groups, s);  // (a K the fp16 tiles cannot walk: the fp32 instruction)
+    if (g.K % 64 || g.kchunk % 64) {  // (a K the fp16 tiles cannot walk: the fp32 instruction)
+      if (g.out_h) s3_set(g.out_h, 0);
+      return launch_gemm(g, DT_FP32, groups, s);
+    }
     GemmArgs q = g;
-    int tile = 0;
-    {
-      // build the split-precision arguments (the split itself is timed as its own launch)
-      const long last = g.M - 1;
-      const long span = (last / g.rpb) * g.a_batch + (last % g.rpb) * g.a_row + (long)(g.K / g.kchunk - 1) * g.kchunk_stride + g.kchunk +
-                        (long)(groups - 1) * g.g_a;
+    const long last = g.M - 1;
+    const long span = (last / g.rpb) * g.a_batch + (last % g.rpb) * g.a_row + (long)(g.K / g.kchunk - 1) * g.kchunk_stride + g.kchunk +
+                      (long)(groups - 1) * g.g_a;
+    const long have = s3_planes_of(g.A);
+    if (have >= span) {  // the producer wrote the planes in place of the fp32 values
+      q.a_plane = have;
+    } else {
       const long plane = (span + 63) & ~63L;
       if ((size_t)plane * 4 > t_s3bytes) return "split-precision product: the A operand exceeds the plane scratch";
       if (const char* m = timed(PC_MISC, 0, s, [&] { return launch_split_planes((const float*)g.A, span, t_s3planes, plane, s); })) return m;
       q.A = t_s3planes;
-      q.k1 = g.K;
-      q.K = 3 * g.K;
-      if (!q.k_algo) q.k_algo = g.K;
       q.a_plane = plane;
-      q.w_plane = g.ldw;
-      q.ldw = 2 * g.ldw;   // W is addressed in halfs: fp32 [N][ldw] became fp16 [N][hi ldw | lo ldw]
-      q.g_w = 2 * g.g_w;
-      q.pre_scale = (const float*)((const char*)g.W + (size_t)groups * g.N * g.ldw * 4);  // afx_engine::wscale
-      tile = gemm_tile_of(q, groups);
     }
+    q.k1 = g.K;
+    q.K = 3 * g.K;
+    if (!q.k_algo) q.k_algo = g.K;
+    q.w_plane = g.ldw;
+    q.ldw = 2 * g.ldw;   // W is addressed in halfs: fp32 [N][ldw] became fp16 [N][hi ldw | lo ldw]
+    q.g_w = 2 * g.g_w;
+    q.pre_scale = (const float*)((const char*)g.W + (size_t)groups * g.N * g.ldw * 4);  // afx_engine::wscale
+    // the result as the NEXT product's A operand, where only products read the buffer and its rows are packed
+    if (g.out_h) {
+      const bool planes_out = s3_ok(g.out_h) && groups == 1 && g.ldo_h == g.N && g.rpb >= g.M && g.oh_row_off == 0 && (g.N & 7) == 0 &&
+                              (g.act == ACT_NONE || g.act == ACT_GELU) && !g.ln_gamma && g.out_h != g.A;
+      q.oh_plane = planes_out ? (long)g.M * g.N : 0;
+      s3_set(g.out_h, q.oh_plane);
+    }
+    const int tile = gemm_tile_of(q, groups);
     return timed(cls[tile], fl, s, [&] { return launch_gemm(q, DT_FP16X3, groups, s); });
   }
   return timed(dt == DT_FP32 ? PC_GEMM_F32 : cls[gemm_tile_of(g, groups)], fl, s, [&] { return launch_gemm(g, dt, groups, s); });
 }
-static const char* P_rownorm(const RowNormArgs& a, int dt, hipStream_t s) {
+static const char* P_rownorm(const RowNormArgs& a_in, int dt, hipStream_t s) {
+  RowNormArgs a = a_in;
+  if (a.out_h && t_s3planes) {  // split precision: the LayerNorm writes the next product's A planes itself
+    const bool planes_out = dt == DT_FP32 && s3_ok(a.out_h) && a.ldo_h == a.C && a.rpb >= a.rows && a.o_row_off == 0 && (a.C & 7) == 0 &&
+                            a.out_h != (const void*)a.x;
+    a.oh_plane = planes_out ? (long)a.rows * a.C : 0;
+    s3_set(a.out_h, a.oh_plane);
+  }
   return timed(PC_ROWNORM, 0, s, [&] { return launch_rownorm(a, dt, s); });
 }
 
@@ -961,7 +1006,12 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     q.out_h = w.qkv; q.ldo_h = 3 * kD;
     KOK(launch_gemm(q, dt, 1, s));
     KOK(timed(PC_MHSA, 4.0 * B * kH * (double)Tt * Tt * 64, s, [&] {
-      if (e->s3 && Tt <= 224) return launch_mhsa_split((const float*)w.qkv, (float*)w.att, B, Tt, kH, s, w.lens);  // split precision: the matrix-core form
+      if (e->s3 && Tt <= 224) {  // split precision: the matrix-core form; its output goes out as the output projection's A planes
+        const long plane = s3_ok(w.att) ? (long)M * kD : 0;
+        s3_set(w.att, plane);
+        return launch_mhsa_split((const float*)w.qkv, (float*)w.att, B, Tt, kH, s, w.lens, plane);
+      }
+      if (e->s3) s3_set(w.att, 0);
       return launch_mhsa(w.qkv, w.att, B, Tt, kH, dt, s, w.lens);
     }));
     KOK(resid_product(w.att, kD, e->wo[l], kD, e->F(P + "self_attn.out_proj.bias")));
@@ -1355,6 +1405,7 @@ extern "C" int afx_forward(afx_handle h, const float* wave, int B, int L, float*
   t_prof = h->prof;
   t_s3planes = w.s3planes;
   t_s3bytes = w.s3bytes;
+  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
   if (run_trunk(h, wave, B, L, w, s)) return 1;
   return run_head(h, B, w.T[6], w, logits, s);
 }
@@ -1371,6 +1422,7 @@ extern "C" int afx_trunk_forward(afx_handle h, const float* wave, int B, int L, 
   t_prof = h->prof;
   t_s3planes = w.s3planes;
   t_s3bytes = w.s3bytes;
+  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
   return run_trunk(h, wave, B, L, w, (hipStream_t)stream);
 }
 extern "C" int afx_head_from_workspace(afx_handle h, int B, int L, float* logits, void* ws, size_t ws_bytes, void* stream) {
@@ -1383,6 +1435,7 @@ extern "C" int afx_head_from_workspace(afx_handle h, int B, int L, float* logits
   t_prof = h->prof;
   t_s3planes = w.s3planes;
   t_s3bytes = w.s3bytes;
+  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
   return run_head(h, B, w.T[6], w, logits, (hipStream_t)stream);
 }
 
@@ -1409,6 +1462,7 @@ extern "C" int afx_tail_forward_strided(afx_handle h, const void* conv5_h, long 
   t_prof = h->prof;
   t_s3planes = w.s3planes;
   t_s3bytes = w.s3bytes;
+  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
   if (run_trunk(h, nullptr, B, 0, w, s, conv5_h, batch_stride)) return 1;
   return run_head(h, B, w.T[6], w, logits, s);
 }
@@ -1462,6 +1516,7 @@ extern "C" int afx_forward_ragged(afx_handle h, const float* wave, int B, int Lm
   t_prof = h->prof;
   t_s3planes = w.s3planes;
   t_s3bytes = w.s3bytes;
+  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
   if (run_trunk(h, wave, B, Lmax, w, s)) return 1;
   const int Tmax = w.T[6];
   if (h->cfg.arch == AFX_ARCH_CONFORMER) return run_head(h, B, Tmax, w, logits, s);
@@ -1501,6 +1556,7 @@ extern "C" int afx_ssl_forward_ragged(afx_handle h, const float* wave, int B, in
   t_prof = h->prof;
   t_s3planes = w.s3planes;
   t_s3bytes = w.s3bytes;
+  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
   if (run_trunk(h, wave, B, Lmax, w, s)) return 1;
   const int Tmax = w.T[6];
   HIP_OK(hipMemcpyAsync(feats, w.ssl_f, (size_t)B * Tmax * kD * 4, hipMemcpyDeviceToDevice, s));
@@ -1522,6 +1578,7 @@ extern "C" int afx_ssl_forward(afx_handle h, const float* wave, int B, int L, fl
   t_prof = h->prof;
   t_s3planes = w.s3planes;
   t_s3bytes = w.s3bytes;
+  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
   if (run_trunk(h, wave, B, L, w, s)) return 1;
   HIP_OK(hipMemcpyAsync(feats, w.ssl_f, (size_t)B * w.T[6] * kD * 4, hipMemcpyDeviceToDevice, s));
   return 0;
@@ -1561,6 +1618,7 @@ extern "C" int afx_head_forward(afx_handle h, const float* feats, int B, int T, 
   t_prof = h->prof;
   t_s3planes = w.s3planes;
   t_s3bytes = w.s3bytes;
+  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
   return run_head(h, B, T, w, logits, s);
 }
 
@@ -1578,6 +1636,7 @@ extern "C" int afx_conformer_forward(afx_handle h, const float* tokens, int B, i
   t_prof = h->prof;
   t_s3planes = w.s3planes;
   t_s3bytes = w.s3bytes;
+  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
   return run_conformer(h, B, T, w, logits, (hipStream_t)stream, tokens, embedding);
 }
 

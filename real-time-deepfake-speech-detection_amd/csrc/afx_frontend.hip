@@ -662,10 +662,23 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
           }
           if (a.out_f) *(f32x4*)(a.out_f + orow * a.ldo_f + c) = y;
           if (a.out_h) {
-            V4 h;
+            if (std::is_same<T, float>::value && a.oh_plane > 0) {  // split precision: the next product's A planes
+              f16x4 hi, lo;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) h[i] = (T)y[i];
-            *(V4*)((T*)a.out_h + orow * a.ldo_h + c) = h;
+              for (int i = 0; i < 4; ++i) {
+                const float sv = y[i] * kS3ActScale;
+                hi[i] = (_Float16)sv;
+                lo[i] = (_Float16)(sv - (float)hi[i]);
+              }
+              _Float16* hp = (_Float16*)a.out_h + orow * a.ldo_h + c;
+              *(f16x4*)hp = hi;
+              *(f16x4*)(hp + a.oh_plane) = lo;
+            } else {
+              V4 h;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) h[i] = (T)y[i];
+              *(V4*)((T*)a.out_h + orow * a.ldo_h + c) = h;
+            }
           }
         }
       }

@@ -317,9 +317,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         }
         if (p.out_h) {
           if constexpr (S3) {
-            float* op = (float*)p.out_h + hrow * p.ldo_h + gcol + n;
-            *(f32x4*)op = va;
-            *(f32x4*)(op + 4) = vb;
+            if (p.oh_plane > 0) {  // the next product's A operand: fp16 hi / lo planes of kS3ActScale x value
+              f16x8 hi, lo;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float sa = va[r] * kS3ActScale, sb = vb[r] * kS3ActScale;
+                hi[r] = (_Float16)sa;
+                hi[4 + r] = (_Float16)sb;
+                lo[r] = (_Float16)(sa - (float)hi[r]);
+                lo[4 + r] = (_Float16)(sb - (float)hi[4 + r]);
+              }
+              _Float16* hp = (_Float16*)p.out_h + hrow * p.ldo_h + gcol + n;
+              *(f16x8*)hp = hi;
+              *(f16x8*)(hp + p.oh_plane) = lo;
+            } else {
+              float* op = (float*)p.out_h + hrow * p.ldo_h + gcol + n;
+              *(f32x4*)op = va;
+              *(f32x4*)(op + 4) = vb;
+            }
           } else {
             V8 h;
 #pragma unroll
@@ -1146,6 +1161,8 @@ static const char* check_gemm(const GemmArgs& p, int groups) {
   if (p.kchunk <= 0 || p.kchunk % 64) return "gemm: kchunk must be a positive multiple of 64";
   if (p.rpb <= 0) return "gemm: rows-per-batch must be positive";
   if (!p.out_f && !p.out_h) return "gemm: no output";
+  if (p.oh_plane && (!p.k1 || (p.N & 7) || (p.act != ACT_NONE && p.act != ACT_GELU) || p.ln_gamma || (p.oh_plane & 7)))
+    return "gemm: plane output goes with the lean split-precision epilogue (N % 8 == 0, no / GELU activation)";
   if (p.k1) {
     if (p.k1 % 64 || p.K != 3 * p.k1 || !p.pre_scale || p.w_plane <= 0 || p.a_plane <= 0 || (p.a_plane & 7) || (p.w_plane & 7))
       return "gemm: split precision needs K = 3 k1, k1 % 64 == 0, both plane strides and the column scales";

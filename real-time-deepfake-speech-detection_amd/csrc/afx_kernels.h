@@ -59,6 +59,10 @@ struct GemmArgs {
   int k1;
   long a_plane, w_plane;
   const float* pre_scale;
+  // split precision, output side: oh_plane > 0 = `out_h` receives the result AS the next product's A operand -- fp16 hi at
+  // out_h, lo at out_h + oh_plane elements, of kS3ActScale x value -- instead of fp32 (the producer writes the planes, no
+  // separate split launch: launch_split_planes)
+  long oh_plane;
   int dbg_nodma;  // attribution build (-DAFX_ATTR) only, ignored otherwise: epilogue bits 8 no activation, 16 narrow stores, 32 no stores, 64 no epilogue
 };
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
@@ -116,6 +120,7 @@ struct RowNormArgs {
   void* out_h;
   long ldo_h;
   int rpb, o_batch_rows, o_row_off;
+  long oh_plane;  // split precision (with DT_FP32): > 0 = out_h receives fp16 hi / lo planes of kS3ActScale x y (lo at + oh_plane elements)
 };
 const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s);
 // zero the time padding rows of the positional-conv operand buffer (B, T+128, C)
@@ -152,7 +157,9 @@ const char* launch_posconv(const PosConvArgs& p, int dtype, hipStream_t s);
 const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t s, const int* lens = nullptr);
 
 // the same attention with fp32 rows in / out and split-precision products on the fp16 matrix pipe (dtype "fp16x3"); T <= 224
-const char* launch_mhsa_split(const float* qkv, float* out, int B, int T, int H, hipStream_t s, const int* lens = nullptr);
+// out_plane > 0: `out` receives fp16 hi / lo planes of kS3ActScale x the result (lo at + out_plane elements) instead of fp32 rows
+const char* launch_mhsa_split(const float* qkv, float* out, int B, int T, int H, hipStream_t s, const int* lens = nullptr,
+                              long out_plane = 0);
 // KV-cached streaming attention (afx_kv_step; not a reference function): ring (S, 256, 3*H*64) rows [q | k | v] in 16-slot
 // groups, cnt[16] valid frames per group, the queries are group q_tile's slots; out (S, 16, H*64)
 const char* launch_mhsa_ring(const void* ring, void* out, int S, int H, int q_tile, const int* cnt, int dtype, hipStream_t s);
