@@ -158,16 +158,5 @@ def test_fp32_teacher_every_utterance_within_tolerance():
     assert err.max().item() <= 1e-5
 
 
-def test_fp32_teacher_full_depth():
-    """BASELINE config 3 at its real depth (24 transformer layers, 4 s clips) in exact mode against the CPU oracle.
-    (The fp16 engine at this depth is gated per utterance in tests/test_gpu_teacher.py.)"""
-    from afx import engine, synth
-    from oracle import models
-    sd = synth.model_state_dict("XLSR_AASIST", n_layers=24)
-    wave = synth.waveforms(2, 64000, batch_idx=7)
-    ref = models.xlsr_aasist_forward(sd, wave)
-    ex = engine.Engine("xlsr_aasist", n_layers=24, dtype="fp32")
-    ex.load_state_dict(sd)
-    err = (ex.forward(wave.cuda()).cpu() - ref).abs().max().item()
-    print(f"teacher 24 layers, exact mode vs oracle: max|dlogit| {err:.2e}")
-    assert err <= 1e-4
+# (BASELINE config 3 at its real depth -- 24 layers, 4-s clips -- in exact mode and in split precision is gated on 48
+# utterances in tests/test_gpu_teacher.py::test_config3_teacher_unconditional_parity_modes, against one shared oracle pass.)
