@@ -604,6 +604,29 @@ def test_ragged_batch_scores_each_clip_as_if_alone(afx_mod, arch, tmp_path):
     assert torch.allclose(torch.tensor(scores), got[:, 1], atol=0, rtol=0)
 
 
+@pytest.mark.parametrize("arch", ["conformer", "xlsr_aasist"])
+def test_ragged_batch_in_split_precision(afx_mod, arch):
+    """The ragged forward in dtype "fp16x3" (producers write the next product's hi / lo operand planes in place, key-padding
+    masks in the split-precision attention): every clip equals itself alone bit for bit and the fp32 oracle to 1e-5."""
+    engine, synth = afx_mod
+    from oracle import models as omodels
+    if arch == "conformer":
+        sd = synth.model_state_dict("ConformerModel", n_layers=2, n_encoders=2)
+        eng = engine.Engine("conformer", n_layers=2, dtype="fp16x3", conf_blocks=2)
+        ofwd = omodels.conformer_forward
+    else:
+        sd = synth.model_state_dict("XLSR_AASIST", n_layers=2)
+        eng = engine.Engine("xlsr_aasist", n_layers=2, dtype="fp16x3")
+        ofwd = omodels.xlsr_aasist_forward
+    eng.load_state_dict(sd)
+    lens = [64000, 16000, 40321, 7000, 64000]
+    clips = [synth.waveforms(1, n, batch_idx=840 + i)[0] for i, n in enumerate(lens)]
+    got = eng.forward_ragged([c.cuda() for c in clips]).cpu()
+    for b, c in enumerate(clips):
+        assert torch.equal(got[b], eng.forward(c[None].cuda()).cpu()[0]), b
+        assert (got[b] - ofwd(sd, c[None])[0]).abs().max().item() <= 1e-5
+
+
 def test_ragged_bit_identity_holds_across_tile_families(afx_mod):
     """The same statement at a batch large enough that its dense products run on OTHER tile instances than a clip's alone
     (48 clips: QKV / FC1 / out-proj / FC2 on the 8-wave 256-wide tiles; one clip alone: 128 x 64 tiles) -- every tile instance
