@@ -123,7 +123,8 @@ int afx_tail_forward_strided(afx_handle h, const void* conv5_h, long batch_strid
  * build's own offline restatement oracle/streaming.py.  An afx_kv holds the per-stream state of
  * n_streams lock-stepped streams (K / V rings of every layer, the positional conv's left context, the feature window);
  * afx_kv_step consumes the NEW frames of conv layer 6 of every stream, (n_streams, n, 512) fp32 with 1 <= n <= 16, and
- * returns the back-end's logits on the window that ends with this chunk. */
+ * returns the back-end's logits on the window that ends with this chunk.  The handle must outlive its afx_kv objects; weights
+ * reloaded into the handle do not refresh keys / values already cached. */
 typedef struct afx_kv afx_kv;
 int afx_kv_create(afx_handle h, int n_streams, afx_kv** out);
 void afx_kv_destroy(afx_kv* kv);
@@ -170,7 +171,9 @@ int afx_engine_set(afx_handle h, const char* key, int value);
 int afx_debug_set(const char* key, int value);
 
 /* ---- single-kernel entry points (unit parity tests; operand pointers are bf16 or
- * fp16 device arrays according to `dtype`) ---------------------------------------- */
+ * fp16 device arrays according to `dtype`; fp32 arrays for AFX_DT_FP32 and, in afx_k_gemm / afx_k_mhsa, for
+ * AFX_DT_FP16X3: the split-precision forms take and return fp32 -- afx_k_gemm then builds the hi / lo operand forms
+ * per call in temporary device memory and synchronises: a test hook) --------------------------------------------- */
 int afx_k_gemm(int dtype, const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
                int act, float alpha, const float* resid, long ldr, float* out_f, long ldo_f, void* out_h, long ldo_h,
                void* stream);
