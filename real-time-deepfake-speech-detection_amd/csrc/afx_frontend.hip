@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void conv0_pack_kernel(const float* __restrict
   }
 }
 
-template <class HT, bool NTS = false>  // NTS (A/B knob conv0_mfma = 3): non-temporal output stores
+template <class HT>
 __global__ __launch_bounds__(256, 2) void conv0_split_kernel(const float* __restrict__ wave, int L, int T0,
                                                           const _Float16* __restrict__ pack, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int pre_emph, float pre_coef,
@@ -381,10 +381,7 @@ __global__ __launch_bounds__(256, 2) void conv0_split_kernel(const float* __rest
         h[r] = (T)__uint_as_float(sw[0]);
         h[4 + r] = (T)__uint_as_float(sw[1]);
       }
-      if (f < T0) {
-        if constexpr (NTS) __builtin_nontemporal_store(h, (V8*)(orow + cp * 32 + cb));
-        else *(V8*)(orow + cp * 32 + cb) = h;
-      }
+      if (f < T0) *(V8*)(orow + cp * 32 + cb) = h;
     }
   }
 }
@@ -515,13 +512,6 @@ const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w
                          const float* gamma, const float* beta, int pre_emph, float pre_coef, void* out_h,
                          int dtype, hipStream_t s, const void* wpack) {
   if (B <= 0 || L < 10 || T0 != (L - 10) / 5 + 1) return "conv0: bad shape";
-  if (dtype == DT_FP16 && g_conv0_mfma == 3 && wpack) {  // A/B: the same kernel with non-temporal output stores
-    dim3 grid((T0 + C0M_FB - 1) / C0M_FB, B);
-    hipLaunchKernelGGL((conv0_split_kernel<FP16, true>), grid, dim3(256), 0, s, wave, L, T0, (const _Float16*)wpack, gamma, beta,
-                       pre_emph, pre_coef, (_Float16*)out_h);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? nullptr : hipGetErrorString(e);
-  }
   if (dtype != DT_FP32 && g_conv0_mfma == 1 && wpack) {  // split precision on the fp16 matrix pipe (packed operand given)
     dim3 grid((T0 + C0M_FB - 1) / C0M_FB, B);
     if (dtype == DT_BF16)
