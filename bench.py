@@ -195,7 +195,7 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32", "fp16x3"],
                     help="fp16 (default; no environment override) / bf16 matrix-core operands, fp32 = exact mode, fp16x3 = split precision")
     ap.add_argument("--cpu-sample", type=int, default=8, help="utterances timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--no-overlap", action="store_true", help="teacher: back-end on the trunk's stream (no head / trunk overlap across steps)")
+    ap.add_argument("--no-overlap", action="store_true", help="back-end on the trunk's stream (no head / trunk overlap across steps)")
     ap.add_argument("--no-config3", action="store_true", help="skip the teacher (BASELINE configs[2]/[3]) side measurement")
     ap.add_argument("--allow-parity-miss", action="store_true", help="report, do not fail, when the parity sample misses 1e-3")
     args = ap.parse_args()
@@ -218,11 +218,13 @@ def main():
     from afx.dist import all_gather_scores
 
     def make_step(w):
-        """One step = one forward of the hot path over the resident batch (+ the RCCL score all-gather when N > 1).  The
-        teacher's steps are issued the way the scoring loop issues them (afx.harness.produce_evaluation_file): graph
-        back-end of step i on the engine's side stream under the trunk of step i+1, scores read after the last step."""
+        """One step = one forward of the hot path over the resident batch (+ the RCCL score all-gather when N > 1).  Steps
+        are issued the way the scoring loop issues them (afx.harness.produce_evaluation_file): the back-end of step i
+        (Conformer head / AASIST graph head) on the engine's side stream under the trunk of step i+1, scores read after
+        the last step; every step completes inside the timed region (the current stream joins the side stream before
+        the closing event and synchronize)."""
         idx = torch.arange(rank * w["B"], (rank + 1) * w["B"], dtype=torch.int32, device="cuda")
-        overlapped = w["arch"] == "xlsr_aasist" and not args.no_overlap
+        overlapped = not args.no_overlap
 
         def step():
             if not overlapped:
@@ -233,7 +235,10 @@ def main():
                 with torch.cuda.stream(w["eng"]._side):
                     return all_gather_scores(idx, scores, world)
             return idx, scores
-        return step, (w["eng"].join if overlapped else None)
+
+        def join():
+            w["eng"].join()
+        return step, (join if overlapped else None)
 
     w = build(args.workload, args.dtype, args.batch, args.seconds, rank)
     arch, oname, n_layers, gflop, B, L, sd, eng, wave = (w[k] for k in ("arch", "oname", "n_layers", "gflop", "B", "L", "sd", "eng", "wave"))
@@ -257,7 +262,8 @@ def main():
         "device_ms_per_step": round(dev_ms, 3),
         "roofline": roofline,
         "kernel_ms_per_step": breakdown,
-        "kernel_ms_note": "hipEvent pairs around every launch in a second, instrumented pass: each class reads ~3 % high",
+        "kernel_ms_note": "hipEvent pairs around every launch in a second, instrumented pass (one stream): each class reads ~3 % high",
+        "issue": "back-end of step i on a side stream under the trunk of step i+1 (the scoring loop's form)" if w_join else "one stream",
     }
 
     # ---- the same K steps with the host hand-over inside: pinned fp32 waveform H2D (256 KB per

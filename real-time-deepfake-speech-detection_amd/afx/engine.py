@@ -140,7 +140,10 @@ class Engine:
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream(self.device)
             if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream(device=self.device)
+                # high priority: the short back-end should not queue behind the next trunk's tiles, and ROCm keeps priority
+                # streams on hardware queues of their own (a normal-priority stream created after RCCL's can share the
+                # trunk stream's queue -- the overlap is then silently lost, tools/diag_dist_overlap.py)
+                self._side = torch.cuda.Stream(device=self.device, priority=-1)
                 self._ov = [dict(ws=None, head_done=None), dict(ws=None, head_done=None)]
                 self._ov_i = 0
             slot = self._ov[self._ov_i]

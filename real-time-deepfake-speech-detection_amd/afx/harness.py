@@ -133,7 +133,7 @@ def prefetch_to_device(batches, device):
     # every stream below is a stream OF `dev`, whatever torch's current device is (the reference passes device=rank and
     # never calls torch.cuda.set_device, main.py:48): the copy runs on a side stream of the engine's GPU and the wait
     # goes to that GPU's compute stream
-    side = torch.cuda.Stream(device=dev)
+    side = torch.cuda.Stream(device=dev, priority=-1)  # (a hardware queue of its own: see Engine.forward_overlapped)
     it = iter(batches)
 
     def stage(item):
@@ -162,9 +162,9 @@ def produce_evaluation_file(dataset, model, device, save_path, batch_size, num_w
     current forward (the reference's ``batch_x.to(device)`` is blocking)."""
     model.eval()
     names, chunks = [], []
-    # models with a graph back-end (XLSR_AASIST) run it on a side stream under the next batch's trunk: the scores are only
-    # read after the last batch, so nothing waits for a head inside the loop
-    overlapped = getattr(model, "afx_arch", None) == "xlsr_aasist" and hasattr(model, "forward_overlapped")
+    # the back-end of a batch (Conformer head: +5 %, AASIST graph head: +5.7 %) runs on a side stream under the next batch's
+    # trunk: the scores are only read after the last batch, so nothing waits for a head inside the loop
+    overlapped = getattr(model, "afx_arch", None) in ("xlsr_aasist", "conformer") and hasattr(model, "forward_overlapped")
     with torch.no_grad():
         loader = ((utt_id, batch_x) for utt_id, batch_x, _label in _loader(dataset, batch_size, num_workers))
         for utt_id, x in prefetch_to_device(loader, device):
@@ -307,7 +307,7 @@ def _produce_evaluation_file_distributed(dataset, model, device, save_path, batc
     model.eval()
     scores = torch.zeros(idx.numel(), dtype=torch.float32, device=device)
     names, outs = {}, []
-    overlapped = getattr(model, "afx_arch", None) == "xlsr_aasist" and hasattr(model, "forward_overlapped")
+    overlapped = getattr(model, "afx_arch", None) in ("xlsr_aasist", "conformer") and hasattr(model, "forward_overlapped")
     with torch.no_grad():
         loader = (((i, utt), x) for i, utt, x, _label in _loader(_Shard(dataset, idx.tolist()), batch_size, num_workers))
         for (i, utt), x in prefetch_to_device(loader, device):

@@ -208,15 +208,24 @@ def test_teacher_to_student_layer_copy_like_main_kd():
     assert (got - ref).abs().max().item() <= 1e-3
 
 
-def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_path):
+@pytest.mark.parametrize("arch", ["xlsr_aasist", "conformer"])
+def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_path, arch):
     """main.py:199-221 scores batch after batch and reads the scores at the end; afx.harness.produce_evaluation_file issues
-    the AASIST back-end of batch i on a side stream under the trunk of batch i+1 (afx_trunk_forward /
-    afx_head_from_workspace, two workspaces alternating).  Same kernels on the same data: every score must equal the
-    one-stream forward's bit for bit, over more batches than workspaces, a ragged last batch and changing batch sizes."""
+    the back-end of batch i (AASIST graph head / Conformer head) on a side stream under the trunk of batch i+1
+    (afx_trunk_forward / afx_head_from_workspace, two workspaces alternating).  Same kernels on the same data: every score
+    must equal the one-stream forward's bit for bit, over more batches than workspaces, a ragged last batch and changing
+    batch sizes."""
     from afx import engine, harness, synth
-    from models.xlsr_aasist import My_XLSR_AASIST
-    sd = synth.model_state_dict("XLSR_AASIST", n_layers=2, head_scale=1.5)
-    eng = engine.Engine("xlsr_aasist", n_layers=2, dtype="fp16")
+    if arch == "xlsr_aasist":
+        from models.xlsr_aasist import My_XLSR_AASIST as Cls
+        sd = synth.model_state_dict("XLSR_AASIST", n_layers=2, head_scale=1.5)
+        eng = engine.Engine("xlsr_aasist", n_layers=2, dtype="fp16")
+        kw = {}
+    else:
+        from models.conformer_baseline import MyModel as Cls
+        sd = synth.model_state_dict("ConformerModel", n_layers=2, n_encoders=2)
+        eng = engine.Engine("conformer", n_layers=2, dtype="fp16", conf_blocks=2)
+        kw = dict(n_encoders=2)
     eng.load_state_dict(sd)
     waves = [synth.waveforms(b, 16000, batch_idx=700 + i).cuda() for i, b in enumerate([5, 5, 5, 3, 7, 5, 1])]
     want = [eng.forward(w).clone() for w in waves]
@@ -233,7 +242,7 @@ def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_p
 
         def __getitem__(self, i):
             return f"utt{i}", synth.waveforms(1, 16000, batch_idx=900 + i)[0], 0
-    model = My_XLSR_AASIST(device="cuda", ssl_cpkt_path=None, num_layers=2, order="first").to("cuda").eval()
+    model = Cls(device="cuda", ssl_cpkt_path=None, num_layers=2, order="first", **kw).to("cuda").eval()
     model.load_state_dict(sd)
     names, scores = harness.produce_evaluation_file(Toy(), model, "cuda", str(tmp_path / "s.txt"), batch_size=4, num_workers=0)
     with torch.no_grad():
@@ -241,4 +250,3 @@ def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_p
     assert names == [f"utt{i}" for i in range(13)]
     assert torch.equal(torch.tensor(scores, dtype=torch.float32), ref)
     assert (tmp_path / "s.txt").read_text().splitlines()[0].startswith("utt0 ")
-

@@ -1,0 +1,95 @@
+"""Diagnostic (not a test, not the bench): the two-stream scoring step next to RCCL.  World size 1 on one GPU
+(RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=...), student, batch 64 x 4 s.
+
+Finding (profiles/r03_k_dist_overlap_hw_queues.txt): with a NORMAL-priority side stream, bringing up the process group
+before the engine's streams exist costs the whole head / trunk overlap, with or without a collective in the step -- the
+side stream then shares one of ROCm's 4 default hardware queues with the trunk's stream (DIAG_LATE_PG=1 or
+GPU_MAX_HW_QUEUES=8 bring it back, the latter not in every process).  A HIGH-priority side stream (what the engine
+creates now) keeps the overlap in every order and queue count.  Where the all-gather sits (head's stream, third stream,
+a step late) makes no measurable difference.
+    DIAG_NO_PG=1    no process group at all (the single-process reference point)
+    DIAG_LATE_PG=1  process group after the engine's first two-stream forward"""
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "real-time-deepfake-speech-detection_amd")]
+from afx import engine, synth  # noqa: E402
+from afx.dist import all_gather_scores  # noqa: E402
+
+
+def main():
+    torch.cuda.set_device(0)
+    with_pg = os.environ.get("DIAG_NO_PG") != "1"
+    late_pg = os.environ.get("DIAG_LATE_PG") == "1"  # the engine's two streams are created and USED before RCCL comes up
+    if with_pg and not late_pg:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    sd = synth.model_state_dict("ConformerModel", n_layers=6)
+    eng = engine.Engine("conformer", n_layers=6, dtype="fp16")
+    eng.load_state_dict(sd)
+    wave = synth.waveforms(64, 64000, batch_idx=0).cuda()
+    if with_pg and late_pg:
+        eng.forward_overlapped(wave)
+        eng.join()
+        torch.cuda.synchronize()
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    idx = torch.arange(64, dtype=torch.int32, device="cuda")
+    third = torch.cuda.Stream()
+    steps = 30
+
+    def run(name, step, join):
+        for _ in range(5):
+            step()
+        join()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        join()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        print(f"{name:58s} {dt * 1e3:7.3f} ms/step {64 / dt:9.1f} utt/s", flush=True)
+
+    run("one stream, no collective", lambda: eng.forward(wave), lambda: None)
+    run("two streams, no collective", lambda: eng.forward_overlapped(wave), eng.join)
+    if not with_pg:
+        return
+    run("one stream + all-gather", lambda: all_gather_scores(idx, eng.forward(wave)[:, 1], 1), lambda: None)
+
+    def side_sync():
+        s = eng.forward_overlapped(wave)[:, 1]
+        with torch.cuda.stream(eng._side):
+            all_gather_scores(idx, s, 1)
+    run("two streams + all-gather on the head's stream (sync op)", side_sync, eng.join)
+
+    pend = []
+
+    def late():
+        s = eng.forward_overlapped(wave)[:, 1]
+        ev = torch.cuda.Event()
+        ev.record(eng._side)
+        pend.append((s, ev))
+        if len(pend) > 1:  # the collective of step i-1, after step i's kernels are queued, on a third stream
+            ps, pev = pend.pop(0)
+            third.wait_event(pev)
+            with torch.cuda.stream(third):
+                all_gather_scores(idx, ps, 1)
+
+    def late_join():
+        while pend:
+            ps, pev = pend.pop(0)
+            third.wait_event(pev)
+            with torch.cuda.stream(third):
+                all_gather_scores(idx, ps, 1)
+        torch.cuda.current_stream().wait_stream(third)
+        eng.join()
+    run("two streams + all-gather one step late on a third stream", late, late_join)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
