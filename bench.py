@@ -40,7 +40,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "real-time-deepfake-speech-detection_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
-
 import torch  # noqa: E402
 
 # dense matrix-core peaks, MI355X_MICROARCH.md "Chip-level parameters" (fp32: the exact-mode MFMA, 1/16 of fp16)
@@ -208,6 +207,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X-native path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    from afx.engine import side_stream
+    # the engine's side stream takes its hardware queue before RCCL's streams exist (ROCm shares 4 queues among a process's
+    # streams in order of first use; on a shared queue the head runs behind the next trunk, not beside it -- and MORE than 4
+    # queues, GPU_MAX_HW_QUEUES=8 or a high-priority stream, made the two-stream step 2x slower: afx/engine.py::side_stream)
+    side_stream(torch.device("cuda", local_rank))
     dist = None
     use_dist = world > 1 or os.environ.get("AFX_FORCE_DIST") == "1"  # the env knob rehearses the RCCL path on one GPU
     if use_dist:

@@ -8,11 +8,12 @@ ddp_util.py).  Unlike its DistributedSampler (main.py:33-39) nothing is duplicat
 shuffled: ranks take i = r (mod W), short shards are padded with the sentinel -1, and
 the merged list is restored to dataset order before it is written.
 
-Hardware queues: ROCm maps normal-priority HIP streams onto 4 hardware queues.  RCCL brings up streams of its own, after
-which a normal-priority stream created later can share the trunk stream's queue: results stay identical but whatever was
-meant to run beside the trunk runs behind it (measured: the head / trunk overlap of Engine.forward_overlapped lost whole,
-4.87 -> 5.13 ms per student step, tools/diag_dist_overlap.py, profiles/r03_k_dist_overlap_hw_queues.txt).  The engine's
-side stream and the scoring loop's copy stream are therefore HIGH-priority streams, which ROCm keeps on queues of their own.
+Hardware queues: ROCm maps a process's HIP streams onto 4 hardware queues in order of first use and shares them from the fifth
+stream on.  RCCL brings up streams of its own; a stream first used after that can share the trunk stream's queue: results stay
+identical but whatever was meant to run beside the trunk runs behind it (measured: the head / trunk overlap of
+Engine.forward_overlapped lost whole, 4.95 -> 5.20 ms per student step).  So: ``afx.engine.side_stream(device)`` BEFORE
+``init_process_group`` (bench.py does).  Neither GPU_MAX_HW_QUEUES=8 nor high-priority streams: more than 4 queues in use
+made the two-stream step 2x slower (tools/diag_dist_overlap.py, profiles/r03_k_dist_overlap_hw_queues.txt).
 """
 import torch
 import torch.distributed as dist

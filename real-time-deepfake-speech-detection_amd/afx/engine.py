@@ -37,6 +37,32 @@ def _cuda_device(device):
     return d if d.index is not None else torch.device("cuda", torch.cuda.current_device())
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """THE side stream of a GPU (one per device and process, shared by its engines): where ``forward_overlapped`` runs the
+    back-ends.  Normal priority; created and USED once, here, so that it owns its hardware queue from then on.  ROCm maps the
+    streams of a process onto 4 hardware queues (GPU_MAX_HW_QUEUES) in order of first use and shares them from the fifth
+    stream on: a side stream first used AFTER RCCL had brought up its streams landed on the queue of torch's default stream
+    -- same scores, the overlap silently lost (tools/diag_dist_overlap.py).  A host that uses a process group calls this
+    (or builds its engine and runs one forward_overlapped) BEFORE ``init_process_group``.  Raising the queue count is NOT
+    the answer: with more than 4 hardware queues in use (GPU_MAX_HW_QUEUES=8 next to RCCL, or one high-priority stream,
+    which brings queues of its own) the two-stream step measured 2x SLOWER than the one-stream step -- 10.1-10.8 ms
+    instead of 4.75 for the teacher (profiles/r03_k_dist_overlap_hw_queues.txt)."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        with torch.cuda.device(key):
+            s = torch.cuda.Stream(device=key)
+            ev = torch.cuda.Event()
+            ev.record(s)  # first use: the stream acquires its hardware queue now
+            ev.synchronize()
+        _SIDE_STREAMS[key] = s
+    return s
+
+
 class Engine:
     """One native engine = one GPU.  The handle's packed weights, the workspace and every launch live on
     ``self.device`` (fixed at construction: the given device, else the current one) whatever torch's current
@@ -140,10 +166,7 @@ class Engine:
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream(self.device)
             if getattr(self, "_side", None) is None:
-                # high priority: the short back-end should not queue behind the next trunk's tiles, and ROCm keeps priority
-                # streams on hardware queues of their own (a normal-priority stream created after RCCL's can share the
-                # trunk stream's queue -- the overlap is then silently lost, tools/diag_dist_overlap.py)
-                self._side = torch.cuda.Stream(device=self.device, priority=-1)
+                self._side = side_stream(self.device)
                 self._ov = [dict(ws=None, head_done=None), dict(ws=None, head_done=None)]
                 self._ov_i = 0
             slot = self._ov[self._ov_i]

@@ -133,7 +133,7 @@ def prefetch_to_device(batches, device):
     # every stream below is a stream OF `dev`, whatever torch's current device is (the reference passes device=rank and
     # never calls torch.cuda.set_device, main.py:48): the copy runs on a side stream of the engine's GPU and the wait
     # goes to that GPU's compute stream
-    side = torch.cuda.Stream(device=dev, priority=-1)  # (a hardware queue of its own: see Engine.forward_overlapped)
+    side = torch.cuda.Stream(device=dev)
     it = iter(batches)
 
     def stage(item):

@@ -1,12 +1,12 @@
 """Diagnostic (not a test, not the bench): the two-stream scoring step next to RCCL.  World size 1 on one GPU
 (RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=...), student, batch 64 x 4 s.
 
-Finding (profiles/r03_k_dist_overlap_hw_queues.txt): with a NORMAL-priority side stream, bringing up the process group
-before the engine's streams exist costs the whole head / trunk overlap, with or without a collective in the step -- the
-side stream then shares one of ROCm's 4 default hardware queues with the trunk's stream (DIAG_LATE_PG=1 or
-GPU_MAX_HW_QUEUES=8 bring it back, the latter not in every process).  A HIGH-priority side stream (what the engine
-creates now) keeps the overlap in every order and queue count.  Where the all-gather sits (head's stream, third stream,
-a step late) makes no measurable difference.
+Finding (profiles/r03_k_dist_overlap_hw_queues.txt): bringing up the process group before the engine's side stream has been
+used costs the whole head / trunk overlap, with or without a collective in the step -- the side stream then shares one of
+ROCm's 4 hardware queues with the trunk's stream.  Using the side stream first (DIAG_LATE_PG=1; afx.engine.side_stream) keeps
+it.  More queues (GPU_MAX_HW_QUEUES=8) or a high-priority side stream look like fixes here and are not: in bench.py, with
+RCCL up, they made the two-stream step 2x slower than the one-stream step.  Where the all-gather sits (head's stream, third
+stream, a step late) makes no measurable difference.
     DIAG_NO_PG=1    no process group at all (the single-process reference point)
     DIAG_LATE_PG=1  process group after the engine's first two-stream forward"""
 import os
