@@ -212,6 +212,7 @@ def main():
     # streams in order of first use; on a shared queue the head runs behind the next trunk, not beside it -- and MORE than 4
     # queues, GPU_MAX_HW_QUEUES=8 or a high-priority stream, made the two-stream step 2x slower: afx/engine.py::side_stream)
     side_stream(torch.device("cuda", local_rank))
+    side_stream(torch.device("cuda", local_rank), "copy")
     dist = None
     use_dist = world > 1 or os.environ.get("AFX_FORCE_DIST") == "1"  # the env knob rehearses the RCCL path on one GPU
     if use_dist:
@@ -278,19 +279,23 @@ def main():
         # untimed warm-up of both hand-over loops (side stream, the allocator's blocks for the staged batches)
         for _ in range(2):
             eng.forward(host_wave.to("cuda", non_blocking=True))[:, 1].cpu()
+        fwd = eng.forward if args.no_overlap else eng.forward_overlapped
         for _m, x in prefetch_to_device(((i, host_wave) for i in range(3)), "cuda"):
-            eng.forward(x)
+            fwd(x)
+        eng.join()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             host_scores = eng.forward(host_wave.to("cuda", non_blocking=True))[:, 1].cpu()
         e2e = time.perf_counter() - t0
         result["with_pcie"] = {"value": round(B * args.steps / e2e, 2), "unit": "utterances/s",
-                               "note": "H2D of the batch + forward + D2H of the scores every step, one stream, no overlap"}
-        # the scoring loop's form (afx.harness.prefetch_to_device): next batch's H2D on a side stream
+                               "note": "H2D of the batch + forward + D2H of the scores every step, one stream, no overlap; `overlapped`: the "
+                                       "scoring loop's form (afx.harness.produce_evaluation_file) -- next batch's H2D on the copy stream, "
+                                       "back-end under the next trunk, one D2H of all scores at the end"}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        outs = [eng.forward(x)[:, 1] for _m, x in prefetch_to_device(((i, host_wave) for i in range(args.steps)), "cuda")]
+        outs = [fwd(x)[:, 1] for _m, x in prefetch_to_device(((i, host_wave) for i in range(args.steps)), "cuda")]
+        eng.join()
         host_scores = torch.cat(outs).cpu()
         e2e = time.perf_counter() - t0
         result["with_pcie"]["overlapped"] = round(B * args.steps / e2e, 2)

@@ -40,7 +40,7 @@ def _cuda_device(device):
 _SIDE_STREAMS = {}
 
 
-def side_stream(device):
+def side_stream(device, role="head"):
     """THE side stream of a GPU (one per device and process, shared by its engines): where ``forward_overlapped`` runs the
     back-ends.  Normal priority; created and USED once, here, so that it owns its hardware queue from then on.  ROCm maps the
     streams of a process onto 4 hardware queues (GPU_MAX_HW_QUEUES) in order of first use and shares them from the fifth
@@ -49,13 +49,15 @@ def side_stream(device):
     (or builds its engine and runs one forward_overlapped) BEFORE ``init_process_group``.  Raising the queue count is NOT
     the answer: with more than 4 hardware queues in use (GPU_MAX_HW_QUEUES=8 next to RCCL, or one high-priority stream,
     which brings queues of its own) the two-stream step measured 2x SLOWER than the one-stream step -- 10.1-10.8 ms
-    instead of 4.75 for the teacher (profiles/r03_k_dist_overlap_hw_queues.txt)."""
+    instead of 4.75 for the teacher (profiles/r03_k_dist_overlap_hw_queues.txt).
+    role "copy": the second (and last) such stream of a GPU, for the scoring loop's H2D prefetch (afx.harness.prefetch_to_device)
+    -- cached for the same reason: a fresh stream per scoring pass would run the process into shared queues after a few passes."""
     device = torch.device(device)
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.index if device.index is not None else torch.cuda.current_device(), role)
     s = _SIDE_STREAMS.get(key)
     if s is None:
-        with torch.cuda.device(key):
-            s = torch.cuda.Stream(device=key)
+        with torch.cuda.device(key[0]):
+            s = torch.cuda.Stream(device=key[0])
             ev = torch.cuda.Event()
             ev.record(s)  # first use: the stream acquires its hardware queue now
             ev.synchronize()

@@ -133,7 +133,8 @@ def prefetch_to_device(batches, device):
     # every stream below is a stream OF `dev`, whatever torch's current device is (the reference passes device=rank and
     # never calls torch.cuda.set_device, main.py:48): the copy runs on a side stream of the engine's GPU and the wait
     # goes to that GPU's compute stream
-    side = torch.cuda.Stream(device=dev)
+    from .engine import side_stream
+    side = side_stream(dev, "copy")  # one per GPU and process (hardware queues: see engine.side_stream)
     it = iter(batches)
 
     def stage(item):
