@@ -460,6 +460,35 @@ def test_engine_is_bound_to_its_device_not_to_the_current_one(afx_mod):
         engine.Engine("ssl", n_layers=1, device="cpu")
 
 
+def test_one_side_stream_and_one_copy_stream_per_gpu(afx_mod):
+    """Hardware queues are a per-process resource shared among streams in order of first use (afx.engine.side_stream): every
+    engine of a GPU runs its back-ends on THE side stream of that GPU and every scoring pass stages on THE copy stream -- no
+    fresh stream per engine or per pass, none of them a priority stream, and both distinct from torch's current stream."""
+    engine, synth = afx_mod
+    from afx.harness import prefetch_to_device
+    side, copy = engine.side_stream("cuda:0"), engine.side_stream(torch.device("cuda", 0), "copy")
+    assert side is engine.side_stream(0) and copy is engine.side_stream("cuda:0", "copy")
+    cur = torch.cuda.current_stream()
+    assert len({side.cuda_stream, copy.cuda_stream, cur.cuda_stream}) == 3
+    assert side.priority == 0 and copy.priority == 0
+    sd = synth.model_state_dict("ConformerModel", n_layers=1, n_encoders=1)
+    wave = synth.waveforms(2, 16000, batch_idx=7).cuda()
+    outs = []
+    for _ in range(2):  # two engines, one side stream
+        eng = engine.Engine("conformer", n_layers=1, dtype="fp16", conf_blocks=1)
+        eng.load_state_dict(sd)
+        got = eng.forward_overlapped(wave)
+        assert eng._side is side
+        eng.join()
+        assert torch.equal(got, eng.forward(wave))
+        outs.append(got.clone())
+    assert torch.equal(outs[0], outs[1])
+    host = wave.cpu()
+    for _ in range(3):  # three passes, one copy stream: the staged batches arrive intact
+        for _meta, x in prefetch_to_device(((i, host) for i in range(3)), "cuda:0"):
+            assert torch.equal(x.cpu(), host)
+
+
 class _FakeOtherDevice:
     """Stands for a tensor on another GPU (this box has one): only what Engine._on_device looks at."""
     is_cuda = True
