@@ -157,6 +157,29 @@ def roofline_of(w, workload, dtype, steps):
     return roofline, breakdown
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# SURVEY.md section 8(d), "algorithmic work per utterance": the MINIMUM HBM traffic of the path (half-precision activations, every
+# tensor written once and read once, weights once per batch): conv-stack activations 26.0 MB written + 26.0 MB read, the residual
+# stream 2 x 0.41 MB and the FFN intermediate 1.63 MB per transformer layer, the waveform 0.256 MB; weights 630.9 MB (24 layers) /
+# 177 MB (6 layers) per batch.
+def path_roofline(value, gflop, n_layers, batch, dtype):
+    mb_per_utt = 52.0 + n_layers * (2 * 0.41 + 1.63) + 0.256 + (630.9 if n_layers == 24 else 177.0) / batch
+    tbs = value * mb_per_utt / 1e6
+    return {"mfma_frac": round(value * gflop / 1e3 / MFMA_PEAK_TFLOPS[dtype], 4), "hbm_frac": round(tbs / 8.0, 4),
+            "min_mb_per_utterance": round(mb_per_utt, 1),
+            "note": "whole path: model FLOPs x utt/s / dense matrix-core peak; SURVEY 8(d)'s minimum HBM bytes x utt/s / 8 TB/s"}
+
+
 def cpu_parity(w, cpu_sample):
     """The CPU oracle on this box's host cores over a bounded sample of the workload's own utterances (rank 0, N = 1):
     (cpu_baseline, parity) -- the oracle's rate and the GPU-vs-oracle |dlogit| of that sample."""
@@ -175,7 +198,7 @@ def cpu_parity(w, cpu_sample):
         cpu_s += time.perf_counter() - t0
         reps += 1
     got = w["eng"].forward(w["wave"])[:n].cpu()
-    base = {"value": round(n * reps / cpu_s, 3), "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+    base = {"value": round(n * reps / cpu_s, 3), "unit": "utterances/s", "cores": torch.get_num_threads(), "cpu": cpu_model(), "kind": "port",
             "sample": f"{reps} batched fp32 forward(s) of the CPU oracle (PyTorch CPU) over {n} of the same 4 s "
                       f"utterances, {cpu_s:.1f} s in all"}
     per_utt = (got - ref).abs().max(dim=1)[0]
@@ -264,6 +287,7 @@ def main():
                    "global_batch": world * B, "samples_per_utterance": L,
                    "parallelism": f"dp{world} (utterance sharding, RCCL score all-gather)" if world > 1 else "single GPU"},
         "model_tflops": round(value * gflop / 1e3, 1),
+        "path_roofline": path_roofline(value / world, gflop, n_layers, B, args.dtype),
         "device_ms_per_step": round(dev_ms, 3),
         "roofline": roofline,
         "kernel_ms_per_step": breakdown,
@@ -320,6 +344,7 @@ def main():
             "value": round(world * t["B"] * args.steps / el, 2), "unit": "utterances/s", "n_gpus": world,
             "global_batch": world * t["B"], "ms_per_step": round(el / args.steps * 1e3, 3),
             "device_ms_per_step": round(dms, 3), "model_tflops": round(world * t["B"] * args.steps / el * t["gflop"] / 1e3, 1),
+            "path_roofline": path_roofline(t["B"] * args.steps / el, t["gflop"], t["n_layers"], t["B"], args.dtype),
             "dtype": args.dtype, "roofline": t_roof, "kernel_ms_per_step": t_break,
             "issue": "back-end of step i on a side stream under the trunk of step i+1 (the scoring loop's form)" if t_join else "one stream",
         }
