@@ -98,6 +98,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise AfxError(f"{LIB_PATH} is missing: the HIP library has not been built "
                            "(run __graft_entry__.build()); there is no CPU fallback")
+        # torch first: its wheel bundles a HIP / HSA runtime of its own, and the process must end up with ONE.  Loaded after
+        # torch, libafx.so's libamdhip64 / libhsa-runtime64 resolve to the copies torch already holds; loaded before it, the
+        # system copies come in as a second runtime and whichever initialises second sees no device (found by running
+        # __graft_entry__.build() and smoke() in one process on a GPU box).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
