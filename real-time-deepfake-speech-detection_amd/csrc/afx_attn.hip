@@ -72,9 +72,12 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typ
     static_assert(KEYS * 8 % NT == 0, "staging loop shape");
     u32x4 kreg[IT];
     V8 vreg[IT];
+    // thread -> 16-byte column c of IT CONSECUTIVE keys (kg IT .. kg IT + IT - 1): the V^T image then takes one IT-key vector
+    // per dimension (8 writes of 2 IT bytes per thread) instead of 8 IT two-byte scatters
+    const int c = tid & 7, kg = tid >> 3;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const int idx = tid + it * NT, key = idx >> 3, c = idx & 7;
+      const int key = kg * IT + it;
       kreg[it] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
       for (int i = 0; i < 8; ++i) vreg[it][i] = (Tt)0.f;
@@ -86,11 +89,25 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typ
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const int idx = tid + it * NT, key = idx >> 3, c = idx & 7;
+      const int key = kg * IT + it;
       *(u32x4*)(k_lds + key * 128 + ((c ^ ((key >> 1) & 7)) * 16)) = kreg[it];
-      if (!(MHSA_DBG & 4)) {
+    }
+    if (!(MHSA_DBG & 4)) {
+      if constexpr (IT == 2 || IT == 4 || IT == 8) {
+        typedef Tt __attribute__((ext_vector_type(IT))) VK;
+        static_assert(ATT_VT_STRIDE % IT == 0, "V^T rows keep the key vectors aligned");
 #pragma unroll
-        for (int i = 0; i < 8; ++i) vt_lds[(c * 8 + i) * ATT_VT_STRIDE + key] = vreg[it][i];
+        for (int i = 0; i < 8; ++i) {
+          VK col;
+#pragma unroll
+          for (int it = 0; it < IT; ++it) col[it] = vreg[it][i];
+          *(VK*)(vt_lds + (c * 8 + i) * ATT_VT_STRIDE + kg * IT) = col;
+        }
+      } else {  // (the 4-wave A/B instance at 224 keys: 7 keys per thread, element by element)
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) vt_lds[(c * 8 + i) * ATT_VT_STRIDE + kg * IT + it] = vreg[it][i];
       }
     }
   }
