@@ -37,7 +37,10 @@ struct MhsaRing {
   int q_tile;
   unsigned char cnt[16];
 };
-template <class HT, int KS, int NW, bool RING = false>  // KS = number of 32-key steps actually computed
+// VTR (round 3): V stays ROW-major in LDS (staged exactly like K: one swizzled 16-byte write per loaded chunk, no transposing
+// scatter) and the V^T fragments of P.V come from `ds_read_b64_tr_b16` -- per 16-lane group a block of 4 keys x 16 dims delivered
+// column-major, i.e. lane (dim) gets its 4 consecutive keys, the same registers the V^T image gave.
+template <class HT, int KS, int NW, bool RING = false, bool VTR = false>  // KS = number of 32-key steps actually computed
 __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typename HT::T* __restrict__ qkv,
                                                    typename HT::T* __restrict__ out, int T, int H, float scale,
                                                    const int* __restrict__ lens, MhsaRing ring) {
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typ
   constexpr int NKT = KS * 2;     // 16-key tiles
   constexpr int KEYS = KS * 32;   // keys covered
   __shared__ __attribute__((aligned(16))) char k_lds[ATT_KEYS * 128];
-  __shared__ __attribute__((aligned(16))) Tt vt_lds[64 * ATT_VT_STRIDE];
+  __shared__ __attribute__((aligned(16))) Tt vt_lds[VTR ? ATT_KEYS * 64 : 64 * ATT_VT_STRIDE];  // VTR: [key][64 dims], chunk c at c ^ (key & 7)
   __shared__ __attribute__((aligned(16))) float mask_lds[ATT_KEYS];  // 0 for a key of this utterance, -1e30 beyond it
 
   const int h = blockIdx.x, b = blockIdx.y;
@@ -92,7 +95,13 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typ
       const int key = kg * IT + it;
       *(u32x4*)(k_lds + key * 128 + ((c ^ ((key >> 1) & 7)) * 16)) = kreg[it];
     }
-    if (!(MHSA_DBG & 4)) {
+    if constexpr (VTR) {
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int key = kg * IT + it;
+        *(V8*)((char*)vt_lds + key * 128 + ((c ^ (key & 7)) * 16)) = vreg[it];
+      }
+    } else if (!(MHSA_DBG & 4)) {
       if constexpr (IT == 2 || IT == 4 || IT == 8) {
         typedef Tt __attribute__((ext_vector_type(IT))) VK;
         static_assert(ATT_VT_STRIDE % IT == 0, "V^T rows keep the key vectors aligned");
@@ -200,6 +209,25 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typ
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto read_v = [&](int s2, V8 (&vf)[4]) {
+      if constexpr (VTR) {
+        // lane 4q + p of a 16-lane group supplies the address of key (block + q), dims 16 nt + 4p .. + 3; the group's lane i
+        // receives dim 16 nt + i of the block's 4 keys.  Blocks: keys 32 s2 + 4g .. + 3 (lo) and 16 beyond (hi).
+        typedef short tr4 __attribute__((__vector_size__(4 * sizeof(short))));
+        const int tq = ql >> 2, tp = ql & 3;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int chunk = nt * 2 + (tp >> 1);
+          const int k_lo = s2 * 32 + g * 4 + tq, k_hi = k_lo + 16;
+          const char* alo = (const char*)vt_lds + k_lo * 128 + ((chunk ^ (k_lo & 7)) * 16) + (tp & 1) * 8;
+          const char* ahi = (const char*)vt_lds + k_hi * 128 + ((chunk ^ (k_hi & 7)) * 16) + (tp & 1) * 8;
+          const tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)alo);
+          const tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)ahi);
+          union { tr4 v[2]; V8 f; } u;
+          u.v[0] = lo;
+          u.v[1] = hi;
+          vf[nt] = u.f;
+        }
+      } else {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const Tt* vr = vt_lds + (nt * 16 + ql) * ATT_VT_STRIDE + s2 * 32 + g * 4;
@@ -210,6 +238,7 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typ
           vf[nt][r] = lo[r];
           vf[nt][4 + r] = hi[r];
         }
+      }
       }
     };
     V8 vfa[4], vfb[4];
@@ -593,6 +622,8 @@ static int g_mhsa_force_long = 0;  // test knob: the blocked kernel at any lengt
 void mhsa_set_force_long(int v) { g_mhsa_force_long = v != 0; }
 static int g_mhsa_zsplit = 0;  // A/B knob: workgroups per (utterance, head) (0 = automatic)
 void mhsa_set_zsplit(int v) { g_mhsa_zsplit = v; }
+static int g_mhsa_vtr = 1;  // A/B knob: 1 (default) = V row-major in LDS + transposing reads, 0 = the V^T image (bit-identical)
+void mhsa_set_vtr(int v) { g_mhsa_vtr = v != 0; }
 static int g_mhsa_waves = 7;  // A/B knob: waves per workgroup of the one-pass kernel beyond 128 frames (4 or 7)
 void mhsa_set_waves(int v) { g_mhsa_waves = v == 4 ? 4 : 7; }
 
@@ -604,12 +635,18 @@ static void launch_mhsa_t(const void* qkv, void* out, int B, int T, int H, float
   dim3 grid(H, B, g_mhsa_zsplit > 0 ? g_mhsa_zsplit : ((long)H * B < 256 && T > 64 ? 2 : 1)), blk(256);
   if (T > ATT_KEYS || g_mhsa_force_long)
     hipLaunchKernelGGL((mhsa_long_kernel<HT>), dim3(H, B, (T + 63) / 64), blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
+  else if (T <= 64 && g_mhsa_vtr)
+    hipLaunchKernelGGL((mhsa_kernel<HT, 2, 4, false, true>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens, MhsaRing{});
   else if (T <= 64)
     hipLaunchKernelGGL((mhsa_kernel<HT, 2, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens, MhsaRing{});
+  else if (T <= 128 && g_mhsa_vtr)
+    hipLaunchKernelGGL((mhsa_kernel<HT, 4, 4, false, true>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens, MhsaRing{});
   else if (T <= 128)
     hipLaunchKernelGGL((mhsa_kernel<HT, 4, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens, MhsaRing{});
   else if (g_mhsa_waves == 4)
     hipLaunchKernelGGL((mhsa_kernel<HT, 7, 4>), grid, blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens, MhsaRing{});
+  else if (g_mhsa_vtr)
+    hipLaunchKernelGGL((mhsa_kernel<HT, 7, 7, false, true>), grid, dim3(448), 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens, MhsaRing{});
   else
     hipLaunchKernelGGL((mhsa_kernel<HT, 7, 7>), grid, dim3(448), 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens, MhsaRing{});
 }
@@ -626,9 +663,9 @@ const char* launch_mhsa_ring(const void* ring, void* out, int S, int H, int q_ti
     r.cnt[i] = (unsigned char)cnt[i];
   }
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL((mhsa_kernel<BF16, 8, 4, true>), dim3(H, S, 1), dim3(256), 0, s, (const BF16::T*)ring, (BF16::T*)out, 256, H, 0.125f, nullptr, r);
+    hipLaunchKernelGGL((mhsa_kernel<BF16, 8, 4, true, true>), dim3(H, S, 1), dim3(256), 0, s, (const BF16::T*)ring, (BF16::T*)out, 256, H, 0.125f, nullptr, r);
   else
-    hipLaunchKernelGGL((mhsa_kernel<FP16, 8, 4, true>), dim3(H, S, 1), dim3(256), 0, s, (const FP16::T*)ring, (FP16::T*)out, 256, H, 0.125f, nullptr, r);
+    hipLaunchKernelGGL((mhsa_kernel<FP16, 8, 4, true, true>), dim3(H, S, 1), dim3(256), 0, s, (const FP16::T*)ring, (FP16::T*)out, 256, H, 0.125f, nullptr, r);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -1778,6 +1778,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
     conf_attn_mfma_set_waves(value);
     return 0;
   }
+  if (!strcmp(key, "mhsa_vtr")) {
+    mhsa_set_vtr(value);
+    return 0;
+  }
   if (!strcmp(key, "mhsa_zsplit")) {
     mhsa_set_zsplit(value);
     return 0;

@@ -155,6 +155,7 @@ const char* launch_posconv(const PosConvArgs& p, int dtype, hipStream_t s);
 // qkv: (B*T, 3*H*64) operand type [q | k | v]; out: (B*T, H*64) operand type.
 // lens (device int32[B], or null): ragged batch -- utterance b has lens[b] valid frames of its T rows (key-padding mask)
 const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t s, const int* lens = nullptr);
+void mhsa_set_vtr(int v);  // A/B knob: V row-major in LDS + ds_read_b64_tr_b16 (0 = the V^T image)
 
 // the same attention with fp32 rows in / out and split-precision products on the fp16 matrix pipe (dtype "fp16x3"); T <= 224
 // out_plane > 0: `out` receives fp16 hi / lo planes of kS3ActScale x the result (lo at + out_plane elements) instead of fp32 rows
