@@ -630,9 +630,10 @@ void mhsa_set_waves(int v) { g_mhsa_waves = v == 4 ? 4 : 7; }
 template <class HT>
 static void launch_mhsa_t(const void* qkv, void* out, int B, int T, int H, float scale, const int* lens, hipStream_t s) {
   typedef typename HT::T Tt;
-  // below one workgroup per CU (B x H < 256) each head's query tiles are split over two workgroups (with seven waves per
-  // workgroup the split stopped paying at B = 16: 11.4 us whole against 11.8 us split; B = 8: 9.9 against 9.1)
-  dim3 grid(H, B, g_mhsa_zsplit > 0 ? g_mhsa_zsplit : ((long)H * B < 256 && T > 64 ? 2 : 1)), blk(256);
+  // up to 1.5 workgroups per CU (B x H <= 384) each head's query tiles are split over two workgroups, each staging K / V itself
+  // (since the staging lost its V^T scatter the split pays through B = 24: teacher step 4.75 -> 4.72 ms at B = 16,
+  // 6.26 -> 6.23 at B = 24, tools/diag_mhsa_vtr.py zsplit; rows do not depend on the split)
+  dim3 grid(H, B, g_mhsa_zsplit > 0 ? g_mhsa_zsplit : ((long)H * B <= 384 && T > 64 ? 2 : 1)), blk(256);
   if (T > ATT_KEYS || g_mhsa_force_long)
     hipLaunchKernelGGL((mhsa_long_kernel<HT>), dim3(H, B, (T + 63) / 64), blk, 0, s, (const Tt*)qkv, (Tt*)out, T, H, scale, lens);
   else if (T <= 64 && g_mhsa_vtr)

@@ -61,5 +61,35 @@ def end_to_end():
     lib().afx_debug_set(b"mhsa_vtr", 1)
 
 
+def zsplit():
+    """Teacher B = 16: query tiles of a (utterance, head) on one workgroup (default at B x H >= 256) or split over two."""
+    import time
+    from afx import engine, synth
+    sd = synth.model_state_dict("XLSR_AASIST", n_layers=24)
+    eng = engine.Engine("xlsr_aasist", n_layers=24, dtype="fp16")
+    eng.load_state_dict(sd)
+    for B in (16, 8, 24):
+        wave = synth.waveforms(B, 64000, batch_idx=0).cuda()
+        line = f"xlsr_aasist B={B}:"
+        ref = None
+        for z in (0, 2, 0, 2):
+            lib().afx_debug_set(b"mhsa_zsplit", z)
+            for _ in range(5):
+                out = eng.forward_overlapped(wave)
+            eng.join()
+            torch.cuda.synchronize()
+            ref = out.clone() if ref is None else ref
+            same = torch.equal(ref, out)
+            t0 = time.perf_counter()
+            for _ in range(30):
+                eng.forward_overlapped(wave)
+            eng.join()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 30
+            line += f"  zsplit={z} {dt * 1e3:.3f} ms{'' if same else ' DIFF'}"
+        print(line, flush=True)
+    lib().afx_debug_set(b"mhsa_zsplit", 0)
+
+
 if __name__ == "__main__":
-    end_to_end() if "e2e" in sys.argv else main()
+    zsplit() if "zsplit" in sys.argv else (end_to_end() if "e2e" in sys.argv else main())
