@@ -91,5 +91,39 @@ def zsplit():
     lib().afx_debug_set(b"mhsa_zsplit", 0)
 
 
+def knob(name, values):
+    """Teacher B = 16 and student B = 64 steps under an integer knob of afx_debug_set."""
+    import time
+    from afx import engine, synth
+    for arch, oname, nl, B in (("xlsr_aasist", "XLSR_AASIST", 24, 16), ("conformer", "ConformerModel", 6, 64)):
+        sd = synth.model_state_dict(oname, n_layers=nl)
+        eng = engine.Engine(arch, n_layers=nl, dtype="fp16")
+        eng.load_state_dict(sd)
+        wave = synth.waveforms(B, 64000, batch_idx=0).cuda()
+        line = f"{arch} B={B}:"
+        ref = None
+        for v in list(values) * 2:
+            lib().afx_debug_set(name.encode(), v)
+            for _ in range(5):
+                out = eng.forward_overlapped(wave)
+            eng.join()
+            torch.cuda.synchronize()
+            ref = out.clone() if ref is None else ref
+            same = torch.equal(ref, out)
+            t0 = time.perf_counter()
+            for _ in range(30):
+                eng.forward_overlapped(wave)
+            eng.join()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 30
+            line += f"  {name}={v} {dt * 1e3:.3f} ms{'' if same else ' DIFF'}"
+        print(line, flush=True)
+        del eng
+
+
 if __name__ == "__main__":
+    if "knob" in sys.argv:
+        i = sys.argv.index("knob")
+        knob(sys.argv[i + 1], [int(x) for x in sys.argv[i + 2:]])
+        sys.exit(0)
     zsplit() if "zsplit" in sys.argv else (end_to_end() if "e2e" in sys.argv else main())
