@@ -1758,6 +1758,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
     gemm_set_tile(value);
     return 0;
   }
+  if (!strcmp(key, "gemm_small_deep")) {
+    gemm_set_small_deep(value);
+    return 0;
+  }
   if (!strcmp(key, "gemm_split")) {
     gemm_set_split(value);
     return 0;

@@ -399,6 +399,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
   }
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  // beyond the table: the raw encoding (gfx9: vmcnt = bits 3:0 and 15:14, expcnt / lgkmcnt fields at their maximum = no wait)
+  if constexpr (N > 10) asm volatile("s_waitcnt %0" ::"n"((N & 15) | ((N >> 4) << 14) | 0x0F70) : "memory");
+  else if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+}
+
 // WR x WC waves per workgroup; each wave owns a (BM/WR) x (BN/WC) block of the tile.
 // ROWLN: the tile spans the whole output row (BN == N), and the epilogue applies
 // LayerNorm over the row (two-pass fp32 statistics, partial sums exchanged through LDS
@@ -564,21 +582,6 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
   gemm_epilogue<HT, BM, BN, WR, WC, ROWLN, LEAN, S3>(p, acc, smem, m0, n0, g);
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 10, "extend the table");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-}
 
 // =======================================================================================
 // 8-phase 256x256 tile kernel (cdna guide, "The 256^2 8-phase template"): 8 waves as 2(M) x
@@ -1133,6 +1136,146 @@ static hipError_t launch_gemm_t(const GemmArgs& p, int groups, hipStream_t s) {
   return hipGetLastError();
 }
 
+// =======================================================================================
+// "Deep" four- / eight-wave tile for products whose tile count leaves ONE workgroup per CU (the teacher's N = 1024 products at
+// M = 16 x 199: 200 tiles of 128 x 128).  gemm_kernel above lives on two or three co-resident workgroups covering each other: a
+// workgroup alone runs one serial chain per K-tile -- barrier, fragment reads, wait, MFMAs -- at 0.64 us, half of what its CU can
+// take in (tools/diag_small_tile_balance.py).  Here the chain is shortened inside the wave instead:
+//   * NS K-tile buffers, LDS-DMA through inline asm, counted vmcnt: NS - 1 tiles in flight, the wait at the top of a K-tile
+//     is for a tile issued NS - 1 iterations ago;
+//   * both k-steps' fragments are requested in one block before the first MFMA (sched_barrier pins the order; the compiler
+//     counts lgkmcnt, so the second step's reads land under the first step's MFMAs).
+// Same k order, same MFMA, same epilogue as every other tile: bit-identical rows.  Plain K only (no chunked K, no planes).
+// =======================================================================================
+template <class HT, int BM, int BN, int WR, int WC, int NS>
+__global__ __launch_bounds__(64 * WR * WC) void gemm_deep_kernel(GemmArgs p) {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+  constexpr int NW = WR * WC;
+  constexpr int WM = BM / WR, WN = BN / WC;
+  constexpr int MT = WM / 16, NT = WN / 16;
+  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+  constexpr int AI = BM / (8 * NW), WI = BN / (8 * NW), PER = AI + WI;
+  static_assert(AI >= 1 && WI >= 1 && NS >= 3 && NS <= 4, "tile / stage shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int g = blockIdx.z;
+  int pm, pn;
+  {
+    const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
+    const int nwg = nM * nN;
+    int L = blockIdx.x;
+    if (p.map_mode >= 1) {
+      const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    }
+    if (p.map_mode == 2) {
+      constexpr int GM = 8;
+      const int width = GM * nN, grp = L / width, first = grp * GM;
+      const int gsz = nM - first < GM ? nM - first : GM;
+      pm = first + (L % width) % gsz;
+      pn = (L % width) / gsz;
+    } else {
+      pm = L / nN;
+      pn = L % nN;
+    }
+  }
+  const int m0 = pm * BM, n0 = pn * BN;
+  const T* Ag = (const T*)p.A + (long)g * p.g_a;
+  const T* Wg = (const T*)p.W + (long)g * p.g_w;
+  const T* a_src[AI];
+  const T* w_src[WI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;
+    a_src[i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int n = n0 + row;
+    n = n < p.N ? n : p.N - 1;
+    w_src[i] = Wg + (long)n * p.ldw + c * 8;
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = p.K >> 6;
+  const unsigned lds_base = (unsigned)(size_t)smem;
+  auto dma16 = [&](const T* src, unsigned lds_off) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + lds_off);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
+  auto stage = [&](int buf, int kt) {
+    const long k0 = (long)kt << 6;
+    const unsigned base = (unsigned)(buf * STAGE);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) dma16(a_src[i] + k0, base + (i * NW + wave) * 1024);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0, base + A_BYTES + (i * NW + wave) * 1024);
+  };
+  const int frow = lane & 15, fsw = (frow >> 1) & 7;
+  const int a_off = (wr * WM + frow) * 128;
+  const int w_off = A_BYTES + (wc * WN + frow) * 128;
+  int slot[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) slot[ks] = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < nk) stage(t, t);
+  int rb = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int behind = nk - 1 - kt;  // tiles issued after tile kt that may stay in flight: min(NS - 2, behind)
+    if (behind >= NS - 2) wait_vmcnt<(NS - 2) * PER>();
+    else if (NS > 3 && behind == 1) wait_vmcnt<PER>();
+    else wait_vmcnt<0>();
+    __syncthreads();  // tile kt landed for every wave; every wave is done with tile kt - 1
+    if (kt + NS - 1 < nk) stage(rb == 0 ? NS - 1 : rb - 1, kt + NS - 1);  // into the buffer tile kt - 1 was read from
+    const char* sb = smem + rb * STAGE;
+    rb = rb + 1 == NS ? 0 : rb + 1;
+    V8 af[2][MT], wf[2][NT];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[ks][j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot[ks]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[ks][i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot[ks]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[ks][j], af[ks][i], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  gemm_epilogue<HT, BM, BN, WR, WC, false, true, false>(p, acc, smem, m0, n0, g);
+}
+
+template <class HT, int BM, int BN, int WR, int WC, int NS>
+static hipError_t launch_gemm_deep_t(const GemmArgs& p, int groups, hipStream_t s) {
+  constexpr int lds = NS * (BM + BN) * 128;
+  static_assert(lds <= 160 * 1024, "K-tile buffers must fit the 160 KB LDS");
+  static LdsLimit lim;
+  if (hipError_t e = lim.ensure((const void*)gemm_deep_kernel<HT, BM, BN, WR, WC, NS>, lds); e != hipSuccess) return e;
+  dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
+  hipLaunchKernelGGL((gemm_deep_kernel<HT, BM, BN, WR, WC, NS>), grid, dim3(64 * WR * WC), lds, s, p);
+  return hipGetLastError();
+}
+
 // tuning knobs for A/B runs (tools/bench_gemm.py); -1 = use the defaults below
 static int g_map_override = -1;
 static int g_tile_override = -1;  // 0: 128x128 / 4 waves, 1: 256x256 / 8 waves
@@ -1140,6 +1283,8 @@ void gemm_set_map_mode(int m) { g_map_override = m; }
 void gemm_set_tile(int t) { g_tile_override = t; }
 static int g_ant_override = -1;  // non-temporal A loads: -1 auto (row-complete tile only), 0, 1
 void gemm_set_a_nt(int v) { g_ant_override = v; }
+static int g_small_deep = 1;  // A/B knob: 1 (default) = the deep form of the 128x64 tile where at most two tiles fall on a CU
+void gemm_set_small_deep(int v) { g_small_deep = v != 0; }
 static int g_deep = -1;  // row-complete conv tile: 0 = 2-stage kernel, otherwise (default) the 8-phase kernel (A/B knob)
 void gemm_set_deep(int v) { g_deep = v; }
 #ifdef AFX_ATTR
@@ -1253,6 +1398,7 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
   if (gemm_is_narrow(p.N)) return 1;
   if (groups != 1) return 0;
   if (g_tile_override == 5) return 1;  // 128x64 / 4 waves (forced)
+  if (g_tile_override >= 6 && g_tile_override <= 9) return plain_k(p) && !p.k1 ? 84 + g_tile_override : 0;  // deep tiles (90..93), A/B
   if (g_tile_override == 3) return plain_k(p) ? 7 : 0;  // 8-phase 256x256
   if (g_tile_override >= 0) return g_tile_override == 1 ? 2 : 0;
   // Wave-quantisation model fitted to tools/bench_gemm.py (profiles/r01_gemm_tile_ab*.txt):
@@ -1260,7 +1406,15 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
   // runs one workgroup per CU, a 128x128 tile two; pick the better fill of the 256 CUs.
   const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   const long b256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-  if (b128 < 384) return 1;  // small batches: halve the tile to spread over the chip
+  if (b128 < 384) {  // small batches: halve the tile to spread over the chip
+    // at most two 128x64 tiles per CU (b128 <= 256: the teacher's N = 1024 products at B <= 16): the deep form of that tile --
+    // three K-tile buffers, counted vmcnt, both k-steps' fragments requested ahead of the MFMAs -- FC2 at M = 16 x 199 50.3 ->
+    // 43.3 us, out-proj 19.4 -> 17.7; at M = 8 x 199 41.6 -> 31.8 (tools/diag_deep_tiles.py).  With three workgroups per CU
+    // (b128 > 256) the two-buffer form, which fits three, stays ahead.  Same k order: bit-identical rows.
+    const bool lean = (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0;
+    if (g_small_deep && b128 <= 256 && plain_k(p) && !p.k1 && lean && p.m_lo == 0) return 92;
+    return 1;
+  }
   if (gemm_split_rows(p, groups) > 0) return 7;  // whole rounds on the 8-phase kernel + a 128x128 remainder
   const double e128 = (double)b128 / (double)(((b128 + 511) / 512) * 512);
   const double e256 = 1.15 * (double)b256 / (double)(((b256 + 255) / 256) * 256);
@@ -1276,6 +1430,10 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 1: return lean ? launch_gemm_t<HT, 128, 64, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 64, 2, 2>(p, groups, s);
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
+    case 90: return launch_gemm_deep_t<HT, 128, 128, 2, 2, 4>(p, groups, s);
+    case 91: return launch_gemm_deep_t<HT, 128, 128, 2, 4, 4>(p, groups, s);
+    case 92: return launch_gemm_deep_t<HT, 128, 64, 2, 2, 3>(p, groups, s);
+    case 93: return launch_gemm_deep_t<HT, 128, 128, 2, 2, 3>(p, groups, s);
     case 7:
       if (g_ph4 == 0) return launch_gemm8_t<HT, 256, 256, false, 8, 3>(p, groups, s);  // default: the three-buffer ring form
 #ifdef AFX_ATTR

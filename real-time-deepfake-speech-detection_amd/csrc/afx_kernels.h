@@ -70,6 +70,7 @@ const char* launch_gemm_f32(const GemmArgs& p, int groups, hipStream_t s);  // a
 bool gemm_is_narrow(int N);  // true: the 128x64 tile instance serves this N
 int gemm_tile_of(const GemmArgs& p, int groups);  // tile instance id (afx_gemm.hip)
 void gemm_set_map_mode(int m);  // A/B knob: -1 default, else force map_mode
+void gemm_set_small_deep(int v);  // A/B knob: 1 (default) = deep form of the 128x64 tile at <= two tiles per CU
 void gemm_set_tile(int t);      // A/B knob: -1 default, 0: 128x128 tile, 1: 256x256 tile
 void gemm_set_a_nt(int v);      // A/B knob: -1 auto, 0/1 non-temporal A-panel loads
 void gemm_set_conv_split(int v);  // A/B knob: 1 (default) = multi-round conv layers as whole rounds of 128-row tiles + a 64-row remainder launch
