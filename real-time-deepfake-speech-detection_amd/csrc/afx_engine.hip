@@ -709,9 +709,9 @@ extern "C" int afx_tap(afx_handle h, const char* name, float* out, size_t cap, s
 // launch of the forward is bracketed by hipEvents on the launch stream and summed per
 // class afterwards.  Off by default: the normal forward records nothing.
 // ---------------------------------------------------------------------------------
-enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN, PC_GEMM_F32, PC_CONV0, PC_POSCONV, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV, PC_CONF_CHAIN,
+enum ProfClass { PC_GEMM128 = 0, PC_GEMM64, PC_GEMM64_DEEP, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN, PC_GEMM_F32, PC_CONV0, PC_POSCONV, PC_ROWNORM, PC_MHSA, PC_CONF_ATTN, PC_CONF_DWCONV, PC_CONF_CHAIN,
                  PC_MISC, PC_AASIST, PC_COUNT };
-static const char* kProfNames[PC_COUNT] = {"gemm_kernel<128x128>", "gemm_kernel<128x64>", "gemm_kernel<256x256>",
+static const char* kProfNames[PC_COUNT] = {"gemm_kernel<128x128>", "gemm_kernel<128x64>", "gemm_deep_kernel<128x64>", "gemm_kernel<256x256>",
                                            "gemm_kernel<128x512,rowLN>", "gemm8_kernel<256x256>", "gemm8_kernel<128x512,rowLN>", "gemm_f32_kernel<128x128>", "conv0_kernel", "posconv_kernel", "rownorm_kernel", "mhsa_kernel", "conf_attn_kernel",
                                            "conf_dwconv_kernel", "conf_chain_kernel", "misc", "aasist_head"};
 struct ProfRec { int cls; hipEvent_t a, b; double flops; };
@@ -784,7 +784,11 @@ static const char* timed(int cls, double flops, hipStream_t s, F&& f) {
 // (pack_linear), and ONE launch walks K three times: K' = 3 K (GemmArgs::k1).
 static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) {
   const double fl = 2.0 * g.M * g.N * (g.k_algo ? g.k_algo : g.K) * groups;
-  static const int cls[9] = {PC_GEMM128, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM256, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN};
+  // profiler class of a tile id (afx_gemm.hip::gemm_tile_of): 92 = the deep form of the 128x64 tile, a class of its own
+  auto cls_of = [](int tile) -> int {
+    static const int cls[9] = {PC_GEMM128, PC_GEMM64, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM256, PC_GEMM256, PC_GEMM_ROWLN, PC_GEMM8_256, PC_GEMM8_ROWLN};
+    return tile == 92 ? PC_GEMM64_DEEP : (tile >= 0 && tile < 9 ? cls[tile] : PC_GEMM128);
+  };
   if (dt == DT_FP32 && t_s3planes) {
     if (g.K % 64 || g.kchunk % 64) {  // (a K the fp16 tiles cannot walk: the fp32 instruction)
       if (g.out_h) s3_set(g.out_h, 0);
@@ -819,9 +823,9 @@ static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) 
       s3_set(g.out_h, q.oh_plane);
     }
     const int tile = gemm_tile_of(q, groups);
-    return timed(cls[tile], fl, s, [&] { return launch_gemm(q, DT_FP16X3, groups, s); });
+    return timed(cls_of(tile), fl, s, [&] { return launch_gemm(q, DT_FP16X3, groups, s); });
   }
-  return timed(dt == DT_FP32 ? PC_GEMM_F32 : cls[gemm_tile_of(g, groups)], fl, s, [&] { return launch_gemm(g, dt, groups, s); });
+  return timed(dt == DT_FP32 ? PC_GEMM_F32 : cls_of(gemm_tile_of(g, groups)), fl, s, [&] { return launch_gemm(g, dt, groups, s); });
 }
 static const char* P_rownorm(const RowNormArgs& a_in, int dt, hipStream_t s) {
   RowNormArgs a = a_in;
