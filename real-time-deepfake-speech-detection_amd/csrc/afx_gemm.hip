@@ -1145,9 +1145,10 @@ static hipError_t launch_gemm_t(const GemmArgs& p, int groups, hipStream_t s) {
 //     is for a tile issued NS - 1 iterations ago;
 //   * both k-steps' fragments are requested in one block before the first MFMA (sched_barrier pins the order; the compiler
 //     counts lgkmcnt, so the second step's reads land under the first step's MFMAs).
-// Same k order, same MFMA, same epilogue as every other tile: bit-identical rows.  Plain K only (no chunked K, no planes).
+// Same k order, same MFMA, same epilogue as every other tile: bit-identical rows.  Plain K only (no chunked K); S3 = the
+// split-precision walk over [xh.wh | xl.wh | xh.wl] (dtype "fp16x3").
 // =======================================================================================
-template <class HT, int BM, int BN, int WR, int WC, int NS>
+template <class HT, int BM, int BN, int WR, int WC, int NS, bool S3 = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_deep_kernel(GemmArgs p) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
@@ -1217,12 +1218,18 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_deep_kernel(GemmArgs p) {
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
   };
   auto stage = [&](int buf, int kt) {
-    const long k0 = (long)kt << 6;
+    long k0 = (long)kt << 6, aplane = 0, wplane = 0;
+    if constexpr (S3) {  // K-tile kt of [xh.wh | xl.wh | xh.wl]: which planes, and the k inside the segment
+      const int seg = k0 >= 2 * p.k1 ? 2 : (k0 >= p.k1 ? 1 : 0);
+      k0 -= (long)seg * p.k1;
+      aplane = seg == 1 ? p.a_plane : 0;
+      wplane = seg == 2 ? p.w_plane : 0;
+    }
     const unsigned base = (unsigned)(buf * STAGE);
 #pragma unroll
-    for (int i = 0; i < AI; ++i) dma16(a_src[i] + k0, base + (i * NW + wave) * 1024);
+    for (int i = 0; i < AI; ++i) dma16(a_src[i] + k0 + aplane, base + (i * NW + wave) * 1024);
 #pragma unroll
-    for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0, base + A_BYTES + (i * NW + wave) * 1024);
+    for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0 + wplane, base + A_BYTES + (i * NW + wave) * 1024);
   };
   const int frow = lane & 15, fsw = (frow >> 1) & 7;
   const int a_off = (wr * WM + frow) * 128;
@@ -1262,17 +1269,17 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_deep_kernel(GemmArgs p) {
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   }
-  gemm_epilogue<HT, BM, BN, WR, WC, false, true, false>(p, acc, smem, m0, n0, g);
+  gemm_epilogue<HT, BM, BN, WR, WC, false, true, S3>(p, acc, smem, m0, n0, g);
 }
 
-template <class HT, int BM, int BN, int WR, int WC, int NS>
+template <class HT, int BM, int BN, int WR, int WC, int NS, bool S3 = false>
 static hipError_t launch_gemm_deep_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = NS * (BM + BN) * 128;
   static_assert(lds <= 160 * 1024, "K-tile buffers must fit the 160 KB LDS");
   static LdsLimit lim;
-  if (hipError_t e = lim.ensure((const void*)gemm_deep_kernel<HT, BM, BN, WR, WC, NS>, lds); e != hipSuccess) return e;
+  if (hipError_t e = lim.ensure((const void*)gemm_deep_kernel<HT, BM, BN, WR, WC, NS, S3>, lds); e != hipSuccess) return e;
   dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
-  hipLaunchKernelGGL((gemm_deep_kernel<HT, BM, BN, WR, WC, NS>), grid, dim3(64 * WR * WC), lds, s, p);
+  hipLaunchKernelGGL((gemm_deep_kernel<HT, BM, BN, WR, WC, NS, S3>), grid, dim3(64 * WR * WC), lds, s, p);
   return hipGetLastError();
 }
 
@@ -1412,7 +1419,7 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
     // 43.3 us, out-proj 19.4 -> 17.7; at M = 8 x 199 41.6 -> 31.8 (tools/diag_deep_tiles.py).  With three workgroups per CU
     // (b128 > 256) the two-buffer form, which fits three, stays ahead.  Same k order: bit-identical rows.
     const bool lean = (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0;
-    if (g_small_deep && b128 <= 256 && plain_k(p) && !p.k1 && lean && p.m_lo == 0) return 92;
+    if (g_small_deep && b128 <= 256 && plain_k(p) && lean && p.m_lo == 0) return 92;
     return 1;
   }
   if (gemm_split_rows(p, groups) > 0) return 7;  // whole rounds on the 8-phase kernel + a 128x128 remainder
@@ -1456,6 +1463,7 @@ static hipError_t dispatch_s3(const GemmArgs& p, int tile, int groups, hipStream
   const bool lean = (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0;
   switch (tile) {
     case 1: return lean ? launch_gemm_t<HT, 128, 64, 2, 2, false, true, true>(p, groups, s) : launch_gemm_t<HT, 128, 64, 2, 2, false, false, true>(p, groups, s);
+    case 92: return launch_gemm_deep_t<HT, 128, 64, 2, 2, 3, true>(p, groups, s);
     case 7: return launch_gemm8_t<HT, 256, 256, false, 8, 3, false, true>(p, groups, s);
     case 75: return launch_gemm8_t<HT, 256, 256, false, 5, 3, false, true>(p, groups, s);
     case 76: return launch_gemm8_t<HT, 256, 256, false, 6, 3, false, true>(p, groups, s);
