@@ -47,5 +47,34 @@ def main():
     lib().afx_debug_set(b"gemm_tile", -1)
 
 
+def maps():
+    """The deep 128x64 tile under the workgroup -> tile orders 0 / 1 / 2 (default)."""
+    for M in (3184,):
+        for name, N, K in (("out-proj", 1024, 1024), ("ffn2", 1024, 4096)):
+            A = (0.1 * torch.randn(M, K, device="cuda")).half()
+            W = (0.03 * torch.randn(N, K, device="cuda")).half()
+            b = 0.1 * torch.randn(N, device="cuda")
+            resid = torch.randn(M, N, device="cuda")
+            line = f"M {M:5d} {name:9s}"
+            ref = None
+            for mp in (2, 0, 1, 2):
+                lib().afx_debug_set(b"gemm_map", mp)
+                fn = lambda: kernels.gemm("fp16", A, W, bias=b, resid=resid, out_f=True, out_h=True)
+                for _ in range(5):
+                    of, oh = fn()
+                torch.cuda.synchronize()
+                ref = (of.clone(), oh.clone()) if ref is None else ref
+                same = torch.equal(of, ref[0]) and torch.equal(oh, ref[1])
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(30):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                line += f" | map {mp}: {e0.elapsed_time(e1) / 30 * 1e3:6.1f}{'' if same else ' DIFF'}"
+            print(line, flush=True)
+    lib().afx_debug_set(b"gemm_map", -1)
+
+
 if __name__ == "__main__":
-    main()
+    maps() if "maps" in sys.argv else main()
