@@ -306,7 +306,7 @@ class Engine:
         and never synchronises inside a forward, so the whole launch sequence is capturable).
         Returns ``run(wave) -> logits``: copies the batch into the graph's static input and
         replays.  Meant for small, latency-bound batches (B = 1 streaming-style calls) on a host that cannot keep up
-        with the launches; on the pool's hosts eager and replay measure the same at B = 1 (1.28 ms student, 3.50 ms
+        with the launches; on the pool's hosts eager and replay measure the same at B = 1 (1.18 ms student, 2.50 ms
         teacher, tools/diag_b1_latency.py): that time is the GPU-side latency of a chain of ~130 / ~330 dependent kernels."""
         with torch.cuda.device(self.device):
             static_in = torch.zeros(B, L, dtype=torch.float32, device=self.device)
