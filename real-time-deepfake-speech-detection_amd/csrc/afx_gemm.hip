@@ -1402,7 +1402,13 @@ static int gemm8_fit_rowln(const GemmArgs& p) {
 
 int gemm_tile_of(const GemmArgs& p, int groups) {
   if (p.ln_gamma) return g_deep != 0 && plain_k(p) ? 8 : 3;
-  if (gemm_is_narrow(p.N)) return 1;
+  if (gemm_is_narrow(p.N)) {
+    // (narrow products with at most two 128x64 tiles per CU: the deep form of the tile, as below)
+    const long t64 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
+    const bool lean = (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0;
+    if (g_small_deep && g_tile_override < 0 && groups == 1 && t64 <= 512 && plain_k(p) && lean && p.m_lo == 0) return 92;
+    return 1;
+  }
   if (groups != 1) return 0;
   if (g_tile_override == 5) return 1;  // 128x64 / 4 waves (forced)
   if (g_tile_override >= 6 && g_tile_override <= 9) return plain_k(p) && !p.k1 ? 84 + g_tile_override : 0;  // deep tiles (90..93), A/B
