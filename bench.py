@@ -23,6 +23,13 @@ Besides the contract fields the JSON line carries
                   bounded sample of the same workload, plus the GPU-vs-oracle parity
                   of that sample (`parity`, `parity_ok`: the run exits non-zero when the
                   sample misses the 1e-3 score tolerance, unless --allow-parity-miss);
+  contract     -- the SAME protocol (warm-up, K steps, barriers) in dtype "fp16x3" (split precision: every dense product as
+                  three fp16 matrix-core products of hi / lo operand pairs, fp32 activations) -- the mode in which "scores
+                  within 1e-3 on EVERY utterance, EER unchanged to 2 d.p." holds whatever the checkpoint's top-k gaps
+                  (DESIGN.md section 5): its rate, its own parity sample and its roofline against 2.5 PF / 3.  Carried by
+                  the headline and by config3;
+  issue_probe  -- both ways of issuing a step (one stream / back-end on a side stream under the next trunk) timed over the
+                  warm-up count before the timed region; the faster one is what the timed region runs (`issue`);
   config3      -- (default workload only) BASELINE configs[2] / [3] beside the headline: the
                   XLS-R-24 + AASIST teacher at batch 16 per GPU timed the same way (same
                   warm-up, K steps, barriers, max over ranks), so that the driver's N = 1
@@ -53,8 +60,9 @@ WORKLOADS = {
 }
 
 
-PMC_FILES = {"conformer_student": "pmc_traffic.json", "xlsr_aasist": "pmc_traffic_teacher.json"}
-MFMA_FILES = {"conformer_student": "pmc_mfma.json", "xlsr_aasist": "pmc_mfma_teacher.json"}
+# committed rocprofv3 PMC summaries per workload: [fp16 / bf16 run, fp16x3 run]
+PMC_FILES = {"conformer_student": ("pmc_traffic.json", "pmc_traffic_fp16x3.json"), "xlsr_aasist": ("pmc_traffic_teacher.json", "pmc_traffic_teacher_fp16x3.json")}
+MFMA_FILES = {"conformer_student": ("pmc_mfma.json", "pmc_mfma_fp16x3.json"), "xlsr_aasist": ("pmc_mfma_teacher.json", "pmc_mfma_teacher_fp16x3.json")}
 
 
 def time_steps(step, steps, warmup, use_dist, dist, join=None):
@@ -90,12 +98,15 @@ def time_steps(step, steps, warmup, use_dist, dist, join=None):
     return elapsed, ev0.elapsed_time(ev1) / steps, out
 
 
-def build(workload, dtype, batch, seconds, rank):
+def build(workload, dtype, batch, seconds, rank, head_scale=None, sd=None):
+    """head_scale: the AASIST head with its matrices scaled (synth.lively: GraphPool scores spread out, so the reference's
+    top-k decisions are decisions and a logit responds to a swapped near-tie -- tests/test_gpu_teacher.py's head)."""
     from afx import engine, synth
     arch, oname, n_layers, gflop = WORKLOADS[workload]
     B = batch or (64 if workload == "conformer_student" else 16)
     L = int(seconds * 16000)
-    sd = synth.model_state_dict(oname, n_layers=n_layers)
+    if sd is None:
+        sd = synth.model_state_dict(oname, n_layers=n_layers, **({"head_scale": head_scale} if head_scale else {}))
     eng = engine.Engine(arch, n_layers=n_layers, dtype=dtype)
     eng.load_state_dict(sd)
     wave = synth.waveforms(B, L, batch_idx=rank).cuda()  # resident in HBM before the timed region
@@ -122,7 +133,7 @@ def roofline_of(w, workload, dtype, steps):
     roofline = {
         "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(gemm_tflops / peak, 4), "traffic": None,
-        "kernel": "afx::" + dom.replace("<", f"<{dtype},").replace("x", ","),
+        "kernel": "afx::" + dom.split("<")[0] + "<" + dtype + "," + dom.split("<")[1].replace("x", ","),
         "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
         "launches_per_step": g["launches"] // steps,
         "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
@@ -134,26 +145,57 @@ def roofline_of(w, workload, dtype, steps):
     }
     breakdown = {k: round(v["ms"] / steps, 4) for k, v in prof.items() if v["launches"]}
     # HBM traffic of that kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: FETCH_SIZE x 2
-    # + WRITE_SIZE, mean bytes per launch on this workload); counters cannot be read from inside this process
-    pmc_path = os.path.join(ROOT, "profiles", PMC_FILES[workload])
+    # + WRITE_SIZE, mean bytes per launch on this workload); counters cannot be read from inside this process.
+    # The class timed above is (kernel template, operand type, tile rows, tile columns); a PMC file serves it only when it
+    # was taken in this dtype at the default batch and holds instances of exactly that class (every tile height is one
+    # instance) -- otherwise `traffic` stays null and the note says why (no prefix guessing).
     default_b = B == (64 if workload == "conformer_student" else 16)
-    kern = dom.split("<")[0] + "<afx::" + dtype.upper() + ", " + dom.split("<")[1].rstrip(">").split(",")[0].replace("x", ", ")
-    if os.path.exists(pmc_path) and default_b and dtype in ("fp16", "bf16"):
-        # every height of the tile (160..256 rows) is one instance of the class: launch-weighted mean over them
-        recs = [r for name, r in json.load(open(pmc_path))["kernels"].items() if name.startswith("afx::" + kern)]
+    want = (dom.split("<")[0], "FP16" if dtype == "fp16x3" else dtype.upper()) + tuple(dom.split("<")[1].rstrip(">").split(",")[0].split("x"))
+
+    def class_of(name):  # "afx::gemm8_kernel<afx::FP16, 256, 256, false, 7, 3, false, false>" -> (kernel, type, rows, cols, s3)
+        if not name.startswith("afx::") or "<" not in name:
+            return None
+        a = [t.strip() for t in name[name.index("<") + 1:name.rindex(">")].split(",")]
+        if len(a) < 3:
+            return None
+        return (name[5:name.index("<")], a[0].replace("afx::", "")) + tuple(a[1:3]), a[-1] == "true"
+
+    def pick(path, what):
+        if not os.path.exists(path):
+            return None, None, f"{what}: profiles/{os.path.basename(path)} is absent"
+        doc = json.load(open(path))
+        if doc.get("dtype", "fp16") != dtype or not default_b:
+            return None, doc, f"{what}: profiles/{os.path.basename(path)} was taken in dtype {doc.get('dtype', 'fp16')} at the default batch, this run is {dtype} at batch {B}"
+        recs = [r for name, r in doc["kernels"].items() if class_of(name) == (want, dtype == "fp16x3")]
+        if not recs or not sum(r["launches_sampled"] for r in recs):
+            return None, doc, f"{what}: profiles/{os.path.basename(path)} holds no launch of the class timed here ({'<'.join(want[:1])}<{', '.join(want[1:])}>)"
+        return recs, doc, None
+
+    stamp = lambda doc: {k: doc[k] for k in ("git", "build_id") if k in doc}
+    recs, doc, why = pick(os.path.join(ROOT, "profiles", PMC_FILES[workload][dtype == "fp16x3"]), "traffic")
+    if recs:
         n = sum(r["launches_sampled"] for r in recs)
-        if n:
-            roofline["traffic"] = round(sum((r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches_sampled"] for r in recs) / n)
-            roofline["traffic_unit"] = f"HBM bytes per launch (rocprofv3 PMC, profiles/{PMC_FILES[workload]})"
-    # matrix-pipe busy fraction of the same class from the committed SQ pass (tools/pmc_lds.sh -> profiles/pmc_mfma.json):
-    # SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES x 4 SIMDs), 0..1; beside it what the achieved rate implies
-    mfma_path = os.path.join(ROOT, "profiles", MFMA_FILES[workload])
-    if os.path.exists(mfma_path) and default_b and dtype in ("fp16", "bf16"):
-        recs = [r for name, r in json.load(open(mfma_path))["kernels"].items() if name.startswith("afx::" + kern)]
+        roofline["traffic"] = round(sum((r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches_sampled"] for r in recs) / n)
+        roofline["traffic_unit"] = f"HBM bytes per launch (rocprofv3 PMC, profiles/{PMC_FILES[workload][dtype == 'fp16x3']})"
+        roofline["traffic_stamp"] = stamp(doc)
+    else:
+        roofline["traffic_note"] = why
+    # matrix-pipe busy fraction of the same class from the committed SQ pass (tools/pmc_mfma.sh):
+    # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), 0..1; beside it what the achieved rate implies
+    recs, doc, why = pick(os.path.join(ROOT, "profiles", MFMA_FILES[workload][dtype == "fp16x3"]), "mfma_busy_frac")
+    if recs:
         n = sum(r["launches_sampled"] for r in recs)
-        if n:
-            roofline["mfma_busy_frac"] = round(sum(r["mfma_busy_frac"] * r["launches_sampled"] for r in recs) / n, 4)
-            roofline["mfma_busy_note"] = f"matrix-pipe busy cycles / (CU busy cycles x 4 SIMDs), rocprofv3 PMC, profiles/{MFMA_FILES[workload]}"
+        roofline["mfma_busy_frac"] = round(sum(r["mfma_busy_frac"] * r["launches_sampled"] for r in recs) / n, 4)
+        roofline["mfma_busy_note"] = (f"matrix-pipe busy cycles / (kernel cycles = GRBM_GUI_ACTIVE / 8, x 1024 SIMDs), rocprofv3 PMC, "
+                                      f"profiles/{MFMA_FILES[workload][dtype == 'fp16x3']}")
+        roofline["mfma_busy_stamp"] = stamp(doc)
+    else:
+        roofline["mfma_busy_note"] = why
+    try:  # the library this process runs (afx_version carries the build id the PMC files are stamped with)
+        from afx._lib import lib
+        roofline["library"] = lib().afx_version().decode()
+    except Exception:
+        pass
     return roofline, breakdown
 
 
@@ -180,30 +222,59 @@ def path_roofline(value, gflop, n_layers, batch, dtype):
             "note": "whole path: model FLOPs x utt/s / dense matrix-core peak; SURVEY 8(d)'s minimum HBM bytes x utt/s / 8 TB/s"}
 
 
-def cpu_parity(w, cpu_sample):
+def oracle_sample(w, cpu_sample):
     """The CPU oracle on this box's host cores over a bounded sample of the workload's own utterances (rank 0, N = 1):
-    (cpu_baseline, parity) -- the oracle's rate and the GPU-vs-oracle |dlogit| of that sample."""
+    (cpu_baseline, oracle logits, oracle taps) -- the oracle's rate and what the GPU legs of every dtype are compared with."""
     from oracle import models as omodels
     n = min(cpu_sample, w["B"])
     # a one-GPU box gets a 16-core share of the host (more threads only oversubscribe it)
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
-    fwd = omodels.conformer_forward if w["arch"] == "conformer" else omodels.xlsr_aasist_forward
+    teacher = w["arch"] != "conformer"
+    fwd = omodels.xlsr_aasist_forward if teacher else omodels.conformer_forward
     cpu_wave = w["wave"][:n].cpu()
     fwd(w["sd"], cpu_wave[:1])  # warm the thread pool
-    reps, cpu_s = 0, 0.0
+    reps, cpu_s, taps = 0, 0.0, {}
     while cpu_s < 10.0 and reps < 50:  # a bounded sample of about 10-20 s of CPU work
+        taps = {}
         t0 = time.perf_counter()
-        ref = fwd(w["sd"], cpu_wave)
+        ref = fwd(w["sd"], cpu_wave, taps=taps) if teacher else fwd(w["sd"], cpu_wave)
         cpu_s += time.perf_counter() - t0
         reps += 1
-    got = w["eng"].forward(w["wave"])[:n].cpu()
     base = {"value": round(n * reps / cpu_s, 3), "unit": "utterances/s", "cores": torch.get_num_threads(), "cpu": cpu_model(), "kind": "port",
             "sample": f"{reps} batched fp32 forward(s) of the CPU oracle (PyTorch CPU) over {n} of the same 4 s "
                       f"utterances, {cpu_s:.1f} s in all"}
+    return base, ref, taps
+
+
+def parity_of(w, ref, taps):
+    """GPU-vs-oracle |dlogit| of the sample `ref` was computed on.  Teacher: beside every utterance whether the REFERENCE
+    MODEL keeps its GraphPool decisions (descending top-k, models/aasist_modules.py:330-336, merged position by position,
+    models/xlsr_aasist.py:160-162) when its back-end is fed this engine's SSL features instead of the oracle's own -- where
+    it does not, a logit moves by what the reference makes of a swapped near-tie, not by a rounding error of this build."""
+    n = ref.shape[0]
+    eng = w["eng"]
+    teacher = w["arch"] != "conformer"
+    if teacher:
+        eng.enable_taps()
+    got = eng.forward(w["wave"])[:n].cpu()
     per_utt = (got - ref).abs().max(dim=1)[0]
-    parity = {"max_abs_dlogit_vs_oracle": float(per_utt.max()), "tolerance": 1e-3, "utterances": n}
-    return base, parity, per_utt.tolist()
+    parity = {"max_abs_dlogit_vs_oracle": float(per_utt.max()), "tolerance": 1e-3, "utterances": n,
+              "per_utterance": [float(f"{v:.3g}") for v in per_utt.tolist()]}
+    if teacher:
+        from oracle import aasist as oa
+        from oracle import models as omodels
+        feats = eng.tap("ssl").cpu().reshape(w["B"], -1, 1024)[:n]
+        eng.enable_taps(False)
+        mid = {}
+        oa.aasist_backend(omodels.split(w["sd"])[1], feats, mid)
+        same = [all(torch.equal(taps["pool_idx"][p][j], mid["pool_idx"][p][j]) for p in taps["pool_idx"]) for j in range(n)]
+        parity["same_topk"] = same
+        parity["utterances_keeping_every_topk_decision"] = int(sum(same))
+        parity["max_where_topk_kept"] = max((float(per_utt[j]) for j in range(n) if same[j]), default=None)
+        parity["max_where_topk_changed"] = max((float(per_utt[j]) for j in range(n) if not same[j]), default=None)
+        parity["feature_rel_l2_max"] = float(max((feats[j] - taps["ssl"][j]).norm() / taps["ssl"][j].norm() for j in range(n)))
+    return parity
 
 
 def main():
@@ -245,14 +316,13 @@ def main():
 
     from afx.dist import all_gather_scores
 
-    def make_step(w):
-        """One step = one forward of the hot path over the resident batch (+ the RCCL score all-gather when N > 1).  Steps
-        are issued the way the scoring loop issues them (afx.harness.produce_evaluation_file): the back-end of step i
-        (Conformer head / AASIST graph head) on the engine's side stream under the trunk of step i+1, scores read after
-        the last step; every step completes inside the timed region (the current stream joins the side stream before
-        the closing event and synchronize)."""
+    def make_step(w, overlapped):
+        """One step = one forward of the hot path over the resident batch (+ the RCCL score all-gather when N > 1).
+        overlapped: issued the way the scoring loop issues it (afx.harness.produce_evaluation_file) -- the back-end of step i
+        (Conformer head / AASIST graph head) on the engine's side stream under the trunk of step i+1, scores read after the
+        last step; every step completes inside the timed region (the current stream joins the side stream, behind the last
+        collective, before the closing event and synchronize)."""
         idx = torch.arange(rank * w["B"], (rank + 1) * w["B"], dtype=torch.int32, device="cuda")
-        overlapped = not args.no_overlap
 
         def step():
             if not overlapped:
@@ -261,39 +331,91 @@ def main():
             scores = w["eng"].forward_overlapped(w["wave"])[:, 1]
             if use_dist:  # the collective follows the head on ITS stream: the next trunk does not wait for it
                 with torch.cuda.stream(w["eng"]._side):
-                    return all_gather_scores(idx, scores, world)
+                    out = all_gather_scores(idx, scores, world)
+                w["eng"].mark_side()  # join() then covers the collective too
+                return out
             return idx, scores
 
         def join():
             w["eng"].join()
         return step, (join if overlapped else None)
 
+    def pick_issue(w):
+        """The two-stream step rests on how ROCm maps streams onto hardware queues (afx/engine.py::side_stream): with more
+        streams in the process (RCCL at world size > 1) the side stream can land on the trunk's queue (overlap lost) or the
+        process can run into the > 4-queue regime that measured 2x slower (profiles/r03_k_dist_overlap_hw_queues.txt).  So
+        the bench does not assume: both forms are timed over the warm-up count right here, max over ranks, and the faster
+        one is what the timed region issues.  Returns (overlapped, probe)."""
+        if args.no_overlap:
+            return False, None
+        n = max(args.warmup, 3)
+        ms = {}
+        for name, ov in (("two_stream", True), ("one_stream", False)):
+            st, jn = make_step(w, ov)
+            el, _, _ = time_steps(st, n, 2, use_dist, dist, join=jn)
+            ms[name] = el / n * 1e3
+        ov = ms["two_stream"] <= ms["one_stream"]
+        return ov, {"steps_each": n, "one_stream_ms_per_step": round(ms["one_stream"], 3), "two_stream_ms_per_step": round(ms["two_stream"], 3),
+                    "issued": "two_stream" if ov else "one_stream"}
+
+    ISSUE = {True: "back-end of step i on a side stream under the trunk of step i+1 (the scoring loop's form)", False: "one stream"}
+
+    def measure(w, workload, dtype):
+        """Warm-up, K timed steps (barriers, max over ranks), then the instrumented roofline pass: the fields every
+        timed configuration of this file carries."""
+        ov, probe = pick_issue(w)
+        st, jn = make_step(w, ov)
+        el, dms, out = time_steps(st, args.steps, args.warmup, use_dist, dist, join=jn)
+        if use_dist:
+            assert out[0].numel() == world * w["B"]
+        roof, brk = roofline_of(w, workload, dtype, args.steps)
+        val = world * w["B"] * args.steps / el
+        r = {"value": round(val, 2), "unit": "utterances/s", "n_gpus": world, "global_batch": world * w["B"],
+             "ms_per_step": round(el / args.steps * 1e3, 3), "device_ms_per_step": round(dms, 3), "dtype": dtype,
+             "model_tflops": round(val * w["gflop"] / 1e3, 1),
+             "path_roofline": path_roofline(val / world, w["gflop"], w["n_layers"], w["B"], dtype),
+             "roofline": roof, "kernel_ms_per_step": brk, "issue": ISSUE[ov]}
+        if probe:
+            r["issue_probe"] = probe
+        return r
+
+    CONTRACT_NOTE = ("dtype fp16x3 (split precision): the mode in which 'scores within 1e-3 on EVERY utterance, EER unchanged to 2 d.p.' "
+                     "holds whatever the checkpoint's top-k gaps (48 / 48 teacher utterances, 4096-trial student EER: tests/test_gpu_teacher.py, "
+                     "tests/test_gpu_models.py); same protocol, same utterances, roofline against 2.5 PF / 3")
+
+    def contract_of(workload, sd, oracle):
+        """The same protocol in the contract-holding precision, on the same weights and utterances."""
+        c = build(workload, "fp16x3", None, 4.0, rank, sd=sd)
+        r = measure(c, workload, "fp16x3")
+        r["note"] = CONTRACT_NOTE
+        if oracle is not None:
+            r["parity"] = parity_of(c, oracle[1], oracle[2])
+            r["parity_ok"] = r["parity"]["max_abs_dlogit_vs_oracle"] <= 1e-3
+        return r
+
+    default_run = args.workload == "conformer_student" and args.seconds == 4.0 and args.batch is None and args.dtype == "fp16"
     w = build(args.workload, args.dtype, args.batch, args.seconds, rank)
-    arch, oname, n_layers, gflop, B, L, sd, eng, wave = (w[k] for k in ("arch", "oname", "n_layers", "gflop", "B", "L", "sd", "eng", "wave"))
-    w_step, w_join = make_step(w)
-    elapsed, dev_ms, out = time_steps(w_step, args.steps, args.warmup, use_dist, dist, join=w_join)
-    if use_dist:
-        assert out[0].numel() == world * B
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * B * args.steps / elapsed
-    roofline, breakdown = roofline_of(w, args.workload, args.dtype, args.steps)
+    m = measure(w, args.workload, args.dtype)
+    eng, wave, B, L = w["eng"], w["wave"], w["B"], w["L"]
 
     result = {
-        "metric": "utterances/sec (4 s @ 16 kHz)" if args.seconds == 4.0 else f"utterances/sec ({args.seconds:g} s @ 16 kHz)", "value": round(value, 2), "unit": "utterances/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "metric": "utterances/sec (4 s @ 16 kHz)" if args.seconds == 4.0 else f"utterances/sec ({args.seconds:g} s @ 16 kHz)", "value": m["value"], "unit": "utterances/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {oname} ({n_layers}-layer XLS-R trunk), batch {B} per GPU, "
+        "config": {"workload": f"{args.workload}: {w['oname']} ({w['n_layers']}-layer XLS-R trunk), batch {B} per GPU, "
                                f"{args.seconds:g} s clips @ 16 kHz, random-init weights",
                    "global_batch": world * B, "samples_per_utterance": L,
                    "parallelism": f"dp{world} (utterance sharding, RCCL score all-gather)" if world > 1 else "single GPU"},
-        "model_tflops": round(value * gflop / 1e3, 1),
-        "path_roofline": path_roofline(value / world, gflop, n_layers, B, args.dtype),
-        "device_ms_per_step": round(dev_ms, 3),
-        "roofline": roofline,
-        "kernel_ms_per_step": breakdown,
+        "model_tflops": m["model_tflops"],
+        "path_roofline": m["path_roofline"],
+        "device_ms_per_step": m["device_ms_per_step"],
+        "roofline": m["roofline"],
+        "kernel_ms_per_step": m["kernel_ms_per_step"],
         "kernel_ms_note": "hipEvent pairs around every launch in a second, instrumented pass (one stream): each class reads ~3 % high",
-        "issue": "back-end of step i on a side stream under the trunk of step i+1 (the scoring loop's form)" if w_join else "one stream",
+        "issue": m["issue"],
     }
+    if "issue_probe" in m:
+        result["issue_probe"] = m["issue_probe"]
 
     # ---- the same K steps with the host hand-over inside: pinned fp32 waveform H2D (256 KB per
     # utterance) + forward + D2H of the scores (main.py:209-213).  Reported beside, never as, `value`.
@@ -325,45 +447,55 @@ def main():
         result["with_pcie"]["overlapped"] = round(B * args.steps / e2e, 2)
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample (rank 0, N=1) ----
+    oracle = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
-        result["cpu_baseline"], result["parity"], _ = cpu_parity(w, args.cpu_sample)
+        oracle = oracle_sample(w, args.cpu_sample)
+        result["cpu_baseline"] = oracle[0]
+        result["parity"] = parity_of(w, oracle[1], oracle[2])
         result["parity_ok"] = result["parity"]["max_abs_dlogit_vs_oracle"] <= 1e-3
 
-    # ---- BASELINE configs[2] (N = 1) / configs[3] (N = 8): the XLS-R-24 + AASIST teacher at batch 16 per GPU, timed by
-    # the same protocol right behind the headline.  Reported beside `value`, never mixed into it.
-    if args.workload == "conformer_student" and not args.no_config3 and args.seconds == 4.0 and args.batch is None:
-        del eng, wave, w
+    # ---- the contract-holding precision on the headline's own configuration (default run only)
+    sd = w["sd"]
+    del eng, wave, w
+    torch.cuda.empty_cache()
+    if default_run:
+        result["contract"] = contract_of(args.workload, sd, oracle)
         torch.cuda.empty_cache()
-        t = build("xlsr_aasist", args.dtype, None, 4.0, rank)
-        t_step, t_join = make_step(t)
-        el, dms, _ = time_steps(t_step, args.steps, args.warmup, use_dist, dist, join=t_join)
-        t_roof, t_break = roofline_of(t, "xlsr_aasist", args.dtype, args.steps)
-        result["config3"] = {
-            "workload": f"xlsr_aasist: XLSR_AASIST (24-layer XLS-R trunk), batch {t['B']} per GPU, 4 s clips @ 16 kHz, random-init weights"
-                        + (f", dp{world} (BASELINE configs[3] at N = 8)" if world > 1 else " (BASELINE configs[2])"),
-            "value": round(world * t["B"] * args.steps / el, 2), "unit": "utterances/s", "n_gpus": world,
-            "global_batch": world * t["B"], "ms_per_step": round(el / args.steps * 1e3, 3),
-            "device_ms_per_step": round(dms, 3), "model_tflops": round(world * t["B"] * args.steps / el * t["gflop"] / 1e3, 1),
-            "path_roofline": path_roofline(t["B"] * args.steps / el, t["gflop"], t["n_layers"], t["B"], args.dtype),
-            "dtype": args.dtype, "roofline": t_roof, "kernel_ms_per_step": t_break,
-            "issue": "back-end of step i on a side stream under the trunk of step i+1 (the scoring loop's form)" if t_join else "one stream",
-        }
+
+    # ---- BASELINE configs[2] (N = 1) / configs[3] (N = 8): the XLS-R-24 + AASIST teacher at batch 16 per GPU, timed by
+    # the same protocol right behind the headline.  Reported beside `value`, never mixed into it.  Its head is the seeded
+    # LIVELY head (matrices x 1.5, tests/test_gpu_teacher.py): with the default-init head every GraphPool score sits within
+    # 1e-6 of its neighbours and no logit responds to a changed top-k decision -- a parity sample on it hides exactly the
+    # effect config 3's contract is about.  Head weights do not change any kernel's time.
+    if args.workload == "conformer_student" and not args.no_config3 and args.seconds == 4.0 and args.batch is None:
+        t = build("xlsr_aasist", args.dtype, None, 4.0, rank, head_scale=1.5)
+        c3 = measure(t, "xlsr_aasist", args.dtype)
+        c3["workload"] = (f"xlsr_aasist: XLSR_AASIST (24-layer XLS-R trunk), batch {t['B']} per GPU, 4 s clips @ 16 kHz, random-init weights, lively head (x 1.5)"
+                          + (f", dp{world} (BASELINE configs[3] at N = 8)" if world > 1 else " (BASELINE configs[2])"))
+        t_oracle = None
         if rank == 0 and world == 1 and args.cpu_sample > 0:
-            # the same 8-utterance oracle sample as the headline.  Reported per utterance: with default-init heads the
-            # reference's own top-k decisions rarely move a logit beyond 1e-3 under the fp16 trunk rounding (DESIGN.md
-            # section 5, tests/test_gpu_teacher.py); the sample's maximum is the figure, parity_ok gates it
-            base, par, per_utt = cpu_parity(t, args.cpu_sample)
-            par["per_utterance"] = [float(f"{v:.3g}") for v in per_utt]
-            result["config3"]["cpu_baseline"], result["config3"]["parity"] = base, par
-            result["config3"]["parity_ok"] = par["max_abs_dlogit_vs_oracle"] <= 1e-3
+            # the 8-utterance oracle sample, per utterance, with the reference's own top-k status beside each: in fp16 a
+            # near-tied pair of graph nodes may swap under the trunk's rounding and the REFERENCE then moves a logit by up to
+            # ~1e-2; `contract` below is the same sample in the precision that keeps every decision
+            t_oracle = oracle_sample(t, args.cpu_sample)
+            c3["cpu_baseline"] = t_oracle[0]
+            c3["parity"] = parity_of(t, t_oracle[1], t_oracle[2])
+            c3["parity_ok"] = c3["parity"]["max_abs_dlogit_vs_oracle"] <= 1e-3
+        t_sd = t["sd"]
+        del t
+        torch.cuda.empty_cache()
+        if args.dtype == "fp16":
+            c3["contract"] = contract_of("xlsr_aasist", t_sd, t_oracle)
+        result["config3"] = c3
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
-    # the headline's parity sample is fatal (a fast wrong answer is not a result); config3's is reported in its object
-    # (`parity_ok`) -- a side line must not cost the driver its headline record
+    # the headline's parity sample is fatal (a fast wrong answer is not a result); config3's and the contracts' are reported
+    # in their objects (`parity_ok`) -- a side line must not cost the driver its headline record
     if rank == 0 and result.get("parity_ok") is False and not args.allow_parity_miss:
         raise SystemExit(f"parity sample misses the 1e-3 score tolerance: {result['parity']} (--allow-parity-miss to report anyway)")
+
 
 if __name__ == "__main__":
     main()

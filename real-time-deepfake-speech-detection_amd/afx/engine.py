@@ -96,6 +96,9 @@ class Engine:
         h = getattr(self, "_h", None)
         if h is not None and h.value and lib is not None:  # module globals are gone at interpreter exit
             try:
+                ev = getattr(self, "_last_head", None)
+                if ev is not None:
+                    ev.synchronize()  # a back-end still on the side stream reads the weights afx_destroy frees
                 lib().afx_destroy(h)
             except Exception:
                 pass
@@ -178,6 +181,10 @@ class Engine:
                 if slot["head_done"] is not None:
                     slot["head_done"].synchronize()
                 slot["ws"] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                # the head reads this block on the side stream: should the slot be dropped with a head still in flight (an
+                # exception in the caller's loop, an engine deleted before join()), the caching allocator must not hand the
+                # block to a current-stream op before the side stream is done with it
+                slot["ws"].record_stream(self._side)
             elif slot["head_done"] is not None:
                 cur.wait_event(slot["head_done"])  # this workspace's previous head (two calls ago) must be done with it
             ws = slot["ws"]
@@ -194,10 +201,45 @@ class Engine:
         return out
 
     def join(self):
-        """Make torch's current stream wait for every back-end forward_overlapped has put on the side stream."""
+        """Make torch's current stream wait for every back-end forward_overlapped has put on the side stream (and for
+        whatever the caller queued behind it there and marked with ``mark_side``)."""
         ev = getattr(self, "_last_head", None)
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def overlap_pays(self, wave, steps=3):
+        """Does the two-stream step beat the one-stream step HERE?  It rests on how ROCm maps this process's streams onto
+        hardware queues (``side_stream``): next to RCCL's streams at world size > 1 the side stream may share the trunk's
+        queue (overlap lost) or the process may use more than 4 queues (measured 2x slower).  Timed once per engine on the
+        caller's batch (``steps`` forwards each way, device-synchronised) and cached; scoring loops that run under a process
+        group ask before they issue (afx.harness.produce_evaluation_file_distributed, bench.py does its own probe)."""
+        if getattr(self, "_overlap_pays", None) is None:
+            dev = self.device
+            def run(fn):
+                fn(wave)  # warm (workspaces, attribute calls)
+                self.join()
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                with torch.cuda.device(dev):
+                    e0.record(torch.cuda.current_stream(dev))
+                    for _ in range(steps):
+                        fn(wave)
+                    self.join()
+                    e1.record(torch.cuda.current_stream(dev))
+                torch.cuda.synchronize(dev)
+                return e0.elapsed_time(e1)
+            two, one = run(self.forward_overlapped), run(self.forward)
+            self._overlap_probe = {"one_stream_ms": one / steps, "two_stream_ms": two / steps}
+            self._overlap_pays = two <= one
+        return self._overlap_pays
+
+    def mark_side(self):
+        """The caller put work of its own on the side stream behind the last back-end (bench.py: the RCCL score all-gather
+        of a step): ``join()`` waits for it too from now on."""
+        if getattr(self, "_side", None) is not None:
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            self._last_head = ev
 
     def ssl(self, wave):
         x = self._wave(wave)

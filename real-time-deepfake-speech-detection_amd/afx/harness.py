@@ -157,6 +157,18 @@ def prefetch_to_device(batches, device):
         cur = nxt
 
 
+def _may_overlap(model):
+    """The scoring loops may call ``model.forward_overlapped(x)`` in place of the reference's ``model(batch_x)``
+    (main.py:211) only where that skips nothing: ``nn.Module.__call__`` is what runs forward (pre-)hooks -- a
+    ``afx.kd.ForwardHookManager`` tap, anything the user registered -- so a model with hooks goes through ``model(x)``."""
+    from torch.nn.modules import module as _m
+    if getattr(model, "afx_arch", None) not in ("xlsr_aasist", "conformer") or not hasattr(model, "forward_overlapped"):
+        return False
+    if model._forward_hooks or model._forward_pre_hooks or _m._global_forward_hooks or _m._global_forward_pre_hooks:
+        return False
+    return True
+
+
 def produce_evaluation_file(dataset, model, device, save_path, batch_size, num_workers=4):
     """main.py:199-221.  Scores stay on the GPU until the end of the pass (one D2H copy
     instead of the reference's per-batch ``.cpu()``), and the next batch's H2D copy overlaps the
@@ -165,7 +177,7 @@ def produce_evaluation_file(dataset, model, device, save_path, batch_size, num_w
     names, chunks = [], []
     # the back-end of a batch (Conformer head: +5 %, AASIST graph head: +5.7 %) runs on a side stream under the next batch's
     # trunk: the scores are only read after the last batch, so nothing waits for a head inside the loop
-    overlapped = getattr(model, "afx_arch", None) in ("xlsr_aasist", "conformer") and hasattr(model, "forward_overlapped")
+    overlapped = _may_overlap(model)
     with torch.no_grad():
         loader = ((utt_id, batch_x) for utt_id, batch_x, _label in _loader(dataset, batch_size, num_workers))
         for utt_id, x in prefetch_to_device(loader, device):
@@ -308,10 +320,14 @@ def _produce_evaluation_file_distributed(dataset, model, device, save_path, batc
     model.eval()
     scores = torch.zeros(idx.numel(), dtype=torch.float32, device=device)
     names, outs = {}, []
-    overlapped = getattr(model, "afx_arch", None) in ("xlsr_aasist", "conformer") and hasattr(model, "forward_overlapped")
+    overlapped, asked = _may_overlap(model), False
     with torch.no_grad():
         loader = (((i, utt), x) for i, utt, x, _label in _loader(_Shard(dataset, idx.tolist()), batch_size, num_workers))
         for (i, utt), x in prefetch_to_device(loader, device):
+            if overlapped and not asked:
+                # next to a process group's streams the two-stream form is not taken on faith: timed once per engine on
+                # the first batch (Engine.overlap_pays), the faster form is what the pass issues
+                overlapped, asked = bool(model.overlap_pays(x)) if hasattr(model, "overlap_pays") else overlapped, True
             outs.append(model.forward_overlapped(x) if overlapped else model(x))  # (graph back-end under the next batch's trunk)
             names.update(zip((int(v) for v in (i.tolist() if torch.is_tensor(i) else i)), utt))
         if overlapped:

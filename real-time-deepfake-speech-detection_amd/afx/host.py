@@ -234,6 +234,12 @@ class AfxModule(nn.Module):
         self._afx_check(x)
         return self._afx_engine().forward_overlapped(x)
 
+    def overlap_pays(self, x):
+        """Engine.overlap_pays on this model's engine: whether the two-stream form is the faster one in this process."""
+        x = x.squeeze(-1) if x.ndim == 3 else x
+        self._afx_check(x)
+        return self._afx_engine().overlap_pays(x)
+
     def join_overlapped(self):
         eng = self.__dict__.get("_afx_eng")
         if eng is not None:

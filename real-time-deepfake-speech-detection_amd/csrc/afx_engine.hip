@@ -115,6 +115,7 @@ struct afx_engine {
   int conf_attn_mfma = 1;   // Conformer attention on the matrix cores (0: the fp32 VALU kernel)
   int fuse_conformer = 1;   // Conformer block: row-local chains fused (afx_conformer_fused.hip); 0 = per-op path
   int fuse_conv_ln = 1;     // conv layers 1-6: LayerNorm + GELU in the GEMM epilogue (0: two kernels)
+  int gemm_small_deep = 1;  // products with at most two 128x64 tiles per CU: the deep form of that tile (0: the two-buffer form)
   std::unordered_map<std::string, TapRec> taps;
 
   // trunk, packed operand-type weights
@@ -567,9 +568,10 @@ struct Carver {
 
 struct Ws {
   int T[7];
-  void *bufA, *bufB, *feats_h, *xpad, *hbuf, *qkv, *att, *ff, *ssl_h;
-  float *tmp32, *x, *ssl_f;
-  void* s3planes = nullptr;   // split precision: the hi / lo fp16 planes of the current product's A operand
+  void *bufA = nullptr, *bufB = nullptr, *feats_h = nullptr, *xpad = nullptr, *hbuf = nullptr, *qkv = nullptr, *att = nullptr, *ff = nullptr,
+       *ssl_h = nullptr;
+  float *tmp32 = nullptr, *x = nullptr, *ssl_f = nullptr;
+  void* s3planes = nullptr;   // split precision: scratch for the pair form of the current product's A operand
   size_t s3bytes = 0;
   float* gn_stats = nullptr;  // group-norm extractor mode: partial sums + mean / rstd of conv layer 0
   // ragged batch (afx_forward_ragged): valid SSL frames per utterance on the device (null = uniform batch), and the
@@ -577,8 +579,8 @@ struct Ws {
   int* lens = nullptr;
   float *bucket_f = nullptr, *bucket_logits = nullptr;
   // Conformer
-  float *ll32, *xc, *qkv32, *glu32;
-  void *hc, *hid, *ao, *u;
+  float *ll32 = nullptr, *xc = nullptr, *qkv32 = nullptr, *glu32 = nullptr;
+  void *hc = nullptr, *hid = nullptr, *ao = nullptr, *u = nullptr;
   // AASIST
   AasistWs aa;
 };
@@ -734,32 +736,37 @@ static thread_local Profiler* t_prof = nullptr;  // the profiler of the engine w
 static thread_local void* t_s3planes = nullptr;
 static thread_local size_t t_s3bytes = 0;
 // Operand buffers whose ONLY readers are dense products may receive their producer's result directly as the product's A
-// operand (fp16 hi / lo planes in place of the fp32 values: same bytes) -- the LayerNorm, the GELU epilogue and the attention
-// write the planes themselves and the separate split launch disappears.  t_s3ok: the buffers of this forward that qualify;
-// t_s3reg: which of them currently hold planes, and their plane stride in elements.
-struct S3Reg { const void* p; long stride; };
-static thread_local const void* t_s3ok[6] = {nullptr};
-static thread_local S3Reg t_s3reg[6] = {};
+// operand (the PAIR FORM of the row -- afx_kernels.h -- in place of its fp32 values: same bytes, row by row) -- the LayerNorms,
+// the GELU / LayerNorm epilogues of the products and the attention write the operand themselves and the separate split launch
+// disappears.  t_s3ok: the buffers of this forward that qualify; t_s3reg: which of them currently hold pair-form rows.
+constexpr int kS3Bufs = 10;
+static thread_local const void* t_s3ok[kS3Bufs] = {nullptr};
+static thread_local const void* t_s3reg[kS3Bufs] = {nullptr};
 static void s3_begin(std::initializer_list<const void*> ok) {
   int i = 0;
-  for (const void* p : ok) t_s3ok[i++] = p;
-  for (; i < 6; ++i) t_s3ok[i] = nullptr;
-  for (S3Reg& r : t_s3reg) r = S3Reg{nullptr, 0};
+  for (const void* p : ok)
+    if (p && i < kS3Bufs) t_s3ok[i++] = p;
+  for (; i < kS3Bufs; ++i) t_s3ok[i] = nullptr;
+  for (const void*& r : t_s3reg) r = nullptr;
 }
 static bool s3_ok(const void* p) {
   if (!p || !t_s3planes) return false;
   for (const void* q : t_s3ok) if (q == p) return true;
   return false;
 }
-static void s3_set(const void* p, long stride) {  // stride 0: the buffer holds fp32 values again
-  for (S3Reg& r : t_s3reg) if (r.p == p) { r.stride = stride; return; }
-  if (!stride) return;
-  for (S3Reg& r : t_s3reg) if (!r.p) { r = S3Reg{p, stride}; return; }
+static void s3_set(const void* p, bool pairs) {  // false: the buffer holds fp32 values again
+  for (const void*& r : t_s3reg) if (r == p) { if (!pairs) r = nullptr; return; }
+  if (!pairs) return;
+  for (const void*& r : t_s3reg) if (!r) { r = p; return; }
 }
-static long s3_planes_of(const void* p) {
-  for (const S3Reg& r : t_s3reg) if (r.p == p) return r.stride;
-  return 0;
+static bool s3_pairs_in(const void* p) {
+  for (const void* r : t_s3reg) if (r && r == p) return true;
+  return false;
 }
+// per-call context of the forward running on this thread: the engine's profiler, its A/B switches, and (split precision) the
+// pair-form scratch of the workspace plus the buffers whose producers may write pair-form rows in place
+static thread_local int t_no_deep = 0;
+static void begin_call(afx_engine* e, const Ws* w);
 static void prof_forget(afx_engine* e) {
   if (!e->prof) return;
   for (hipEvent_t ev : e->prof->pool) (void)hipEventDestroy(ev);
@@ -779,10 +786,15 @@ static const char* timed(int cls, double flops, hipStream_t s, F&& f) {
   p->recs.push_back({cls, a, b, flops});
   return m;
 }
-// Split precision (P_gemm below): x.w ~ xh.wh + xl.wh + xh.wl on the fp16 matrix pipe.  The fp32 A operand (the span of it
-// the product addresses) is split into two fp16 planes, the weight is already stored as [hi | lo] rows with per-row scales
-// (pack_linear), and ONE launch walks K three times: K' = 3 K (GemmArgs::k1).
-static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) {
+// Split precision (P_gemm below): x.w ~ xh.wl + xl.wh + xh.wh on the fp16 matrix pipe.  Both operands go in PAIR FORM
+// (afx_kernels.h): the weight is stored that way with per-row scales behind it (pack_linear), the fp32 A operand is either
+// already there (its producer wrote pair-form rows in place: s3_pairs_in) or the span the product addresses is converted into
+// the workspace's scratch; ONE launch then walks the 2 K halfs of a row like a plain fp16 operand and issues three matrix
+// instructions per K-step on the fragments it reads anyway (round 3 walked K three times over separate hi / lo planes: 1.5x
+// the K-tiles, operand bytes and fragment reads for the same matrix-pipe work).
+static const char* P_gemm(const GemmArgs& g_in, int dt, int groups, hipStream_t s) {
+  GemmArgs g = g_in;
+  g.no_deep = t_no_deep;  // (the engine's "gemm_small_deep" switch)
   const double fl = 2.0 * g.M * g.N * (g.k_algo ? g.k_algo : g.K) * groups;
   // profiler class of a tile id (afx_gemm.hip::gemm_tile_of): 92 = the deep form of the 128x64 tile, a class of its own
   auto cls_of = [](int tile) -> int {
@@ -790,37 +802,39 @@ static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) 
     return tile == 92 ? PC_GEMM64_DEEP : (tile >= 0 && tile < 9 ? cls[tile] : PC_GEMM128);
   };
   if (dt == DT_FP32 && t_s3planes) {
-    if (g.K % 64 || g.kchunk % 64) {  // (a K the fp16 tiles cannot walk: the fp32 instruction)
-      if (g.out_h) s3_set(g.out_h, 0);
+    const bool groups32 = !(g.K % 32 || g.kchunk % 32 || g.a_row % 32 || g.a_batch % 32 || g.g_a % 32 || g.kchunk_stride % 32 || g.ldw % 32 || g.g_w % 32);
+    if (!groups32 || ((size_t)g.A & 127)) {  // (rows the pair form cannot address in whole 32-element groups: the fp32 instruction)
+      if (g.out_h) s3_set(g.out_h, false);
       return launch_gemm(g, DT_FP32, groups, s);
     }
     GemmArgs q = g;
-    const long last = g.M - 1;
-    const long span = (last / g.rpb) * g.a_batch + (last % g.rpb) * g.a_row + (long)(g.K / g.kchunk - 1) * g.kchunk_stride + g.kchunk +
-                      (long)(groups - 1) * g.g_a;
-    const long have = s3_planes_of(g.A);
-    if (have >= span) {  // the producer wrote the planes in place of the fp32 values
-      q.a_plane = have;
-    } else {
-      const long plane = (span + 63) & ~63L;
-      if ((size_t)plane * 4 > t_s3bytes) return "split-precision product: the A operand exceeds the plane scratch";
-      if (const char* m = timed(PC_MISC, 0, s, [&] { return launch_split_planes((const float*)g.A, span, t_s3planes, plane, s); })) return m;
+    if (!s3_pairs_in(g.A)) {  // convert the span of A this product addresses (fp32 elements from g.A on) into the scratch
+      const long last = g.M - 1;
+      long span = (last / g.rpb) * g.a_batch + (last % g.rpb) * g.a_row + (long)(g.K / g.kchunk - 1) * g.kchunk_stride + g.kchunk +
+                  (long)(groups - 1) * g.g_a;
+      span = (span + 31) & ~31L;
+      if ((size_t)span * 4 > t_s3bytes) return "split-precision product: the A operand exceeds the pair-form scratch";
+      if (const char* m = timed(PC_MISC, 0, s, [&] { return launch_split_pairs((const float*)g.A, span, t_s3planes, s); })) return m;
       q.A = t_s3planes;
-      q.a_plane = plane;
     }
+    // every K-side length counts halfs of the pair form: twice the fp32-element value
     q.k1 = g.K;
-    q.K = 3 * g.K;
+    q.K = 2 * g.K;
     if (!q.k_algo) q.k_algo = g.K;
-    q.w_plane = g.ldw;
-    q.ldw = 2 * g.ldw;   // W is addressed in halfs: fp32 [N][ldw] became fp16 [N][hi ldw | lo ldw]
+    q.kchunk = 2 * g.kchunk;
+    q.kchunk_stride = 2 * g.kchunk_stride;
+    q.a_row = 2 * g.a_row;
+    q.a_batch = 2 * g.a_batch;
+    q.g_a = 2 * g.g_a;
+    q.ldw = 2 * g.ldw;
     q.g_w = 2 * g.g_w;
     q.pre_scale = (const float*)((const char*)g.W + (size_t)groups * g.N * g.ldw * 4);  // afx_engine::wscale
-    // the result as the NEXT product's A operand, where only products read the buffer and its rows are packed
+    // the result as the NEXT product's A operand, where only products read the buffer (pair-form rows in place of fp32 rows)
     if (g.out_h) {
-      const bool planes_out = s3_ok(g.out_h) && groups == 1 && g.ldo_h == g.N && g.rpb >= g.M && g.oh_row_off == 0 && (g.N & 7) == 0 &&
-                              (g.act == ACT_NONE || g.act == ACT_GELU) && !g.ln_gamma && g.out_h != g.A;
-      q.oh_plane = planes_out ? (long)g.M * g.N : 0;
-      s3_set(g.out_h, q.oh_plane);
+      const bool pairs_out = s3_ok(g.out_h) && (g.N & 7) == 0 && (g.g_n & 7) == 0 && (g.ldo_h & 31) == 0 &&
+                             (g.act == ACT_NONE || g.act == ACT_GELU) && g.out_h != g.A;
+      q.oh_pairs = pairs_out ? 1 : 0;
+      s3_set(g.out_h, pairs_out);
     }
     const int tile = gemm_tile_of(q, groups);
     return timed(cls_of(tile), fl, s, [&] { return launch_gemm(q, DT_FP16X3, groups, s); });
@@ -829,13 +843,21 @@ static const char* P_gemm(const GemmArgs& g, int dt, int groups, hipStream_t s) 
 }
 static const char* P_rownorm(const RowNormArgs& a_in, int dt, hipStream_t s) {
   RowNormArgs a = a_in;
-  if (a.out_h && t_s3planes) {  // split precision: the LayerNorm writes the next product's A planes itself
-    const bool planes_out = dt == DT_FP32 && s3_ok(a.out_h) && a.ldo_h == a.C && a.rpb >= a.rows && a.o_row_off == 0 && (a.C & 7) == 0 &&
-                            a.out_h != (const void*)a.x;
-    a.oh_plane = planes_out ? (long)a.rows * a.C : 0;
-    s3_set(a.out_h, a.oh_plane);
+  if (a.out_h && t_s3planes) {  // split precision: the LayerNorm writes the next product's A operand (pair-form rows) itself
+    const bool pairs_out = dt == DT_FP32 && s3_ok(a.out_h) && (a.ldo_h & 31) == 0 && a.out_h != (const void*)a.x;
+    a.oh_pairs = pairs_out ? 1 : 0;
+    s3_set(a.out_h, pairs_out);
   }
   return timed(PC_ROWNORM, 0, s, [&] { return launch_rownorm(a, dt, s); });
+}
+
+static void begin_call(afx_engine* e, const Ws* w) {
+  t_prof = e->prof;
+  t_no_deep = e->gemm_small_deep ? 0 : 1;
+  t_s3planes = w ? w->s3planes : nullptr;
+  t_s3bytes = w ? w->s3bytes : 0;
+  if (w) s3_begin({w->bufA, w->bufB, w->feats_h, w->hbuf, w->att, w->ff, w->xpad, w->hc, w->ssl_h});
+  else s3_begin({});
 }
 
 extern "C" int afx_profile_begin(afx_handle h) {
@@ -930,7 +952,7 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
         g.out_f = w.tmp32; g.ldo_f = kC;
       }
       KOK(launch_gemm(g, dt, 1, s));
-    } else if (e->fuse_conv_ln && dt != DT_FP32) {
+    } else if (e->fuse_conv_ln && (dt != DT_FP32 || e->s3)) {  // (split precision: the same tile with the pair-form walk)
       g.ln_gamma = cf(i, ".2.1.weight"); g.ln_beta = cf(i, ".2.1.bias"); g.ln_eps = kLnEps;
       if (i < 6) {
         g.out_h = out; g.ldo_h = kC;
@@ -1011,11 +1033,11 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     KOK(launch_gemm(q, dt, 1, s));
     KOK(timed(PC_MHSA, 4.0 * B * kH * (double)Tt * Tt * 64, s, [&] {
       if (e->s3 && Tt <= 224) {  // split precision: the matrix-core form; its output goes out as the output projection's A planes
-        const long plane = s3_ok(w.att) ? (long)M * kD : 0;
-        s3_set(w.att, plane);
-        return launch_mhsa_split((const float*)w.qkv, (float*)w.att, B, Tt, kH, s, w.lens, plane);
+        const bool pairs = s3_ok(w.att);
+        s3_set(w.att, pairs);
+        return launch_mhsa_split((const float*)w.qkv, (float*)w.att, B, Tt, kH, s, w.lens, pairs);
       }
-      if (e->s3) s3_set(w.att, 0);
+      if (e->s3) s3_set(w.att, false);
       return launch_mhsa(w.qkv, w.att, B, Tt, kH, dt, s, w.lens);
     }));
     KOK(resid_product(w.att, kD, e->wo[l], kD, e->F(P + "self_attn.out_proj.bias")));
@@ -1307,8 +1329,7 @@ extern "C" int afx_kv_step(afx_kv* k, const float* feats6, int n, float* logits,
   const size_t needb = kv_carve(e, S, n, Th, ws, &w);
   if (ws_bytes < needb) return fail("afx_kv_step: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   hipStream_t s = (hipStream_t)stream;
-  t_prof = e->prof;
-  t_s3planes = nullptr;
+  begin_call(e, nullptr);
   const size_t hs = e->hsz;
   k->cnt[group] = n;
   // feature LayerNorm -> operand type
@@ -1406,10 +1427,7 @@ extern "C" int afx_forward(afx_handle h, const float* wave, int B, int L, float*
   const size_t needb = carve(h, B, L, 0, ws, &w);
   if (ws_bytes < needb) return fail("afx_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   hipStream_t s = (hipStream_t)stream;
-  t_prof = h->prof;
-  t_s3planes = w.s3planes;
-  t_s3bytes = w.s3bytes;
-  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
+  begin_call(h, &w);
   if (run_trunk(h, wave, B, L, w, s)) return 1;
   return run_head(h, B, w.T[6], w, logits, s);
 }
@@ -1423,10 +1441,7 @@ extern "C" int afx_trunk_forward(afx_handle h, const float* wave, int B, int L, 
   Ws w;
   const size_t needb = carve(h, B, L, 0, ws, &w);
   if (ws_bytes < needb) return fail("afx_trunk_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
-  t_prof = h->prof;
-  t_s3planes = w.s3planes;
-  t_s3bytes = w.s3bytes;
-  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
+  begin_call(h, &w);
   return run_trunk(h, wave, B, L, w, (hipStream_t)stream);
 }
 extern "C" int afx_head_from_workspace(afx_handle h, int B, int L, float* logits, void* ws, size_t ws_bytes, void* stream) {
@@ -1436,10 +1451,7 @@ extern "C" int afx_head_from_workspace(afx_handle h, int B, int L, float* logits
   const size_t needb = carve(h, B, L, 0, ws, &w);
   if (ws_bytes < needb) return fail("afx_head_from_workspace: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   if (w.T[6] < 1) return fail("afx_head_from_workspace: %d samples are too few for one output frame", L);
-  t_prof = h->prof;
-  t_s3planes = w.s3planes;
-  t_s3bytes = w.s3bytes;
-  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
+  begin_call(h, &w);
   return run_head(h, B, w.T[6], w, logits, (hipStream_t)stream);
 }
 
@@ -1463,10 +1475,7 @@ extern "C" int afx_tail_forward_strided(afx_handle h, const void* conv5_h, long 
   if (ws_bytes < needb) return fail("afx_tail_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   if (w.T[6] < 1) return fail("afx_tail_forward: %d conv-layer-5 frames are too few for one output frame", T5);
   hipStream_t s = (hipStream_t)stream;
-  t_prof = h->prof;
-  t_s3planes = w.s3planes;
-  t_s3bytes = w.s3bytes;
-  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
+  begin_call(h, &w);
   if (run_trunk(h, nullptr, B, 0, w, s, conv5_h, batch_stride)) return 1;
   return run_head(h, B, w.T[6], w, logits, s);
 }
@@ -1517,10 +1526,7 @@ extern "C" int afx_forward_ragged(afx_handle h, const float* wave, int B, int Lm
   hipStream_t s = (hipStream_t)stream;
   std::vector<int> frames;
   if (ragged_setup(h, B, Lmax, n_samples, w, frames, s)) return 1;
-  t_prof = h->prof;
-  t_s3planes = w.s3planes;
-  t_s3bytes = w.s3bytes;
-  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
+  begin_call(h, &w);
   if (run_trunk(h, wave, B, Lmax, w, s)) return 1;
   const int Tmax = w.T[6];
   if (h->cfg.arch == AFX_ARCH_CONFORMER) return run_head(h, B, Tmax, w, logits, s);
@@ -1557,10 +1563,7 @@ extern "C" int afx_ssl_forward_ragged(afx_handle h, const float* wave, int B, in
   hipStream_t s = (hipStream_t)stream;
   std::vector<int> frames;
   if (ragged_setup(h, B, Lmax, n_samples, w, frames, s)) return 1;
-  t_prof = h->prof;
-  t_s3planes = w.s3planes;
-  t_s3bytes = w.s3bytes;
-  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
+  begin_call(h, &w);
   if (run_trunk(h, wave, B, Lmax, w, s)) return 1;
   const int Tmax = w.T[6];
   HIP_OK(hipMemcpyAsync(feats, w.ssl_f, (size_t)B * Tmax * kD * 4, hipMemcpyDeviceToDevice, s));
@@ -1579,10 +1582,7 @@ extern "C" int afx_ssl_forward(afx_handle h, const float* wave, int B, int L, fl
   const size_t needb = carve(h, B, L, 0, ws, &w);
   if (ws_bytes < needb) return fail("afx_ssl_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   hipStream_t s = (hipStream_t)stream;
-  t_prof = h->prof;
-  t_s3planes = w.s3planes;
-  t_s3bytes = w.s3bytes;
-  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
+  begin_call(h, &w);
   if (run_trunk(h, wave, B, L, w, s)) return 1;
   HIP_OK(hipMemcpyAsync(feats, w.ssl_f, (size_t)B * w.T[6] * kD * 4, hipMemcpyDeviceToDevice, s));
   return 0;
@@ -1619,10 +1619,7 @@ extern "C" int afx_head_forward(afx_handle h, const float* feats, int B, int T, 
                        h->dt == AFX_DT_BF16 ? 1 : 0);
     HIP_OK(hipGetLastError());
   }
-  t_prof = h->prof;
-  t_s3planes = w.s3planes;
-  t_s3bytes = w.s3bytes;
-  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
+  begin_call(h, &w);
   return run_head(h, B, T, w, logits, s);
 }
 
@@ -1637,10 +1634,7 @@ extern "C" int afx_conformer_forward(afx_handle h, const float* tokens, int B, i
   memset(&w, 0, sizeof w);
   const size_t needb = carve(h, B, 0, T, ws, &w);
   if (ws_bytes < needb) return fail("afx_conformer_forward: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
-  t_prof = h->prof;
-  t_s3planes = w.s3planes;
-  t_s3bytes = w.s3bytes;
-  s3_begin({w.bufA, w.bufB, w.feats_h, w.hbuf, w.att, w.ff});
+  begin_call(h, &w);
   return run_conformer(h, B, T, w, logits, (hipStream_t)stream, tokens, embedding);
 }
 
@@ -1671,19 +1665,19 @@ extern "C" int afx_k_gemm(int dtype, const void* A, long lda, const void* W, lon
     // (weight rows [hi | lo] + row scales, built once per checkpoint; the A planes, built per product in the workspace)
     // are built per call in temporary device memory, and the call synchronises the stream before it frees them.
     hipStream_t s = (hipStream_t)stream;
-    if (K % 64 || lda != K || ldw != K) return fail("afx_k_gemm(fp16x3): contiguous rows, K %% 64 == 0");
+    if (K % 32 || lda != K || ldw != K || ((size_t)A & 127)) return fail("afx_k_gemm(fp16x3): contiguous 128-byte aligned rows, K %% 32 == 0");
     void *wp = nullptr, *planes = nullptr;
-    const long plane = ((long)M * K + 63) & ~63L;
-    if (hipMalloc(&wp, (size_t)N * K * 4 + (size_t)N * 4) != hipSuccess || hipMalloc(&planes, (size_t)plane * 4) != hipSuccess) {
+    const long span = ((long)M * K + 31) & ~31L;
+    if (hipMalloc(&wp, (size_t)N * K * 4 + (size_t)N * 4) != hipSuccess || hipMalloc(&planes, (size_t)span * 4) != hipSuccess) {
       (void)hipFree(wp);
       return fail("afx_k_gemm(fp16x3): device allocation failed");
     }
     float* sc = (float*)((char*)wp + (size_t)N * K * 4);
     const char* m = launch_pack_linear((const float*)W, N, K, K, wp, DT_FP32, s);
     if (!m) m = launch_split_weight_rows(wp, N, K, sc, s);
-    if (!m) m = launch_split_planes((const float*)A, (long)M * K, planes, plane, s);
+    if (!m) m = launch_split_pairs((const float*)A, span, planes, s);
     if (!m) {
-      g.A = planes; g.W = wp; g.k1 = K; g.K = 3 * K; g.kchunk = K; g.a_plane = plane; g.w_plane = K; g.ldw = 2L * K; g.pre_scale = sc;
+      g.A = planes; g.W = wp; g.k1 = K; g.K = 2 * K; g.kchunk = 2 * K; g.a_row = 2L * K; g.ldw = 2L * K; g.pre_scale = sc;
       m = launch_gemm(g, DT_FP16X3, 1, s);
     }
     (void)hipStreamSynchronize(s);
@@ -1835,6 +1829,7 @@ extern "C" int afx_engine_set(afx_handle h, const char* key, int value) {
   else if (!strcmp(key, "conf_attn_mfma")) h->conf_attn_mfma = value != 0;
   else if (!strcmp(key, "fuse_conformer")) h->fuse_conformer = value != 0;
   else if (!strcmp(key, "fuse_conv_ln")) h->fuse_conv_ln = value != 0;
+  else if (!strcmp(key, "gemm_small_deep")) h->gemm_small_deep = value != 0;
   else return fail("afx_engine_set: unknown key '%s'", key);
   return 0;
 }

@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
           }
           if (a.out_f) *(f32x4*)(a.out_f + orow * a.ldo_f + c) = y;
           if (a.out_h) {
-            if (std::is_same<T, float>::value && a.oh_plane > 0) {  // split precision: the next product's A planes
+            if (std::is_same<T, float>::value && a.oh_pairs) {  // split precision: the next product's A operand, pair form
               f16x4 hi, lo;
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
@@ -670,9 +670,9 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
                 hi[i] = (_Float16)sv;
                 lo[i] = (_Float16)(sv - (float)hi[i]);
               }
-              _Float16* hp = (_Float16*)a.out_h + orow * a.ldo_h + c;
+              _Float16* hp = (_Float16*)a.out_h + orow * (2 * a.ldo_h) + s3_pair_index(c);
               *(f16x4*)hp = hi;
-              *(f16x4*)(hp + a.oh_plane) = lo;
+              *(f16x4*)(hp + 32) = lo;
             } else {
               V4 h;
 #pragma unroll
@@ -805,8 +805,8 @@ const char* launch_pack_posconv(const float* v, const float* g, int C, int cpg, 
 }
 
 // ---- split precision (DT_FP16X3) operand preparation --------------------------------------------------------------------
-// One workgroup per weight row: the row is read whole (registers -> LDS) before anything is written, so the fp16 [hi | lo]
-// form can take the place of the fp32 row it was made from.
+// One workgroup per weight row: the row is read whole (registers -> LDS) before anything is written, so its pair form
+// (afx_kernels.h: hi / lo halves interleaved in groups of 32) can take the place of the fp32 row it was made from.
 __global__ __launch_bounds__(256) void split_weight_rows_kernel(float* w, int K, float* row_scale) {
   extern __shared__ float srow[];
   float* row = w + (long)blockIdx.x * K;
@@ -830,17 +830,19 @@ __global__ __launch_bounds__(256) void split_weight_rows_kernel(float* w, int K,
     e = e > 100 ? 100 : (e < -100 ? -100 : e);
   }
   const float sc = ldexpf(1.0f, e);
+  __syncthreads();  // (every thread has read its part of the row: the pair form overwrites it)
   _Float16* out = (_Float16*)row;
   for (int k = threadIdx.x; k < K; k += 256) {
     const float v = srow[k] * sc;
     const _Float16 h = (_Float16)v;
-    out[k] = h;
-    out[K + k] = (_Float16)(v - (float)h);
+    const long o = s3_pair_index(k);
+    out[o] = h;
+    out[o + 32] = (_Float16)(v - (float)h);
   }
   if (threadIdx.x == 0) row_scale[blockIdx.x] = ldexpf(1.0f, -e) / kS3ActScale;
 }
 const char* launch_split_weight_rows(void* w, int N, int K, float* row_scale, hipStream_t s) {
-  if (K > 12288) return "split_weight_rows: rows of at most 12288 elements";
+  if (K > 12288 || K % 32) return "split_weight_rows: rows of at most 12288 elements, whole 32-element groups";
   static LdsLimit lim;
   if (hipError_t e = lim.ensure((const void*)split_weight_rows_kernel, K * 4 + 64); e != hipSuccess) return hipGetErrorString(e);
   hipLaunchKernelGGL(split_weight_rows_kernel, dim3(N), dim3(256), (size_t)K * 4, s, (float*)w, K, row_scale);
@@ -848,39 +850,31 @@ const char* launch_split_weight_rows(void* w, int N, int K, float* row_scale, hi
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
 
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long n8, long n, _Float16* __restrict__ hi,
-                                                           _Float16* __restrict__ lo) {
+// fp32 values -> their pair form: a thread turns 8 consecutive values (inside one 32-element group) into 16 B of hi and 16 B of lo halves
+__global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restrict__ x, long n8, _Float16* __restrict__ out) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
     const long o = i * 8;
-    if (o + 8 <= n) {
-      const f32x4 a = *(const f32x4*)(x + o), b = *(const f32x4*)(x + o + 4);
-      f16x8 h, l;
+    const f32x4 a = *(const f32x4*)(x + o), b = *(const f32x4*)(x + o + 4);
+    f16x8 h, l;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float va = a[r] * kS3ActScale, vb = b[r] * kS3ActScale;
-        h[r] = (_Float16)va;
-        h[4 + r] = (_Float16)vb;
-        l[r] = (_Float16)(va - (float)h[r]);
-        l[4 + r] = (_Float16)(vb - (float)h[4 + r]);
-      }
-      *(f16x8*)(hi + o) = h;
-      *(f16x8*)(lo + o) = l;
-    } else {
-      for (long j = o; j < n; ++j) {
-        const float v = x[j] * kS3ActScale;
-        const _Float16 h = (_Float16)v;
-        hi[j] = h;
-        lo[j] = (_Float16)(v - (float)h);
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float va = a[r] * kS3ActScale, vb = b[r] * kS3ActScale;
+      h[r] = (_Float16)va;
+      h[4 + r] = (_Float16)vb;
+      l[r] = (_Float16)(va - (float)h[r]);
+      l[4 + r] = (_Float16)(vb - (float)h[4 + r]);
     }
+    _Float16* hp = out + s3_pair_index(o);
+    *(f16x8*)hp = h;
+    *(f16x8*)(hp + 32) = l;
   }
 }
-const char* launch_split_planes(const float* x, long n, void* planes, long plane_stride, hipStream_t s) {
+const char* launch_split_pairs(const float* x, long n, void* pairs, hipStream_t s) {
   if (n <= 0) return nullptr;
-  if (((size_t)x & 15) || ((size_t)planes & 15) || (plane_stride & 7)) return "split_planes: 16-byte aligned operands";
-  const long n8 = (n + 7) / 8;
+  if (((size_t)x & 127) || ((size_t)pairs & 127) || (n & 31)) return "split_pairs: whole, 128-byte aligned groups of 32 elements";
+  const long n8 = n / 8;
   const int blocks = (int)min((long)8192, (n8 + 255) / 256);
-  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, x, n8, n, (_Float16*)planes, (_Float16*)planes + plane_stride);
+  hipLaunchKernelGGL(split_pairs_kernel, dim3(blocks), dim3(256), 0, s, x, n8, (_Float16*)pairs);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

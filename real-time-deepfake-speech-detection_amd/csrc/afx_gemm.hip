@@ -41,6 +41,23 @@ namespace afx {
 // swapped so a lane holds 4 consecutive columns of one row) -> bias / activation / residual
 // / LayerNorm -> wide stores.
 // ---------------------------------------------------------------------------------------
+// split precision: 8 consecutive results (columns n .. n+7, n % 8 == 0: inside one 32-element group) as the next product's
+// A operand -- the pair form of kS3ActScale x value in place of the fp32 row (GemmArgs::oh_pairs)
+__device__ __forceinline__ void store_pairs8(void* out_h, long hrow, long ldo_h, long col, const f32x4& va, const f32x4& vb) {
+  f16x8 hi, lo;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float sa = va[r] * kS3ActScale, sb = vb[r] * kS3ActScale;
+    hi[r] = (_Float16)sa;
+    hi[4 + r] = (_Float16)sb;
+    lo[r] = (_Float16)(sa - (float)hi[r]);
+    lo[4 + r] = (_Float16)(sb - (float)hi[4 + r]);
+  }
+  _Float16* hp = (_Float16*)out_h + hrow * (2 * ldo_h) + s3_pair_index(col);
+  *(f16x8*)hp = hi;
+  *(f16x8*)(hp + 32) = lo;
+}
+
 // LEAN (the 8-phase kernels): only what the launcher sends them -- no activation or erf-GELU, N % 8 == 0.
 // The general form inlines the other activations at every one of the 32 steps and carries the 4-column
 // fallback: ~300 KB of code around a 12-KB K-loop, refetched through the instruction cache after every tile.
@@ -182,9 +199,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         }
         if (p.out_h) {
           if constexpr (S3) {
-            float* op = (float*)p.out_h + hrow * p.ldo_h + n;
-            *(f32x4*)op = va;
-            *(f32x4*)(op + 4) = vb;
+            if (p.oh_pairs) {
+              store_pairs8(p.out_h, hrow, p.ldo_h, n, va, vb);
+            } else {
+              float* op = (float*)p.out_h + hrow * p.ldo_h + n;
+              *(f32x4*)op = va;
+              *(f32x4*)(op + 4) = vb;
+            }
           } else {
             V8 h;
 #pragma unroll
@@ -317,19 +338,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         }
         if (p.out_h) {
           if constexpr (S3) {
-            if (p.oh_plane > 0) {  // the next product's A operand: fp16 hi / lo planes of kS3ActScale x value
-              f16x8 hi, lo;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float sa = va[r] * kS3ActScale, sb = vb[r] * kS3ActScale;
-                hi[r] = (_Float16)sa;
-                hi[4 + r] = (_Float16)sb;
-                lo[r] = (_Float16)(sa - (float)hi[r]);
-                lo[4 + r] = (_Float16)(sb - (float)hi[4 + r]);
-              }
-              _Float16* hp = (_Float16*)p.out_h + hrow * p.ldo_h + gcol + n;
-              *(f16x8*)hp = hi;
-              *(f16x8*)(hp + p.oh_plane) = lo;
+            if (p.oh_pairs) {  // the next product's A operand, in pair form
+              store_pairs8(p.out_h, hrow, p.ldo_h, gcol + n, va, vb);
             } else {
               float* op = (float*)p.out_h + hrow * p.ldo_h + gcol + n;
               *(f32x4*)op = va;
@@ -397,6 +407,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       }
     }
   }
+}
+
+// Split precision, one 64-half K-tile of pair-form operands (32 k values): acc += w_lo.a_hi + w_hi.a_lo + w_hi.a_hi, the small
+// terms first.  EVERY tile kernel issues exactly this sequence per K-tile and output element, so a row's bits do not depend on
+// the tile family that computed it (ragged batches, tests/test_gpu_models.py::test_ragged_bit_identity_holds_across_tile_families).
+template <class HT, int MT, int NT>
+__device__ __forceinline__ void s3_mfma(const typename HT::V8 (&wh)[NT], const typename HT::V8 (&wl)[NT], const typename HT::V8 (&ah)[MT],
+                                        const typename HT::V8 (&al)[MT], f32x4 (&acc)[MT][NT]) {
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wl[j], ah[i], acc[i][j]);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wh[j], al[i], acc[i][j]);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wh[j], ah[i], acc[i][j]);
 }
 
 template <int N>
@@ -519,15 +549,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
                    : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
   };
   auto stage = [&](int buf, int kt) {
-    int k0 = kt << 6;
-    long aplane = 0, wplane = 0;
-    if constexpr (S3) {  // K-tile kt of [xh.wh | xl.wh | xh.wl]: which planes, and the k inside the segment
-      const int seg = k0 >= 2 * p.k1 ? 2 : (k0 >= p.k1 ? 1 : 0);
-      k0 -= seg * p.k1;
-      aplane = seg == 1 ? p.a_plane : 0;
-      wplane = seg == 2 ? p.w_plane : 0;
-    }
-    const long ka = (long)(k0 / p.kchunk) * p.kchunk_stride + (k0 % p.kchunk) + aplane;
+    // (split precision: the operands are in pair form and K counts its halfs -- the same walk as a plain fp16 operand)
+    const int k0 = kt << 6;
+    const long ka = (long)(k0 / p.kchunk) * p.kchunk_stride + (k0 % p.kchunk);
     const unsigned base = (unsigned)(buf * STAGE);
     // a_nt: the A panel is read by exactly one workgroup (row-complete tile) -- stream it
     // non-temporally so it does not evict the W panel every workgroup re-reads from L2
@@ -535,7 +559,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) dma16(a_src[i] + ka, base + (i * NW + wave) * 1024, p.a_nt != 0);
 #pragma unroll
-      for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0 + wplane, base + A_BYTES + (i * NW + wave) * 1024, false);
+      for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0, base + A_BYTES + (i * NW + wave) * 1024, false);
     } else {
 #pragma unroll
       for (int i = 0; i < AI; ++i)
@@ -544,7 +568,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
                                          16, 0, 0);
 #pragma unroll
       for (int i = 0; i < WI; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0 + wplane),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0),
                                          (__attribute__((address_space(3))) void*)(smem + base + A_BYTES + (i * NW + wave) * 1024),
                                          16, 0, 0);
     }
@@ -562,20 +586,36 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_kernel(GemmArgs p) {
     __syncthreads();  // tile kt landed for every wave; every wave is done with tile kt-1
     if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
     const char* sb = smem + (kt & 1) * STAGE;
+    if constexpr (S3) {
+      // pair form: k-step 0 of the LDS rows holds the hi halves of 32 k values, k-step 1 their lo halves
+      V8 af[2][MT], wf[2][NT];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int slot = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
-      V8 af[MT], wf[NT];
+      for (int ks = 0; ks < 2; ++ks) {
+        const int slot = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
+        for (int j = 0; j < NT; ++j) wf[ks][j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
+        for (int i = 0; i < MT; ++i) af[ks][i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
+      }
       __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
+      s3_mfma<HT, MT, NT>(wf[0], wf[1], af[0], af[1], acc);
       __builtin_amdgcn_s_setprio(0);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int slot = ((ks * 4 + (lane >> 4)) ^ fsw) * 16;
+        V8 af[MT], wf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = *(const V8*)(sb + w_off + j * 16 * 128 + slot);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + a_off + i * 16 * 128 + slot);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+      }
     }
   }
 
@@ -713,25 +753,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
   };
-  // element offset of K-tile kt inside an A / W row.  Split precision (S3): the K-tiles walk [xh.wh | xl.wh | xh.wl] --
-  // segment 1 reads A's lo plane, segment 2 W's lo half; the k inside a segment restarts at 0.
-  const int nk1 = S3 ? (p.k1 >> 6) : 0;
-  auto koffA = [&](int kt) -> long {
-    if constexpr (S3) {
-      const int seg = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
-      return (long)(kt - seg * nk1) * 64 + (seg == 1 ? p.a_plane : 0);
-    } else {
-      return (long)kt * 64;
-    }
-  };
-  auto koffB = [&](int kt) -> long {
-    if constexpr (S3) {
-      const int seg = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
-      return (long)(kt - seg * nk1) * 64 + (seg == 2 ? p.w_plane : 0);
-    } else {
-      return (long)kt * 64;
-    }
-  };
+  // element offset of K-tile kt inside an A / W row (split precision: pair-form operands, K counts halfs -- the same walk)
+  auto koffA = [&](int kt) -> long { return (long)kt * 64; };
+  auto koffB = [&](int kt) -> long { return (long)kt * 64; };
   auto stageA = [&](int h, int buf, int kt) {
     const long ko = koffA(kt);
 #pragma unroll
@@ -775,17 +799,21 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
   auto quadrant = [&](int ah, int bh) {  // 16 MFMAs: (A half ah) x (B half bh) x K = 64
     if (AFX_DBG(p, 2048)) return;  // timing only: K-loop without its MFMAs
     __builtin_amdgcn_s_setprio(1);
+    // (split precision, pair-form operands: k-step 0 = the hi halves of the K-tile's 32 k values, k-step 1 = their lo halves;
+    // three passes w_lo.a_hi, w_hi.a_lo, w_hi.a_hi in the order of s3_mfma -- 24 MFMAs where the fp16 walk issues 16)
 #pragma unroll
-    for (int ks = 0; ks < KSN; ++ks)
+    for (int ks = 0; ks < (S3 ? 3 : KSN); ++ks) {
+      const int kw = S3 ? (ks == 0 ? 1 : 0) : ks, ka = S3 ? (ks == 1 ? 1 : 0) : ks;
 #pragma unroll
       for (int mi = 0; mi < MTH; ++mi)
         if (mi < (ah ? MF1 : MF0)) {
 #pragma unroll
           for (int nj = 0; nj < NTH; ++nj) {
             acc[ah * MF0 + mi][bh * NTH + nj] =
-                HT::mfma(wf[WIDE ? 0 : bh][nj][ks], af[WIDE ? ah : 0][mi][ks], acc[ah * MF0 + mi][bh * NTH + nj]);
+                HT::mfma(wf[WIDE ? 0 : bh][nj][kw], af[WIDE ? ah : 0][mi][ka], acc[ah * MF0 + mi][bh * NTH + nj]);
           }
         }
+    }
     __builtin_amdgcn_s_setprio(0);
   };
   // ---- PH == 3 ("ring3", the DEFAULT of the 256-wide instance; 0-4.5 % over the two-buffer form,
@@ -1218,18 +1246,12 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_deep_kernel(GemmArgs p) {
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
   };
   auto stage = [&](int buf, int kt) {
-    long k0 = (long)kt << 6, aplane = 0, wplane = 0;
-    if constexpr (S3) {  // K-tile kt of [xh.wh | xl.wh | xh.wl]: which planes, and the k inside the segment
-      const int seg = k0 >= 2 * p.k1 ? 2 : (k0 >= p.k1 ? 1 : 0);
-      k0 -= (long)seg * p.k1;
-      aplane = seg == 1 ? p.a_plane : 0;
-      wplane = seg == 2 ? p.w_plane : 0;
-    }
+    const long k0 = (long)kt << 6;  // (split precision: pair-form operands, K counts halfs -- the same walk)
     const unsigned base = (unsigned)(buf * STAGE);
 #pragma unroll
-    for (int i = 0; i < AI; ++i) dma16(a_src[i] + k0 + aplane, base + (i * NW + wave) * 1024);
+    for (int i = 0; i < AI; ++i) dma16(a_src[i] + k0, base + (i * NW + wave) * 1024);
 #pragma unroll
-    for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0 + wplane, base + A_BYTES + (i * NW + wave) * 1024);
+    for (int i = 0; i < WI; ++i) dma16(w_src[i] + k0, base + A_BYTES + (i * NW + wave) * 1024);
   };
   const int frow = lane & 15, fsw = (frow >> 1) & 7;
   const int a_off = (wr * WM + frow) * 128;
@@ -1260,12 +1282,16 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_deep_kernel(GemmArgs p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (S3) {
+      s3_mfma<HT, MT, NT>(wf[0], wf[1], af[0], af[1], acc);
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[ks][j], af[ks][i], acc[i][j]);
+          for (int j = 0; j < NT; ++j) acc[i][j] = HT::mfma(wf[ks][j], af[ks][i], acc[i][j]);
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -1302,8 +1328,8 @@ static constexpr int g_nodma = 0;
 bool gemm_set_nodma(int v) { return v == 0; }  // the product build has no such switch
 #endif
 
-// true: K is walked linearly (no chunked addressing) -- in split precision, inside each of the three segments
-static bool plain_k(const GemmArgs& p) { return p.kchunk == (p.k1 ? p.k1 : p.K); }
+// true: K is walked linearly (no chunked addressing)
+static bool plain_k(const GemmArgs& p) { return p.kchunk == p.K; }
 
 // Host-side shape contract; anything else is a programming error in the caller.
 static const char* check_gemm(const GemmArgs& p, int groups) {
@@ -1313,12 +1339,12 @@ static const char* check_gemm(const GemmArgs& p, int groups) {
   if (p.kchunk <= 0 || p.kchunk % 64) return "gemm: kchunk must be a positive multiple of 64";
   if (p.rpb <= 0) return "gemm: rows-per-batch must be positive";
   if (!p.out_f && !p.out_h) return "gemm: no output";
-  if (p.oh_plane && (!p.k1 || (p.N & 7) || (p.act != ACT_NONE && p.act != ACT_GELU) || p.ln_gamma || (p.oh_plane & 7)))
-    return "gemm: plane output goes with the lean split-precision epilogue (N % 8 == 0, no / GELU activation)";
+  if (p.oh_pairs && (!p.k1 || (p.N & 7) || (p.g_n & 7) || (p.act != ACT_NONE && p.act != ACT_GELU) || (p.ldo_h & 31) || !p.out_h))
+    return "gemm: pair-form output goes with the lean split-precision epilogue (N % 8 == 0, no / GELU activation, row stride % 32 == 0)";
   if (p.k1) {
-    if (p.k1 % 64 || p.K != 3 * p.k1 || !p.pre_scale || p.w_plane <= 0 || p.a_plane <= 0 || (p.a_plane & 7) || (p.w_plane & 7))
-      return "gemm: split precision needs K = 3 k1, k1 % 64 == 0, both plane strides and the column scales";
-    if (p.k1 % p.kchunk) return "gemm: split precision: the segment must be whole chunks";
+    if (p.k1 % 32 || p.K != 2 * p.k1 || !p.pre_scale) return "gemm: split precision needs pair-form operands (K = 2 k1 halfs, k1 % 32 == 0) and the column scales";
+    if (((size_t)p.A & 127) || ((size_t)p.W & 127) || (p.a_row & 63) || (p.a_batch & 63) || (p.g_a & 63) || (p.ldw & 63) || (p.g_w & 63) || (p.kchunk_stride & 63))
+      return "gemm: split precision: pair-form rows start on whole 32-element groups";
   }
   if (p.ln_gamma) {
     if (p.N != 512 || groups != 1) return "gemm: the fused LayerNorm epilogue needs N == 512 (row-complete tile)";
@@ -1406,12 +1432,16 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
     // (narrow products with at most two 128x64 tiles per CU: the deep form of the tile, as below)
     const long t64 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
     const bool lean = (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0;
-    if (g_small_deep && g_tile_override < 0 && groups == 1 && t64 <= 512 && plain_k(p) && lean && p.m_lo == 0) return 92;
+    if (g_small_deep && !p.no_deep && g_tile_override < 0 && groups == 1 && t64 <= 512 && plain_k(p) && lean && p.m_lo == 0) return 92;
     return 1;
   }
   if (groups != 1) return 0;
   if (g_tile_override == 5) return 1;  // 128x64 / 4 waves (forced)
+#ifdef AFX_ATTR
   if (g_tile_override >= 6 && g_tile_override <= 9) return plain_k(p) && !p.k1 ? 84 + g_tile_override : 0;  // deep tiles (90..93), A/B
+#else
+  if (g_tile_override == 8) return plain_k(p) ? 92 : 0;  // the deep 128x64 tile, forced (tests)
+#endif
   if (g_tile_override == 3) return plain_k(p) ? 7 : 0;  // 8-phase 256x256
   if (g_tile_override >= 0) return g_tile_override == 1 ? 2 : 0;
   // Wave-quantisation model fitted to tools/bench_gemm.py (profiles/r01_gemm_tile_ab*.txt):
@@ -1425,7 +1455,7 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
     // 43.3 us, out-proj 19.4 -> 17.7; at M = 8 x 199 41.6 -> 31.8 (tools/diag_deep_tiles.py).  With three workgroups per CU
     // (b128 > 256) the two-buffer form, which fits three, stays ahead.  Same k order: bit-identical rows.
     const bool lean = (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0;
-    if (g_small_deep && b128 <= 256 && plain_k(p) && lean && p.m_lo == 0) return 92;
+    if (g_small_deep && !p.no_deep && b128 <= 256 && plain_k(p) && lean && p.m_lo == 0) return 92;
     return 1;
   }
   if (gemm_split_rows(p, groups) > 0) return 7;  // whole rounds on the 8-phase kernel + a 128x128 remainder
@@ -1443,10 +1473,12 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 1: return lean ? launch_gemm_t<HT, 128, 64, 2, 2, false, true>(p, groups, s) : launch_gemm_t<HT, 128, 64, 2, 2>(p, groups, s);
     case 2: return launch_gemm_t<HT, 256, 256, 2, 4>(p, groups, s);
     case 3: return launch_gemm_t<HT, 128, 512, 2, 4, true>(p, groups, s);
+#ifdef AFX_ATTR  // measured, not faster (profiles/r03_k_small_experiments.txt): only in the attribution build, for tools/diag_deep_tiles.py
     case 90: return launch_gemm_deep_t<HT, 128, 128, 2, 2, 4>(p, groups, s);
     case 91: return launch_gemm_deep_t<HT, 128, 128, 2, 4, 4>(p, groups, s);
-    case 92: return launch_gemm_deep_t<HT, 128, 64, 2, 2, 3>(p, groups, s);
     case 93: return launch_gemm_deep_t<HT, 128, 128, 2, 2, 3>(p, groups, s);
+#endif
+    case 92: return launch_gemm_deep_t<HT, 128, 64, 2, 2, 3>(p, groups, s);
     case 7:
       if (g_ph4 == 0) return launch_gemm8_t<HT, 256, 256, false, 8, 3>(p, groups, s);  // default: the three-buffer ring form
 #ifdef AFX_ATTR

@@ -11,7 +11,16 @@ namespace afx {
 // runs on the fp16 matrix pipe as x.w ~ xh.wh + xl.wh + xh.wl with fp16 hi / lo pairs of both operands (GemmArgs::k1)
 enum DType { DT_BF16 = 0, DT_FP16 = 1, DT_FP32 = 2, DT_FP16X3 = 3 };
 inline size_t dtype_size(int dt) { return dt == DT_FP32 || dt == DT_FP16X3 ? 4 : 2; }
-constexpr float kS3ActScale = 16.f;  // split-precision A operands are scaled by this power of two before the hi / lo split (lo parts of O(1) activations stay in fp16's normal range; overflow only beyond |x| = 4094)
+#ifndef AFX_S3_ACT_SCALE
+#define AFX_S3_ACT_SCALE 16.f
+#endif
+constexpr float kS3ActScale = AFX_S3_ACT_SCALE;  // split-precision A operands are scaled by this power of two before the hi / lo split (the -D hook exists for A/B builds: make variant)
+// PAIR FORM (round 4): the hi / lo halves of a split-precision operand are interleaved in groups of 32 elements -- element k
+// of a row lives at half (k / 32) * 64 + k % 32 (hi) and 32 halfs further (lo) -- so a row of K values is 2 K consecutive
+// halfs in the bytes its fp32 form would take (row-local: any row stride that is a multiple of 32 elements works), and one
+// 128-byte piece of it is exactly one K-step of the matrix instruction for BOTH halves: the tile kernels walk it like a plain
+// fp16 operand of 2 K columns and issue, per 64-half K-tile, lo.hi + hi.lo + hi.hi on the fragments they have read anyway.
+__host__ __device__ inline long s3_pair_index(long k) { return ((k >> 5) << 6) + (k & 31); }
 
 struct GemmArgs {
   const void* A;  // matrix-core operand type (bf16/fp16), K contiguous
@@ -49,20 +58,20 @@ struct GemmArgs {
   const float* ln_beta;
   float ln_eps;
   int a_nt;  // 1: non-temporal LDS-DMA for the A panel (set by launch_gemm)
+  int no_deep;  // 1: never the deep form of the 128x64 tile (per-engine A/B switch "gemm_small_deep" = 0; bit-identical rows either way)
   int m_lo;  // 8-wave kernels only: the launch covers rows [m_lo, M) (set by launch_gemm for a remainder launch; 0 otherwise)
   // ---- split precision (launch_gemm with DT_FP16X3; set by the engine's wrapper, 0 / null otherwise) ---------------------
-  // K holds THREE segments of k1 each: [xh.wh | xl.wh | xh.wl].  A is a pair of fp16 planes (hi at A, lo at A + a_plane
-  // elements, same addressing in both); W rows are [hi k1' | lo k1'] with the lo half w_plane elements behind the hi half
-  // (ldw = 2 x w_plane); kchunk / kchunk_stride address INSIDE a segment.  The epilogue multiplies the accumulator of
-  // column n by pre_scale[n] (the inverse of the row's power-of-two weight scale x the activation scale) before the
-  // bias, and writes `out_h` as FP32 (the engine's operand buffers are fp32 in this mode).
+  // k1 = the algorithmic K; A and W are in PAIR FORM (above) and every length / stride on the K side of this struct counts
+  // HALFS of it: K = 2 k1, a_row / a_batch / g_a / kchunk / kchunk_stride / ldw / g_w are twice their fp32-element values.
+  // Per 64-half K-tile (32 k values: hi | lo) a tile kernel issues w_lo.a_hi + w_hi.a_lo + w_hi.a_hi.  The epilogue
+  // multiplies the accumulator of column n by pre_scale[n] (the inverse of the row's power-of-two weight scale x the
+  // activation scale) before the bias, and writes `out_h` as FP32 (the engine's operand buffers are fp32 in that mode).
   int k1;
-  long a_plane, w_plane;
   const float* pre_scale;
-  // split precision, output side: oh_plane > 0 = `out_h` receives the result AS the next product's A operand -- fp16 hi at
-  // out_h, lo at out_h + oh_plane elements, of kS3ActScale x value -- instead of fp32 (the producer writes the planes, no
-  // separate split launch: launch_split_planes)
-  long oh_plane;
+  // split precision, output side: oh_pairs != 0 = `out_h` receives the result AS the next product's A operand -- the pair
+  // form of kS3ActScale x value, row by row in place of the fp32 row (ldo_h % 32 == 0) -- instead of fp32 (the producer
+  // writes the operand, no separate split launch: launch_split_pairs)
+  int oh_pairs;
   int dbg_nodma;  // attribution build (-DAFX_ATTR) only, ignored otherwise: epilogue bits 8 no activation, 16 narrow stores, 32 no stores, 64 no epilogue
 };
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
@@ -121,7 +130,7 @@ struct RowNormArgs {
   void* out_h;
   long ldo_h;
   int rpb, o_batch_rows, o_row_off;
-  long oh_plane;  // split precision (with DT_FP32): > 0 = out_h receives fp16 hi / lo planes of kS3ActScale x y (lo at + oh_plane elements)
+  int oh_pairs;  // split precision (with DT_FP32): != 0 = out_h receives the PAIR FORM of kS3ActScale x y in place of the fp32 row (ldo_h % 32 == 0)
 };
 const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s);
 // zero the time padding rows of the positional-conv operand buffer (B, T+128, C)
@@ -134,11 +143,12 @@ const char* launch_pack_conv(const float* w, int N, int Cin, int k, void* out_h,
 const char* launch_pack_posconv(const float* v, const float* g, int C, int cpg, int k, float* norm_tmp /*[k]*/,
                                 void* out_h, int dtype, hipStream_t s);
 // Split precision (DT_FP16X3).  Weights: a matrix packed as fp32 rows [N][K] (the pack launchers above with DT_FP32) is
-// rewritten IN PLACE as fp16 rows [hi K | lo K] of w * 2^s_n, s_n the power of two that brings the row's largest magnitude
-// to [8192, 16384); row_scale[n] = 1 / (2^s_n * kS3ActScale).  K <= 12288.
+// rewritten IN PLACE as the pair form of w * 2^s_n, s_n the power of two that brings the row's largest magnitude
+// to [8192, 16384); row_scale[n] = 1 / (2^s_n * kS3ActScale).  K <= 12288, K % 32 == 0.
 const char* launch_split_weight_rows(void* w_f32_inplace, int N, int K, float* row_scale, hipStream_t s);
-// Activations: n fp32 values -> hi plane (n halfs at `planes`) and lo plane (at planes + plane_stride) of x * kS3ActScale
-const char* launch_split_planes(const float* x, long n, void* planes, long plane_stride, hipStream_t s);
+// Activations: n fp32 values (n % 32 == 0, x 128-byte aligned: whole 32-element groups) -> the pair form of x * kS3ActScale
+// at `pairs` (2 n halfs; x itself when the operand may be rewritten in place is NOT supported: distinct buffers)
+const char* launch_split_pairs(const float* x, long n, void* pairs, hipStream_t s);
 
 // ---- positional conv of the encoder as a sliding-window kernel (afx_posconv.hip) ---------------
 // x (B*T, 1024) fp32 += GELU(grouped conv over the time-padded operand copy xpad (B, T+128, 1024)); T <= 224
@@ -159,9 +169,9 @@ const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dty
 void mhsa_set_vtr(int v);  // A/B knob: V row-major in LDS + ds_read_b64_tr_b16 (0 = the V^T image)
 
 // the same attention with fp32 rows in / out and split-precision products on the fp16 matrix pipe (dtype "fp16x3"); T <= 224
-// out_plane > 0: `out` receives fp16 hi / lo planes of kS3ActScale x the result (lo at + out_plane elements) instead of fp32 rows
+// out_pairs: `out` receives the pair form of kS3ActScale x the result (row by row, in place of the fp32 rows) instead of fp32 rows
 const char* launch_mhsa_split(const float* qkv, float* out, int B, int T, int H, hipStream_t s, const int* lens = nullptr,
-                              long out_plane = 0);
+                              bool out_pairs = false);
 // KV-cached streaming attention (afx_kv_step; not a reference function): ring (S, 256, 3*H*64) rows [q | k | v] in 16-slot
 // groups, cnt[16] valid frames per group, the queries are group q_tile's slots; out (S, 16, H*64)
 const char* launch_mhsa_ring(const void* ring, void* out, int S, int H, int q_tile, const int* cnt, int dtype, hipStream_t s);
