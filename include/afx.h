@@ -141,6 +141,14 @@ size_t afx_head_workspace_bytes(afx_handle h, int B, int T);
  * afx_head_workspace_bytes(h, B, T). */
 int afx_conformer_forward(afx_handle h, const float* tokens, int B, int T, float* logits, float* embedding, void* ws,
                           size_t ws_bytes, void* stream);
+/* Overflow guard (no reference counterpart: the reference computes in fp32, models/fe.py:11-21).  The half-precision
+ * engines keep operand copies in fp16 / bf16 (fp16x3: fp16 hi / lo pairs); a checkpoint with outlier channels can push one
+ * past the format's range, after which the scores are NaN -- or, behind the AASIST head's max-pooling and top-k, finite
+ * garbage.  Every forward counts, on the device and for free, the rows of the trunk's final LayerNorm whose statistics are
+ * not finite and the logits that are not finite; this call waits for `stream`, returns non-zero (afx_last_error names the
+ * counts and the precision) when anything was counted since the last check, and clears the counters.  A scoring loop calls
+ * it once before it writes its scores (afx/harness.py does). */
+int afx_check_finite(afx_handle h, void* stream);
 /* debug taps (off by default; when on, forward keeps fp32 copies of intermediates) */
 int afx_enable_taps(afx_handle h, int on);
 /* debug taps: copy an intermediate of the LAST forward on this workspace into `out`

@@ -57,6 +57,7 @@ SIGNATURES = {
     "afx_kv_state_bytes": (_Z, [_P]),
     "afx_kv_workspace_bytes": (_Z, [_P, _I]),
     "afx_kv_step": (_I, [_P, _P, _I, _P, _P, _Z, _P]),
+    "afx_check_finite": (_I, [_P, _P]),
     "afx_enable_taps": (_I, [_P, _I]),
     "afx_tap": (_I, [_P, C.c_char_p, _P, _Z, C.POINTER(_Z), _P]),
     "afx_profile_begin": (_I, [_P]),

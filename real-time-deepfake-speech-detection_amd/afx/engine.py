@@ -241,6 +241,14 @@ class Engine:
             ev.record(self._side)
             self._last_head = ev
 
+    def check_finite(self):
+        """Raise ``AfxError`` if any forward since the last check produced non-finite trunk features or logits (an operand
+        copy left the range of this engine's precision: afx_check_finite).  Synchronises torch's current stream (after
+        joining the side stream); the scoring loops call it once, before they write a score."""
+        self.join()
+        with torch.cuda.device(self.device):
+            check(lib().afx_check_finite(self._h, self._stream()))
+
     def ssl(self, wave):
         x = self._wave(wave)
         B, L = x.shape

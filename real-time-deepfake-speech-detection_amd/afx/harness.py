@@ -186,9 +186,15 @@ def produce_evaluation_file(dataset, model, device, save_path, batch_size, num_w
             names.extend(utt_id)
         if overlapped:
             model.join_overlapped()
+    _check_finite(model)  # (an fp16 operand overflow is an error here, not a NaN -- or a plausible-looking -- score in the file)
     scores = torch.cat(chunks).cpu().numpy().ravel().tolist() if chunks else []
     write_score_file(save_path, names, scores)
     return names, scores
+
+
+def _check_finite(model):
+    if hasattr(model, "check_finite"):
+        model.check_finite()
 
 
 def checkpoint_comment(ckpt_path):
@@ -259,6 +265,7 @@ def produce_evaluation_file_ragged(dataset, model, device, save_path, batch_size
         for utt_id, clips, _label in loader:
             chunks.append(model.forward_ragged([torch.as_tensor(c) for c in clips])[:, 1])
             names.extend(utt_id)
+    _check_finite(model)
     scores = torch.cat(chunks).cpu().numpy().ravel().tolist() if chunks else []
     write_score_file(save_path, names, scores)
     return names, scores
@@ -279,6 +286,7 @@ def evaluate(model, loader, device, loss_fn=None, preprocessor=None):
                 loss_sum += loss_fn(out, label).item() * x.size(0)
             n_correct += (out.max(dim=1)[1] == label).sum().item()
             n_total += x.size(0)
+    _check_finite(model)
     return loss_sum / max(n_total, 1), n_correct / max(n_total, 1) * 100
 
 
@@ -332,6 +340,7 @@ def _produce_evaluation_file_distributed(dataset, model, device, save_path, batc
             names.update(zip((int(v) for v in (i.tolist() if torch.is_tensor(i) else i)), utt))
         if overlapped:
             model.join_overlapped()
+    _check_finite(model)
     if outs:
         got = torch.cat([o[:, 1] for o in outs])
         scores[: got.numel()] = got

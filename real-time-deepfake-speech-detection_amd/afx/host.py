@@ -245,6 +245,13 @@ class AfxModule(nn.Module):
         if eng is not None:
             eng.join()
 
+    def check_finite(self):
+        """Engine.check_finite: raises if a forward since the last check overflowed its operand precision (non-finite
+        features / logits) -- the scoring loops call it before they write a score file."""
+        eng = self.__dict__.get("_afx_eng")
+        if eng is not None:
+            eng.check_finite()
+
     def set_precision(self, dtype):
         """'fp16' (default) or 'bf16' matrix-core operands; 'fp16x3' (split precision, fp32-accurate, ~1/3 of the rate) or
         'fp32' (exact mode, 1/16) where every score must hold the tolerance whatever the checkpoint's top-k gaps."""

@@ -206,6 +206,30 @@ def model_state_dict(model, n_layers=24, **kw):
     return sd
 
 
+def with_outliers(sd, gain=30.0, n=4):
+    """A copy of a seeded state_dict with XLS-R-style OUTLIER CHANNELS (trained wav2vec2 / XLS-R trunks carry a few channels
+    whose activations are orders of magnitude above the rest; seeded weights at init scale do not): in every transformer
+    layer ``n`` rows of ``fc1`` (weight and bias: those FFN hidden units), ``n`` rows of ``out_proj`` (those residual
+    channels) and ``n`` gains of both LayerNorms are multiplied by ``gain``.  With gain 30 - 300 the FFN hidden and the
+    residual stream reach 1e2 - 1e4 -- what the fp16 operand copies of a half-precision engine have to hold
+    (tests/test_gpu_outliers.py).  Which rows: seeded per layer, the same on every box."""
+    out = dict(sd)
+    layers = sorted({k.split("encoder.layers.")[1].split(".")[0] for k in sd if "encoder.layers." in k}, key=int)
+    for l in layers:
+        p = f"{SSL_PREFIX}encoder.layers.{l}."
+        g = _gen(p + "outliers")
+        dim, ffn = sd[p + "fc2.weight"].shape
+        hid = torch.randperm(ffn, generator=g)[:n]
+        ch = torch.randperm(dim, generator=g)[:n]
+        ln = torch.randperm(dim, generator=g)[:n]
+        for k, idx in ((p + "fc1.weight", hid), (p + "fc1.bias", hid), (p + "self_attn.out_proj.weight", ch),
+                       (p + "self_attn_layer_norm.weight", ln), (p + "final_layer_norm.weight", ln)):
+            t = sd[k].clone()
+            t[idx] = t[idx] * gain
+            out[k] = t
+    return out
+
+
 def waveforms(batch, length=64000, batch_idx=0, scale=0.1):
     """x = 0.1*randn(B, L), seed 1234 + batch_idx."""
     g = torch.Generator(device="cpu")

@@ -242,6 +242,7 @@ constexpr int ACV_TM = 64;  // output pixels per workgroup step
 // holds two waves (one workgroup per CU: the weights of the 64 -> 64 (2,3) conv are 100 KB of LDS).  The staged pixels
 // are split into their fp16 hi / lo halves ONCE, while they are written to LDS (each is then read by kh x 3 taps and
 // two column waves): the inner loop is LDS fragment reads and MFMAs only.
+constexpr int ACV_PAD = 16;  // halfs of padding per LDS row (32 B)
 template <int NT>
 __global__ __launch_bounds__(512) void aas_conv_kernel(F32GemmArgs p, int C, int taps, int cpo, int ntiles) {
   static_assert(NT % 2 == 0, "two column halves");
@@ -250,8 +251,12 @@ __global__ __launch_bounds__(512) void aas_conv_kernel(F32GemmArgs p, int C, int
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
   constexpr int N = NT * 16;
-  const int K = p.nch * p.kc, Kp = K + 8;            // halfs per weight row in LDS (16 B of padding)
-  const int Cp = C + 8, SP = ACV_TM + taps - 1;      // halfs per pixel in LDS (16 B of padding); pixels per slab
+  // LDS rows (weights: K halfs, pixels: C halfs; both multiples of 32) are padded by 32 B: a row stride of 32 (mod 64) bytes
+  // is what the lane groups of ds_read_b128 -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS) --
+  // read without a bank conflict when lane l takes row l & 15, 16-byte piece l >> 4.  Round 3's 16 B of padding (stride 16
+  // mod 64) put two addresses on a bank in every group: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.41 - 0.47 on these kernels.
+  const int K = p.nch * p.kc, Kp = K + ACV_PAD;            // halfs per weight row in LDS
+  const int Cp = C + ACV_PAD, SP = ACV_TM + taps - 1;      // halfs per pixel in LDS; pixels per slab
   _Float16* wh = (_Float16*)acv_lds;                 // [N][Kp]
   _Float16* wl = wh + (long)N * Kp;                  // [N][Kp]
   _Float16* sh = wl + (long)N * Kp;                  // [nch][SP][Cp]  hi halves of the staged pixels
@@ -404,7 +409,7 @@ static bool try_launch_aas_conv(const F32GemmArgs& p, hipStream_t s, hipError_t*
   if (!p.Wh || !p.Wl || p.lda <= 0 || p.lda % 32 || p.kc % p.lda || p.chunk_stride % p.lda) return false;
   const int C = (int)p.lda, taps = p.kc / C, cpo = (int)(p.chunk_stride / C), K = p.nch * p.kc;
   const int SP = ACV_TM + taps - 1;
-  const long lds = 2L * p.N * (K + 8) * 2 + 2L * p.nch * SP * (C + 8) * 2;
+  const long lds = 2L * p.N * (K + ACV_PAD) * 2 + 2L * p.nch * SP * (C + ACV_PAD) * 2;
   if (lds > 160 * 1024 || (long)p.nch * SP * (C / 4) > 5 * 512 || (long)p.N * (K / 8) > 6 * 512) return false;
   const int ntiles = (int)((p.M + ACV_TM - 1) / ACV_TM);
   static int n_cu_of[kMaxDevices] = {0};
@@ -830,7 +835,8 @@ static void launch_rowlins(const RowlinArgs* q, int n, hipStream_t s) {
 __global__ void readout_kernel(const float* T1, const float* Ta1, const float* S1, const float* m1, const float* ma1,
                                const float* T2, const float* Ta2, const float* S2, const float* Sa2, const float* m2,
                                const float* ma2, int nT, int nS, const float* __restrict__ ow,
-                               const float* __restrict__ ob, float* __restrict__ hidden, float* __restrict__ logits) {
+                               const float* __restrict__ ob, float* __restrict__ hidden, float* __restrict__ logits,
+                               int* __restrict__ nonfinite) {
   __shared__ float hid[160];
   const int b = blockIdx.x, d = threadIdx.x;  // 32 threads
   float tmax = 0.f, tsum = 0.f;
@@ -859,6 +865,7 @@ __global__ void readout_kernel(const float* T1, const float* Ta1, const float* S
     float a = ob[d];
     for (int k = 0; k < 160; ++k) a = fmaf(ow[d * 160 + k], hid[k], a);
     logits[b * 2 + d] = a;
+    if (nonfinite && !(fabsf(a) <= 3.0e38f)) atomicAdd(nonfinite, 1);  // overflow guard (NaN fails the compare too)
   }
 }
 
@@ -1028,7 +1035,7 @@ void aasist_carve(int B, int T, const Alloc& take, AasistWs* ws) {
   } while (0)
 
 const char* aasist_forward(const AasistWeights& w, const float* feats, int B, int T, AasistWs& ws, float* logits,
-                           hipStream_t s) {
+                           hipStream_t s, int* nonfinite) {
   if (!w.ready) return "aasist: weights not finalized";
   int wd, wp, img;
   dims(T, &wd, &wp, &img);
@@ -1206,7 +1213,7 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
   }
   hipLaunchKernelGGL(readout_kernel, dim3(B), dim3(32), 0, s, br[0].T1p, br[0].Ta, br[0].S1p, br[0].m1, br[0].ma,
                      br[1].T1p, br[1].Ta, br[1].S1p, br[1].Sa, br[1].m1, br[1].ma, nT1, nS1, w.out_w, w.out_b,
-                     ws.hidden, logits);
+                     ws.hidden, logits, nonfinite);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typ
 // ---------------------------------------------------------------------------------------
 template <int KS, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void mhsa_split_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int H,
-                                                                 float scale, const int* __restrict__ lens, int out_pairs) {
+                                                                 float scale, const int* __restrict__ lens, int out_pairs, float out_scale) {
   typedef _Float16 Tt;
   typedef f16x8 V8;
   typedef f16x4 V4;
@@ -433,14 +433,14 @@ __global__ __launch_bounds__(64 * NW, 2) void mhsa_split_kernel(const float* __r
     const int q = q0 + ql;
     if (q < T) {
       const long eoff = ((long)b * Trow + q) * (H * 64) + h * 64;
-      if (out_pairs) {  // the output projection's A operand: the pair form of kS3ActScale x value in place of the fp32 row
+      if (out_pairs) {  // the output projection's A operand: the pair form of out_scale x value in place of the fp32 row
         _Float16* hp = (_Float16*)out + 2 * eoff;  // (eoff % 64 == 0: a head's 64 columns are two whole 32-element groups)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           f16x4 hi, lo;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float sv = o[nt][r] * rinv * kS3ActScale;
+            const float sv = o[nt][r] * rinv * out_scale;
             hi[r] = (_Float16)sv;
             lo[r] = (_Float16)(sv - (float)hi[r]);
           }
@@ -673,13 +673,13 @@ const char* launch_mhsa_ring(const void* ring, void* out, int S, int H, int q_ti
 }
 
 // fp32 rows in / out, products in split precision on the fp16 matrix pipe (the engine's "fp16x3"); T <= 224
-const char* launch_mhsa_split(const float* qkv, float* out, int B, int T, int H, hipStream_t s, const int* lens, bool out_pairs) {
+const char* launch_mhsa_split(const float* qkv, float* out, int B, int T, int H, hipStream_t s, const int* lens, bool out_pairs, float out_scale) {
   if (T <= 0 || T > ATT_KEYS || B <= 0 || B > 65535 || H <= 0) return "mhsa_split: 1..224 frames";
   const float scale = 0.125f;
   dim3 grid(H, B, (long)H * B < 256 && T > 64 ? 2 : 1);
-  if (T <= 64) hipLaunchKernelGGL((mhsa_split_kernel<2, 4>), grid, dim3(256), 0, s, qkv, out, T, H, scale, lens, out_pairs ? 1 : 0);
-  else if (T <= 128) hipLaunchKernelGGL((mhsa_split_kernel<4, 4>), grid, dim3(256), 0, s, qkv, out, T, H, scale, lens, out_pairs ? 1 : 0);
-  else hipLaunchKernelGGL((mhsa_split_kernel<7, 7>), grid, dim3(448), 0, s, qkv, out, T, H, scale, lens, out_pairs ? 1 : 0);
+  if (T <= 64) hipLaunchKernelGGL((mhsa_split_kernel<2, 4>), grid, dim3(256), 0, s, qkv, out, T, H, scale, lens, out_pairs ? 1 : 0, out_scale);
+  else if (T <= 128) hipLaunchKernelGGL((mhsa_split_kernel<4, 4>), grid, dim3(256), 0, s, qkv, out, T, H, scale, lens, out_pairs ? 1 : 0, out_scale);
+  else hipLaunchKernelGGL((mhsa_split_kernel<7, 7>), grid, dim3(448), 0, s, qkv, out, T, H, scale, lens, out_pairs ? 1 : 0, out_scale);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

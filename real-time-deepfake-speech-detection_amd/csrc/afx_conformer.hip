@@ -746,7 +746,7 @@ const char* launch_conf_dwconv(const float* x, long ldx, const float* w, const f
 // ---------------------------------------------------------------------------------
 __global__ void small_linear_kernel(const float* __restrict__ x, long row_stride, int rows, int K,
                                     const float* __restrict__ w, const float* __restrict__ b, int N,
-                                    float* __restrict__ out) {
+                                    float* __restrict__ out, int* __restrict__ nonfinite) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -755,13 +755,17 @@ __global__ void small_linear_kernel(const float* __restrict__ x, long row_stride
     float a = 0.f;
     for (int kk = lane; kk < K; kk += 64) a = fmaf(xr[kk], w[(long)n * K + kk], a);
     a = wave_sum(a);
-    if (lane == 0) out[(long)r * N + n] = a + (b ? b[n] : 0.f);
+    if (lane == 0) {
+      a += b ? b[n] : 0.f;
+      out[(long)r * N + n] = a;
+      if (nonfinite && !(fabsf(a) <= 3.0e38f)) atomicAdd(nonfinite, 1);  // (NaN fails the compare too)
+    }
   }
 }
 const char* launch_small_linear(const float* x, long row_stride, int rows, int K, const float* w, const float* b,
-                                int N, float* out, hipStream_t s) {
+                                int N, float* out, hipStream_t s, int* nonfinite) {
   hipLaunchKernelGGL(small_linear_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, row_stride, rows, K, w, b, N,
-                     out);
+                     out, nonfinite);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -117,6 +117,9 @@ struct afx_engine {
   int fuse_conv_ln = 1;     // conv layers 1-6: LayerNorm + GELU in the GEMM epilogue (0: two kernels)
   int gemm_small_deep = 1;  // products with at most two 128x64 tiles per CU: the deep form of that tile (0: the two-buffer form)
   std::unordered_map<std::string, TapRec> taps;
+  // overflow guard: device counters [0] rows of the trunk's final LayerNorm with non-finite statistics, [1] non-finite logits
+  // (written by those kernels of every forward, read and cleared by afx_check_finite)
+  int* nonfinite = nullptr;
 
   // trunk, packed operand-type weights
   void* convw[7] = {nullptr};
@@ -186,6 +189,7 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
   e->w2.assign(nl, nullptr);
   e->bqkv.assign(nl, nullptr);
   bool ok = true;
+  ok &= (e->nonfinite = (int*)e->dalloc(16)) != nullptr && hipMemset(e->nonfinite, 0, 16) == hipSuccess;
   if (!head_only) {
     for (int i = 1; i < 7; ++i) ok &= (e->convw[i] = e->walloc(kC, (size_t)kC * kConvK[i])) != nullptr;
     ok &= (e->projw = e->walloc(kD, kC)) != nullptr;
@@ -254,6 +258,28 @@ extern "C" void afx_destroy(afx_handle h) {
 extern "C" int afx_enable_taps(afx_handle h, int on) {
   if (!h) return fail("afx_enable_taps: null handle");
   h->taps_on = on != 0;
+  return 0;
+}
+
+// Overflow guard.  The half-precision modes keep operand COPIES in fp16 / bf16 (LayerNorm outputs, q | k | v rows, attention
+// output, the GELU'd FFN hidden, conv-stack activations; split precision: fp16 hi / lo pairs of scale x the value).  A
+// trained checkpoint with outlier channels can push one of them past the format's range (fp16: 65 504; fp16x3: 65 504 /
+// its activation scale: kS3ScaleFree = 1 for unbounded operands); the inf then turns every later row statistic into NaN.  Rather than hand back NaN -- or, behind the AASIST
+// head's max-pooling and top-k, finite garbage -- scores, the trunk's final LayerNorm and the kernels that write the logits
+// count what is not finite (no cost: one compare per row / logit), and this call turns a non-zero count into an error:
+// it waits for `stream`, reads and clears the counters.  Scoring loops call it once, before they write a score.
+extern "C" int afx_check_finite(afx_handle h, void* stream) {
+  if (!h) return fail("afx_check_finite: null handle");
+  int c[2] = {0, 0};
+  hipStream_t s = (hipStream_t)stream;
+  HIP_OK(hipMemcpyAsync(c, h->nonfinite, 8, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  if (c[0] || c[1]) {
+    HIP_OK(hipMemsetAsync(h->nonfinite, 0, 8, s));
+    return fail("non-finite values since the last check: %d feature rows of the trunk's final LayerNorm, %d logits -- an operand copy left the "
+                "range of this engine's precision (%s); the scores of these batches are invalid.  Use dtype \"fp32\" (exact mode) for this checkpoint",
+                c[0], c[1], h->s3 ? "fp16x3: fp16 hi / lo pairs" : (h->dt == AFX_DT_FP16 ? "fp16 operands: |x| <= 65504" : (h->dt == AFX_DT_BF16 ? "bf16 operands" : "fp32")));
+  }
   return 0;
 }
 
@@ -740,28 +766,29 @@ static thread_local size_t t_s3bytes = 0;
 // the GELU / LayerNorm epilogues of the products and the attention write the operand themselves and the separate split launch
 // disappears.  t_s3ok: the buffers of this forward that qualify; t_s3reg: which of them currently hold pair-form rows.
 constexpr int kS3Bufs = 10;
+struct S3Reg { const void* p; float scale; };  // scale: the power of two the rows were multiplied by before the split (0: fp32 values)
 static thread_local const void* t_s3ok[kS3Bufs] = {nullptr};
-static thread_local const void* t_s3reg[kS3Bufs] = {nullptr};
+static thread_local S3Reg t_s3reg[kS3Bufs] = {};
 static void s3_begin(std::initializer_list<const void*> ok) {
   int i = 0;
   for (const void* p : ok)
     if (p && i < kS3Bufs) t_s3ok[i++] = p;
   for (; i < kS3Bufs; ++i) t_s3ok[i] = nullptr;
-  for (const void*& r : t_s3reg) r = nullptr;
+  for (S3Reg& r : t_s3reg) r = S3Reg{nullptr, 0.f};
 }
 static bool s3_ok(const void* p) {
   if (!p || !t_s3planes) return false;
   for (const void* q : t_s3ok) if (q == p) return true;
   return false;
 }
-static void s3_set(const void* p, bool pairs) {  // false: the buffer holds fp32 values again
-  for (const void*& r : t_s3reg) if (r == p) { if (!pairs) r = nullptr; return; }
-  if (!pairs) return;
-  for (const void*& r : t_s3reg) if (!r) { r = p; return; }
+static void s3_set(const void* p, float scale) {  // 0: the buffer holds fp32 values again
+  for (S3Reg& r : t_s3reg) if (r.p == p) { r.scale = scale; if (scale == 0.f) r.p = nullptr; return; }
+  if (scale == 0.f) return;
+  for (S3Reg& r : t_s3reg) if (!r.p) { r = S3Reg{p, scale}; return; }
 }
-static bool s3_pairs_in(const void* p) {
-  for (const void* r : t_s3reg) if (r && r == p) return true;
-  return false;
+static float s3_pairs_in(const void* p) {  // the scale of the pair-form rows `p` holds, 0 when it holds fp32 values
+  for (const S3Reg& r : t_s3reg) if (r.p && r.p == p) return r.scale;
+  return 0.f;
 }
 // per-call context of the forward running on this thread: the engine's profiler, its A/B switches, and (split precision) the
 // pair-form scratch of the workspace plus the buffers whose producers may write pair-form rows in place
@@ -803,18 +830,20 @@ static const char* P_gemm(const GemmArgs& g_in, int dt, int groups, hipStream_t 
   };
   if (dt == DT_FP32 && t_s3planes) {
     const bool groups32 = !(g.K % 32 || g.kchunk % 32 || g.a_row % 32 || g.a_batch % 32 || g.g_a % 32 || g.kchunk_stride % 32 || g.ldw % 32 || g.g_w % 32);
-    if (!groups32 || ((size_t)g.A & 127)) {  // (rows the pair form cannot address in whole 32-element groups: the fp32 instruction)
-      if (g.out_h) s3_set(g.out_h, false);
+    if (!groups32 || ((size_t)g.A & 15)) {  // (rows the pair form cannot address in whole 32-element groups: the fp32 instruction)
+      if (g.out_h) s3_set(g.out_h, 0.f);
       return launch_gemm(g, DT_FP32, groups, s);
     }
     GemmArgs q = g;
-    if (!s3_pairs_in(g.A)) {  // convert the span of A this product addresses (fp32 elements from g.A on) into the scratch
+    float a_scale = s3_pairs_in(g.A);
+    if (a_scale == 0.f) {  // convert the span of A this product addresses (fp32 elements from g.A on) into the scratch
       const long last = g.M - 1;
       long span = (last / g.rpb) * g.a_batch + (last % g.rpb) * g.a_row + (long)(g.K / g.kchunk - 1) * g.kchunk_stride + g.kchunk +
                   (long)(groups - 1) * g.g_a;
       span = (span + 31) & ~31L;
       if ((size_t)span * 4 > t_s3bytes) return "split-precision product: the A operand exceeds the pair-form scratch";
-      if (const char* m = timed(PC_MISC, 0, s, [&] { return launch_split_pairs((const float*)g.A, span, t_s3planes, s); })) return m;
+      a_scale = kS3ScaleFree;
+      if (const char* m = timed(PC_MISC, 0, s, [&] { return launch_split_pairs((const float*)g.A, span, t_s3planes, a_scale, s); })) return m;
       q.A = t_s3planes;
     }
     // every K-side length counts halfs of the pair form: twice the fp32-element value
@@ -829,12 +858,15 @@ static const char* P_gemm(const GemmArgs& g_in, int dt, int groups, hipStream_t 
     q.ldw = 2 * g.ldw;
     q.g_w = 2 * g.g_w;
     q.pre_scale = (const float*)((const char*)g.W + (size_t)groups * g.N * g.ldw * 4);  // afx_engine::wscale
-    // the result as the NEXT product's A operand, where only products read the buffer (pair-form rows in place of fp32 rows)
+    q.a_inv = 1.0f / a_scale;
+    // the result as the NEXT product's A operand, where only products read the buffer (pair-form rows in place of fp32 rows);
+    // a LayerNorm epilogue bounds its output (the larger scale), anything else is unbounded in a trained checkpoint
     if (g.out_h) {
       const bool pairs_out = s3_ok(g.out_h) && (g.N & 7) == 0 && (g.g_n & 7) == 0 && (g.ldo_h & 31) == 0 &&
                              (g.act == ACT_NONE || g.act == ACT_GELU) && g.out_h != g.A;
       q.oh_pairs = pairs_out ? 1 : 0;
-      s3_set(g.out_h, pairs_out);
+      q.oh_scale = g.ln_gamma ? kS3ScaleBounded : kS3ScaleFree;
+      s3_set(g.out_h, pairs_out ? q.oh_scale : 0.f);
     }
     const int tile = gemm_tile_of(q, groups);
     return timed(cls_of(tile), fl, s, [&] { return launch_gemm(q, DT_FP16X3, groups, s); });
@@ -846,7 +878,8 @@ static const char* P_rownorm(const RowNormArgs& a_in, int dt, hipStream_t s) {
   if (a.out_h && t_s3planes) {  // split precision: the LayerNorm writes the next product's A operand (pair-form rows) itself
     const bool pairs_out = dt == DT_FP32 && s3_ok(a.out_h) && (a.ldo_h & 31) == 0 && a.out_h != (const void*)a.x;
     a.oh_pairs = pairs_out ? 1 : 0;
-    s3_set(a.out_h, pairs_out);
+    a.oh_scale = kS3ScaleBounded;  // |LayerNorm output| <= sqrt(C) |gamma| + |beta|
+    s3_set(a.out_h, pairs_out ? a.oh_scale : 0.f);
   }
   return timed(PC_ROWNORM, 0, s, [&] { return launch_rownorm(a, dt, s); });
 }
@@ -952,7 +985,10 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
         g.out_f = w.tmp32; g.ldo_f = kC;
       }
       KOK(launch_gemm(g, dt, 1, s));
-    } else if (e->fuse_conv_ln && (dt != DT_FP32 || e->s3)) {  // (split precision: the same tile with the pair-form walk)
+    } else if (e->fuse_conv_ln && dt != DT_FP32) {
+      // (split precision takes the two-kernel form below: measured, the row-complete tile with the pair-form walk and the fp32
+      // erf-GELU in its epilogue is SLOWER than the 256-wide tile + a LayerNorm pass that writes the next layer's pair-form
+      // operand -- student 12.9 against 12.3 ms per forward, teacher 9.0 / 8.75: profiles/r04_s3_knobs.txt)
       g.ln_gamma = cf(i, ".2.1.weight"); g.ln_beta = cf(i, ".2.1.bias"); g.ln_eps = kLnEps;
       if (i < 6) {
         g.out_h = out; g.ldo_h = kC;
@@ -1034,10 +1070,10 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
     KOK(timed(PC_MHSA, 4.0 * B * kH * (double)Tt * Tt * 64, s, [&] {
       if (e->s3 && Tt <= 224) {  // split precision: the matrix-core form; its output goes out as the output projection's A planes
         const bool pairs = s3_ok(w.att);
-        s3_set(w.att, pairs);
-        return launch_mhsa_split((const float*)w.qkv, (float*)w.att, B, Tt, kH, s, w.lens, pairs);
+        s3_set(w.att, pairs ? kS3ScaleFree : 0.f);
+        return launch_mhsa_split((const float*)w.qkv, (float*)w.att, B, Tt, kH, s, w.lens, pairs, kS3ScaleFree);
       }
-      if (e->s3) s3_set(w.att, false);
+      if (e->s3) s3_set(w.att, 0.f);
       return launch_mhsa(w.qkv, w.att, B, Tt, kH, dt, s, w.lens);
     }));
     KOK(resid_product(w.att, kD, e->wo[l], kD, e->F(P + "self_attn.out_proj.bias")));
@@ -1058,6 +1094,7 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
   RowNormArgs nf = plain_norm(w.x, kD, M, kD, e->F("ssl.encoder.layer_norm.weight"), e->F("ssl.encoder.layer_norm.bias"));
   nf.out_f = w.ssl_f; nf.ldo_f = kD;
   nf.out_h = w.ssl_h; nf.ldo_h = kD;
+  nf.nonfinite = e->nonfinite;  // overflow guard: an operand copy that left fp16's range anywhere in the trunk ends here as inf / NaN
   KOK(launch_rownorm(nf, dt, s));
   if (tap(e, "ssl", w.ssl_f, (size_t)M * kD, false, s)) return 1;
   return 0;
@@ -1204,7 +1241,7 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
   }
   KOK(timed(PC_MISC, 0, s, [&] {
     return launch_small_linear(w.xc, (long)N * E, B, E, e->F("conformer.fc5.weight"), e->F("conformer.fc5.bias"), 2,
-                               logits, s);
+                               logits, s, e->nonfinite + 1);
   }));
   if (embedding)  // x[:, 0, :] (models/conformer_baseline.py:27)
     HIP_OK(hipMemcpy2DAsync(embedding, (size_t)E * 4, w.xc, (size_t)N * E * 4, (size_t)E * 4, B, hipMemcpyDeviceToDevice, s));
@@ -1214,7 +1251,7 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
 static int run_head(afx_engine* e, int B, int T, Ws& w, float* logits, hipStream_t s) {
   if (e->cfg.arch == AFX_ARCH_CONFORMER) return run_conformer(e, B, T, w, logits, s);
   if (e->cfg.arch == AFX_ARCH_XLSR_AASIST) {
-    if (const char* m = timed(PC_AASIST, 2.0 * B * 1.399e9 / 2, s, [&] { return aasist_forward(e->aw, w.ssl_f, B, T, w.aa, logits, s); }))
+    if (const char* m = timed(PC_AASIST, 2.0 * B * 1.399e9 / 2, s, [&] { return aasist_forward(e->aw, w.ssl_f, B, T, w.aa, logits, s, e->nonfinite + 1); }))
       return fail("%s", m);
     if (e->taps_on) {
       if (tap(e, "e_S", w.aa.eS, (size_t)B * 42 * 64, false, s)) return 1;
@@ -1394,6 +1431,7 @@ extern "C" int afx_kv_step(afx_kv* k, const float* feats6, int n, float* logits,
   {
     RowNormArgs nf = plain_norm(w.x, kD, M, kD, e->F("ssl.encoder.layer_norm.weight"), e->F("ssl.encoder.layer_norm.bias"));
     nf.out_f = nxt; nf.ldo_f = kD; nf.rpb = n; nf.o_batch_rows = kKvFeat; nf.o_row_off = kKvFeat - n;
+    nf.nonfinite = e->nonfinite;
     KOK(launch_rownorm(nf, dt, s));
   }
   k->pp ^= 1;
@@ -1542,7 +1580,7 @@ extern "C" int afx_forward_ragged(afx_handle h, const float* wave, int B, int Lm
     for (int k = 0; k < nb; ++k)
       HIP_OK(hipMemcpyAsync(w.bucket_f + (size_t)k * t * kD, w.ssl_f + (size_t)idx[k] * Tmax * kD, (size_t)t * kD * 4,
                             hipMemcpyDeviceToDevice, s));
-    if (const char* m = aasist_forward(h->aw, w.bucket_f, nb, t, w.aa, w.bucket_logits, s)) return fail("%s", m);
+    if (const char* m = aasist_forward(h->aw, w.bucket_f, nb, t, w.aa, w.bucket_logits, s, h->nonfinite + 1)) return fail("%s", m);
     for (int k = 0; k < nb; ++k)
       HIP_OK(hipMemcpyAsync(logits + (size_t)idx[k] * 2, w.bucket_logits + (size_t)k * 2, 8, hipMemcpyDeviceToDevice, s));
   }
@@ -1665,7 +1703,7 @@ extern "C" int afx_k_gemm(int dtype, const void* A, long lda, const void* W, lon
     // (weight rows [hi | lo] + row scales, built once per checkpoint; the A planes, built per product in the workspace)
     // are built per call in temporary device memory, and the call synchronises the stream before it frees them.
     hipStream_t s = (hipStream_t)stream;
-    if (K % 32 || lda != K || ldw != K || ((size_t)A & 127)) return fail("afx_k_gemm(fp16x3): contiguous 128-byte aligned rows, K %% 32 == 0");
+    if (K % 32 || lda != K || ldw != K || ((size_t)A & 15)) return fail("afx_k_gemm(fp16x3): contiguous 16-byte aligned rows, K %% 32 == 0");
     void *wp = nullptr, *planes = nullptr;
     const long span = ((long)M * K + 31) & ~31L;
     if (hipMalloc(&wp, (size_t)N * K * 4 + (size_t)N * 4) != hipSuccess || hipMalloc(&planes, (size_t)span * 4) != hipSuccess) {
@@ -1675,9 +1713,9 @@ extern "C" int afx_k_gemm(int dtype, const void* A, long lda, const void* W, lon
     float* sc = (float*)((char*)wp + (size_t)N * K * 4);
     const char* m = launch_pack_linear((const float*)W, N, K, K, wp, DT_FP32, s);
     if (!m) m = launch_split_weight_rows(wp, N, K, sc, s);
-    if (!m) m = launch_split_pairs((const float*)A, span, planes, s);
+    if (!m) m = launch_split_pairs((const float*)A, span, planes, kS3ScaleFree, s);
     if (!m) {
-      g.A = planes; g.W = wp; g.k1 = K; g.K = 2 * K; g.kchunk = 2 * K; g.a_row = 2L * K; g.ldw = 2L * K; g.pre_scale = sc;
+      g.A = planes; g.W = wp; g.k1 = K; g.K = 2 * K; g.kchunk = 2 * K; g.a_row = 2L * K; g.ldw = 2L * K; g.pre_scale = sc; g.a_inv = 1.0f / kS3ScaleFree;
       m = launch_gemm(g, DT_FP16X3, 1, s);
     }
     (void)hipStreamSynchronize(s);

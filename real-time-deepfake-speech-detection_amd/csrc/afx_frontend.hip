@@ -644,7 +644,10 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
         }
       }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv + a.eps);
+    const float var = wave_sum(sq) * inv;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    // overflow guard: an operand copy that left fp16's range upstream arrives here as inf / NaN statistics (NaN fails every compare)
+    if (a.nonfinite && lane == 0 && !(fabsf(mean) <= 3.0e38f && var <= 3.0e38f)) atomicAdd(a.nonfinite, 1);
     const long orow = (r / a.rpb) * a.o_batch_rows + (r % a.rpb) + a.o_row_off;
     // the activation branch sits OUTSIDE the element loops: inlined per element, the three activations were
     // 3 k of this kernel's 3.8 k instructions (every LayerNorm of the two models is activation-free)
@@ -666,7 +669,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
               f16x4 hi, lo;
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                const float sv = y[i] * kS3ActScale;
+                const float sv = y[i] * a.oh_scale;
                 hi[i] = (_Float16)sv;
                 lo[i] = (_Float16)(sv - (float)hi[i]);
               }
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(256) void split_weight_rows_kernel(float* w, int K,
     out[o] = h;
     out[o + 32] = (_Float16)(v - (float)h);
   }
-  if (threadIdx.x == 0) row_scale[blockIdx.x] = ldexpf(1.0f, -e) / kS3ActScale;
+  if (threadIdx.x == 0) row_scale[blockIdx.x] = ldexpf(1.0f, -e);
 }
 const char* launch_split_weight_rows(void* w, int N, int K, float* row_scale, hipStream_t s) {
   if (K > 12288 || K % 32) return "split_weight_rows: rows of at most 12288 elements, whole 32-element groups";
@@ -851,14 +854,14 @@ const char* launch_split_weight_rows(void* w, int N, int K, float* row_scale, hi
 }
 
 // fp32 values -> their pair form: a thread turns 8 consecutive values (inside one 32-element group) into 16 B of hi and 16 B of lo halves
-__global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restrict__ x, long n8, _Float16* __restrict__ out) {
+__global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restrict__ x, long n8, _Float16* __restrict__ out, float scale) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
     const long o = i * 8;
     const f32x4 a = *(const f32x4*)(x + o), b = *(const f32x4*)(x + o + 4);
     f16x8 h, l;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float va = a[r] * kS3ActScale, vb = b[r] * kS3ActScale;
+      const float va = a[r] * scale, vb = b[r] * scale;
       h[r] = (_Float16)va;
       h[4 + r] = (_Float16)vb;
       l[r] = (_Float16)(va - (float)h[r]);
@@ -869,12 +872,12 @@ __global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restric
     *(f16x8*)(hp + 32) = l;
   }
 }
-const char* launch_split_pairs(const float* x, long n, void* pairs, hipStream_t s) {
+const char* launch_split_pairs(const float* x, long n, void* pairs, float scale, hipStream_t s) {
   if (n <= 0) return nullptr;
-  if (((size_t)x & 127) || ((size_t)pairs & 127) || (n & 31)) return "split_pairs: whole, 128-byte aligned groups of 32 elements";
+  if (((size_t)x & 15) || ((size_t)pairs & 15) || (n & 31)) return "split_pairs: whole groups of 32 elements, 16-byte aligned";
   const long n8 = n / 8;
   const int blocks = (int)min((long)8192, (n8 + 255) / 256);
-  hipLaunchKernelGGL(split_pairs_kernel, dim3(blocks), dim3(256), 0, s, x, n8, (_Float16*)pairs);
+  hipLaunchKernelGGL(split_pairs_kernel, dim3(blocks), dim3(256), 0, s, x, n8, (_Float16*)pairs, scale);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

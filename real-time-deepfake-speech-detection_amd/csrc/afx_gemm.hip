@@ -42,12 +42,12 @@ namespace afx {
 // / LayerNorm -> wide stores.
 // ---------------------------------------------------------------------------------------
 // split precision: 8 consecutive results (columns n .. n+7, n % 8 == 0: inside one 32-element group) as the next product's
-// A operand -- the pair form of kS3ActScale x value in place of the fp32 row (GemmArgs::oh_pairs)
-__device__ __forceinline__ void store_pairs8(void* out_h, long hrow, long ldo_h, long col, const f32x4& va, const f32x4& vb) {
+// A operand -- the pair form of scale x value in place of the fp32 row (GemmArgs::oh_pairs, oh_scale)
+__device__ __forceinline__ void store_pairs8(void* out_h, long hrow, long ldo_h, long col, const f32x4& va, const f32x4& vb, float scale) {
   f16x8 hi, lo;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float sa = va[r] * kS3ActScale, sb = vb[r] * kS3ActScale;
+    const float sa = va[r] * scale, sb = vb[r] * scale;
     hi[r] = (_Float16)sa;
     hi[4 + r] = (_Float16)sb;
     lo[r] = (_Float16)(sa - (float)hi[r]);
@@ -86,7 +86,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       vec[t] = p.bias[n0 + t];
       vec[BN + t] = p.ln_gamma[n0 + t];
       vec[2 * BN + t] = p.ln_beta[n0 + t];
-      if constexpr (S3) vec[3 * BN + t] = p.pre_scale[n0 + t];
+      if constexpr (S3) vec[3 * BN + t] = p.pre_scale[n0 + t] * p.a_inv;
     }
     __syncthreads();
     const int kq = lane >> 4;
@@ -200,7 +200,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         if (p.out_h) {
           if constexpr (S3) {
             if (p.oh_pairs) {
-              store_pairs8(p.out_h, hrow, p.ldo_h, n, va, vb);
+              store_pairs8(p.out_h, hrow, p.ldo_h, n, va, vb, p.oh_scale);
             } else {
               float* op = (float*)p.out_h + hrow * p.ldo_h + n;
               *(f32x4*)op = va;
@@ -247,8 +247,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       }
       if constexpr (S3) {
         rsc[jp][0] = rsc[jp][1] = f32x4{1.f, 1.f, 1.f, 1.f};
-        if (na < p.N) rsc[jp][0] = *(const f32x4*)(p.pre_scale + gcol + na);
-        if (nbb < p.N) rsc[jp][1] = *(const f32x4*)(p.pre_scale + gcol + nbb);
+        if (na < p.N) rsc[jp][0] = *(const f32x4*)(p.pre_scale + gcol + na) * p.a_inv;
+        if (nbb < p.N) rsc[jp][1] = *(const f32x4*)(p.pre_scale + gcol + nbb) * p.a_inv;
       }
     }
     constexpr int STEPS = MT * (NT / 2);
@@ -339,7 +339,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         if (p.out_h) {
           if constexpr (S3) {
             if (p.oh_pairs) {  // the next product's A operand, in pair form
-              store_pairs8(p.out_h, hrow, p.ldo_h, gcol + n, va, vb);
+              store_pairs8(p.out_h, hrow, p.ldo_h, gcol + n, va, vb, p.oh_scale);
             } else {
               float* op = (float*)p.out_h + hrow * p.ldo_h + gcol + n;
               *(f32x4*)op = va;
@@ -386,7 +386,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       const int n = n0 + wc * WN + j * 16 + 4 * kq;
       if (n >= p.N) continue;
       f32x4 v = acc[i][j];
-      if constexpr (S3) v *= *(const f32x4*)(p.pre_scale + gcol + n);
+      if constexpr (S3) v *= *(const f32x4*)(p.pre_scale + gcol + n) * p.a_inv;
       if (p.bias) v += *(const f32x4*)(p.bias + gcol + n);
       if (p.act != ACT_NONE && !(AFX_DBG(p, 8))) {
 #pragma unroll
@@ -1342,8 +1342,9 @@ static const char* check_gemm(const GemmArgs& p, int groups) {
   if (p.oh_pairs && (!p.k1 || (p.N & 7) || (p.g_n & 7) || (p.act != ACT_NONE && p.act != ACT_GELU) || (p.ldo_h & 31) || !p.out_h))
     return "gemm: pair-form output goes with the lean split-precision epilogue (N % 8 == 0, no / GELU activation, row stride % 32 == 0)";
   if (p.k1) {
-    if (p.k1 % 32 || p.K != 2 * p.k1 || !p.pre_scale) return "gemm: split precision needs pair-form operands (K = 2 k1 halfs, k1 % 32 == 0) and the column scales";
-    if (((size_t)p.A & 127) || ((size_t)p.W & 127) || (p.a_row & 63) || (p.a_batch & 63) || (p.g_a & 63) || (p.ldw & 63) || (p.g_w & 63) || (p.kchunk_stride & 63))
+    if (p.k1 % 32 || p.K != 2 * p.k1 || !p.pre_scale || !(p.a_inv > 0.f) || (p.oh_pairs && !(p.oh_scale > 0.f)))
+      return "gemm: split precision needs pair-form operands (K = 2 k1 halfs, k1 % 32 == 0), the column scales and the operand scales";
+    if (((size_t)p.A & 15) || ((size_t)p.W & 15) || (p.a_row & 63) || (p.a_batch & 63) || (p.g_a & 63) || (p.ldw & 63) || (p.g_w & 63) || (p.kchunk_stride & 63))
       return "gemm: split precision: pair-form rows start on whole 32-element groups";
   }
   if (p.ln_gamma) {

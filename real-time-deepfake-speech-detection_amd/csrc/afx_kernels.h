@@ -11,10 +11,16 @@ namespace afx {
 // runs on the fp16 matrix pipe as x.w ~ xh.wh + xl.wh + xh.wl with fp16 hi / lo pairs of both operands (GemmArgs::k1)
 enum DType { DT_BF16 = 0, DT_FP16 = 1, DT_FP32 = 2, DT_FP16X3 = 3 };
 inline size_t dtype_size(int dt) { return dt == DT_FP32 || dt == DT_FP16X3 ? 4 : 2; }
-#ifndef AFX_S3_ACT_SCALE
-#define AFX_S3_ACT_SCALE 16.f
-#endif
-constexpr float kS3ActScale = AFX_S3_ACT_SCALE;  // split-precision A operands are scaled by this power of two before the hi / lo split (the -D hook exists for A/B builds: make variant)
+// Split-precision A operands are scaled by a power of two before the hi / lo split, per operand KIND (the product divides it
+// out again: GemmArgs::a_inv).  The matrix instruction keeps fp16 subnormals (tools/denorm_probe.hip), so the scale only
+// decides where the lo half of a small entry stops being exact to 2^-22 relative and becomes exact to 2^-25 / scale absolute:
+//   * LayerNorm outputs are bounded by sqrt(C) |gamma| + |beta| -- x 16 (|y| < 4094; entries above 0.008 fully precise);
+//   * everything else (GELU'd FFN hidden, attention output, projections, a caller's features) is unbounded in a trained
+//     checkpoint -- x 1: the same range as the fp16 mode (65 504), entries above 0.125 fully precise.
+// Measured on the 48-utterance teacher gate: all x 16: features 1.1e-6 / logits 1.4e-6; all x 1: 4.4e-6 / 2.8e-6
+// (profiles/r04_s3_scale_ab.txt); no GraphPool decision moves either way.
+constexpr float kS3ScaleBounded = 16.f;
+constexpr float kS3ScaleFree = 1.f;
 // PAIR FORM (round 4): the hi / lo halves of a split-precision operand are interleaved in groups of 32 elements -- element k
 // of a row lives at half (k / 32) * 64 + k % 32 (hi) and 32 halfs further (lo) -- so a row of K values is 2 K consecutive
 // halfs in the bytes its fp32 form would take (row-local: any row stride that is a multiple of 32 elements works), and one
@@ -64,14 +70,17 @@ struct GemmArgs {
   // k1 = the algorithmic K; A and W are in PAIR FORM (above) and every length / stride on the K side of this struct counts
   // HALFS of it: K = 2 k1, a_row / a_batch / g_a / kchunk / kchunk_stride / ldw / g_w are twice their fp32-element values.
   // Per 64-half K-tile (32 k values: hi | lo) a tile kernel issues w_lo.a_hi + w_hi.a_lo + w_hi.a_hi.  The epilogue
-  // multiplies the accumulator of column n by pre_scale[n] (the inverse of the row's power-of-two weight scale x the
-  // activation scale) before the bias, and writes `out_h` as FP32 (the engine's operand buffers are fp32 in that mode).
+  // multiplies the accumulator of column n by pre_scale[n] x a_inv (the inverse of the row's power-of-two weight scale x
+  // the inverse of the A operand's activation scale) before the bias, and writes `out_h` as FP32 (the engine's operand
+  // buffers are fp32 in that mode).
   int k1;
   const float* pre_scale;
+  float a_inv;
   // split precision, output side: oh_pairs != 0 = `out_h` receives the result AS the next product's A operand -- the pair
-  // form of kS3ActScale x value, row by row in place of the fp32 row (ldo_h % 32 == 0) -- instead of fp32 (the producer
+  // form of oh_scale x value, row by row in place of the fp32 row (ldo_h % 32 == 0) -- instead of fp32 (the producer
   // writes the operand, no separate split launch: launch_split_pairs)
   int oh_pairs;
+  float oh_scale;
   int dbg_nodma;  // attribution build (-DAFX_ATTR) only, ignored otherwise: epilogue bits 8 no activation, 16 narrow stores, 32 no stores, 64 no epilogue
 };
 const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s);
@@ -130,7 +139,9 @@ struct RowNormArgs {
   void* out_h;
   long ldo_h;
   int rpb, o_batch_rows, o_row_off;
-  int oh_pairs;  // split precision (with DT_FP32): != 0 = out_h receives the PAIR FORM of kS3ActScale x y in place of the fp32 row (ldo_h % 32 == 0)
+  int* nonfinite;  // device counter or null: += 1 for every row whose statistics are not finite (the engine's overflow guard on the trunk's final LayerNorm)
+  int oh_pairs;  // split precision (with DT_FP32): != 0 = out_h receives the PAIR FORM of oh_scale x y in place of the fp32 row (ldo_h % 32 == 0)
+  float oh_scale;
 };
 const char* launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s);
 // zero the time padding rows of the positional-conv operand buffer (B, T+128, C)
@@ -144,11 +155,11 @@ const char* launch_pack_posconv(const float* v, const float* g, int C, int cpg, 
                                 void* out_h, int dtype, hipStream_t s);
 // Split precision (DT_FP16X3).  Weights: a matrix packed as fp32 rows [N][K] (the pack launchers above with DT_FP32) is
 // rewritten IN PLACE as the pair form of w * 2^s_n, s_n the power of two that brings the row's largest magnitude
-// to [8192, 16384); row_scale[n] = 1 / (2^s_n * kS3ActScale).  K <= 12288, K % 32 == 0.
+// to [8192, 16384); row_scale[n] = 2^-s_n.  K <= 12288, K % 32 == 0.
 const char* launch_split_weight_rows(void* w_f32_inplace, int N, int K, float* row_scale, hipStream_t s);
-// Activations: n fp32 values (n % 32 == 0, x 128-byte aligned: whole 32-element groups) -> the pair form of x * kS3ActScale
-// at `pairs` (2 n halfs; x itself when the operand may be rewritten in place is NOT supported: distinct buffers)
-const char* launch_split_pairs(const float* x, long n, void* pairs, hipStream_t s);
+// Activations: n fp32 values (n % 32 == 0: whole 32-element groups; 16-byte aligned) -> the pair form of x * scale
+// at `pairs` (2 n halfs; distinct buffers)
+const char* launch_split_pairs(const float* x, long n, void* pairs, float scale, hipStream_t s);
 
 // ---- positional conv of the encoder as a sliding-window kernel (afx_posconv.hip) ---------------
 // x (B*T, 1024) fp32 += GELU(grouped conv over the time-padded operand copy xpad (B, T+128, 1024)); T <= 224
@@ -169,9 +180,9 @@ const char* launch_mhsa(const void* qkv, void* out, int B, int T, int H, int dty
 void mhsa_set_vtr(int v);  // A/B knob: V row-major in LDS + ds_read_b64_tr_b16 (0 = the V^T image)
 
 // the same attention with fp32 rows in / out and split-precision products on the fp16 matrix pipe (dtype "fp16x3"); T <= 224
-// out_pairs: `out` receives the pair form of kS3ActScale x the result (row by row, in place of the fp32 rows) instead of fp32 rows
+// out_pairs: `out` receives the pair form of out_scale x the result (row by row, in place of the fp32 rows) instead of fp32 rows
 const char* launch_mhsa_split(const float* qkv, float* out, int B, int T, int H, hipStream_t s, const int* lens = nullptr,
-                              bool out_pairs = false);
+                              bool out_pairs = false, float out_scale = 1.f);
 // KV-cached streaming attention (afx_kv_step; not a reference function): ring (S, 256, 3*H*64) rows [q | k | v] in 16-slot
 // groups, cnt[16] valid frames per group, the queries are group q_tile's slots; out (S, 16, H*64)
 const char* launch_mhsa_ring(const void* ring, void* out, int S, int H, int q_tile, const int* cnt, int dtype, hipStream_t s);
@@ -221,7 +232,8 @@ struct ConfChainArgs {
 };
 const char* launch_conf_chain(const ConfChainArgs& p, int stage, int dtype, hipStream_t s);
 // logits = fc5(token0):  x (B*N, E) fp32 rows, token row = b*N.
+// nonfinite (device counter or null): += 1 for every output that is not finite
 const char* launch_small_linear(const float* x, long row_stride, int rows, int K, const float* w, const float* b,
-                                int N, float* out, hipStream_t s);
+                                int N, float* out, hipStream_t s, int* nonfinite = nullptr);
 
 }  // namespace afx

@@ -106,6 +106,10 @@ for arch, prefix in ((AAS, "xlsr_aasist"), (CONF, "conformer"), (SSL, "conformer
             fails(lib.afx_tap(h, b"ssl", ptr(out), 8, C.byref(cnt), None), "too small")
             fails(lib.afx_tap(h, b"nope", None, 0, C.byref(cnt), None), "no tap named")
             ok(lib.afx_enable_taps(h, 0), "taps off")
+            ok(lib.afx_check_finite(h, None), "overflow guard (the shim's device memory is zero-filled: nothing counted)")
+            ok(lib.afx_engine_set(h, b"gemm_small_deep", 0), "per-engine tile switch")
+            ok(lib.afx_forward(h, ptr(wave), B, Ls, ptr(logits), ptr(ws), n, None), "forward without the deep tile")
+            ok(lib.afx_engine_set(h, b"gemm_small_deep", 1), "per-engine tile switch back")
             # per-class timing
             ok(lib.afx_profile_begin(h), "profile begin")
             ok(lib.afx_forward(h, ptr(wave), B, Ls, ptr(logits), ptr(ws), n, None), "profiled forward")
