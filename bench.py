@@ -369,6 +369,7 @@ def main():
         if use_dist:
             assert out[0].numel() == world * w["B"]
         roof, brk = roofline_of(w, workload, dtype, args.steps)
+        w["eng"].check_finite()  # (an operand overflow in any step above is an error, not a rate)
         val = world * w["B"] * args.steps / el
         r = {"value": round(val, 2), "unit": "utterances/s", "n_gpus": world, "global_batch": world * w["B"],
              "ms_per_step": round(el / args.steps * 1e3, 3), "device_ms_per_step": round(dms, 3), "dtype": dtype,

@@ -79,6 +79,16 @@ __global__ void bn_fold_kernel(const float* w, const float* b, const float* m, c
   }
 }
 
+__global__ void absmax_kernel(const float* x, int n, float* out) {  // out[0] = max |x| (one workgroup)
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(x[i]));
+  __shared__ float red[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 struct FT {  // fp32 device tensor owned by the engine
   float* p = nullptr;
   size_t n = 0;
@@ -120,6 +130,10 @@ struct afx_engine {
   // overflow guard: device counters [0] rows of the trunk's final LayerNorm with non-finite statistics, [1] non-finite logits
   // (written by those kernels of every forward, read and cleared by afx_check_finite)
   int* nonfinite = nullptr;
+  // split precision: the scale each LayerNorm's output takes as a pair-form operand, keyed by the LayerNorm's gamma pointer and
+  // chosen at finalize from |y| <= sqrt(C) max|gamma| + max|beta|: the largest power of two <= kS3ScaleBounded that keeps the hi
+  // half inside fp16 -- a LayerNorm output cannot overflow whatever the checkpoint's gains are
+  std::unordered_map<const float*, float> ln_scale;
 
   // trunk, packed operand-type weights
   void* convw[7] = {nullptr};
@@ -464,6 +478,39 @@ static int fold_bn(afx_engine* e, const std::string& p, int n, float* scale, flo
   return 0;
 }
 
+// split precision: one scale per LayerNorm (afx_engine::ln_scale) from the maxima of its gain and offset
+static int s3_layernorm_scales(afx_engine* h, hipStream_t s) {
+  h->ln_scale.clear();
+  if (!h->s3) return 0;
+  std::vector<std::pair<const FT*, const FT*>> lns;
+  for (const auto& kv : h->f) {
+    const std::string& k = kv.first;
+    if (kv.second.shape.size() != 1 || !ends_with(k, ".weight")) continue;
+    auto b = h->f.find(k.substr(0, k.size() - 6) + "bias");
+    if (b != h->f.end() && b->second.n == kv.second.n) lns.push_back({&kv.second, &b->second});
+  }
+  if (lns.empty()) return 0;
+  float* d = nullptr;
+  HIP_OK(hipMalloc((void**)&d, lns.size() * 8));
+  for (size_t i = 0; i < lns.size(); ++i) {
+    hipLaunchKernelGGL(absmax_kernel, dim3(1), dim3(256), 0, s, lns[i].first->p, (int)lns[i].first->n, d + 2 * i);
+    hipLaunchKernelGGL(absmax_kernel, dim3(1), dim3(256), 0, s, lns[i].second->p, (int)lns[i].second->n, d + 2 * i + 1);
+  }
+  std::vector<float> m(2 * lns.size());
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(m.data(), d, m.size() * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail("afx_finalize: %s", hipGetErrorString(e));
+  for (size_t i = 0; i < lns.size(); ++i) {
+    const float bound = sqrtf((float)lns[i].first->n) * m[2 * i] + m[2 * i + 1];
+    float sc = kS3ScaleBounded;
+    while (sc * bound > 60000.f && sc > 1e-6f) sc *= 0.5f;  // (a non-finite gain stays non-finite: the overflow guard reports it)
+    h->ln_scale[lns[i].first->p] = sc;
+  }
+  return 0;
+}
+
 extern "C" int afx_finalize(afx_handle h, void* stream) {
   if (!h) return fail("afx_finalize: null handle");
   hipStream_t s = (hipStream_t)stream;
@@ -554,6 +601,7 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
       }
     }
     if (head_only) {
+      if (int rc = s3_layernorm_scales(h, s)) return rc;
       h->finalized = true;
       return 0;
     }
@@ -572,6 +620,7 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
             h->aw, [&](const std::string& k) { return h->F(k); }, [&](size_t bytes) { return h->dalloc(bytes); }, s))
       return fail("afx_finalize: %s", m);
   }
+  if (int rc = s3_layernorm_scales(h, s)) return rc;
   h->finalized = true;
   return 0;
 }
@@ -793,6 +842,7 @@ static float s3_pairs_in(const void* p) {  // the scale of the pair-form rows `p
 // per-call context of the forward running on this thread: the engine's profiler, its A/B switches, and (split precision) the
 // pair-form scratch of the workspace plus the buffers whose producers may write pair-form rows in place
 static thread_local int t_no_deep = 0;
+static thread_local const std::unordered_map<const float*, float>* t_ln_scale = nullptr;
 static void begin_call(afx_engine* e, const Ws* w);
 static void prof_forget(afx_engine* e) {
   if (!e->prof) return;
@@ -878,7 +928,11 @@ static const char* P_rownorm(const RowNormArgs& a_in, int dt, hipStream_t s) {
   if (a.out_h && t_s3planes) {  // split precision: the LayerNorm writes the next product's A operand (pair-form rows) itself
     const bool pairs_out = dt == DT_FP32 && s3_ok(a.out_h) && (a.ldo_h & 31) == 0 && a.out_h != (const void*)a.x;
     a.oh_pairs = pairs_out ? 1 : 0;
-    a.oh_scale = kS3ScaleBounded;  // |LayerNorm output| <= sqrt(C) |gamma| + |beta|
+    a.oh_scale = kS3ScaleBounded;  // |LayerNorm output| <= sqrt(C) max|gamma| + max|beta|: the scale finalize chose for this LayerNorm
+    if (t_ln_scale) {
+      auto it = t_ln_scale->find(a.gamma);
+      if (it != t_ln_scale->end()) a.oh_scale = it->second;
+    }
     s3_set(a.out_h, pairs_out ? a.oh_scale : 0.f);
   }
   return timed(PC_ROWNORM, 0, s, [&] { return launch_rownorm(a, dt, s); });
@@ -887,6 +941,7 @@ static const char* P_rownorm(const RowNormArgs& a_in, int dt, hipStream_t s) {
 static void begin_call(afx_engine* e, const Ws* w) {
   t_prof = e->prof;
   t_no_deep = e->gemm_small_deep ? 0 : 1;
+  t_ln_scale = &e->ln_scale;
   t_s3planes = w ? w->s3planes : nullptr;
   t_s3bytes = w ? w->s3bytes : 0;
   if (w) s3_begin({w->bufA, w->bufB, w->feats_h, w->hbuf, w->att, w->ff, w->xpad, w->hc, w->ssl_h});

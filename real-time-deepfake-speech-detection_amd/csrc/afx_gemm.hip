@@ -1441,7 +1441,8 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
 #ifdef AFX_ATTR
   if (g_tile_override >= 6 && g_tile_override <= 9) return plain_k(p) && !p.k1 ? 84 + g_tile_override : 0;  // deep tiles (90..93), A/B
 #else
-  if (g_tile_override == 8) return plain_k(p) ? 92 : 0;  // the deep 128x64 tile, forced (tests)
+  if (g_tile_override == 8)  // the deep 128x64 tile, forced (tests) -- where its lean epilogue applies
+    return plain_k(p) && (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0 && p.m_lo == 0 ? 92 : 0;
 #endif
   if (g_tile_override == 3) return plain_k(p) ? 7 : 0;  // 8-phase 256x256
   if (g_tile_override >= 0) return g_tile_override == 1 ? 2 : 0;

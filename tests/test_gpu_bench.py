@@ -1,9 +1,12 @@
 """bench.py as the driver runs it: ONE JSON line on stdout with the contract's fields, the roofline / cpu_baseline objects, the
-parity of the sample -- and the same under RCCL (AFX_FORCE_DIST=1: process group + per-step score all-gather at world size 1,
-the path the N > 1 runs take), where the two-stream issue must not be slower than the one-stream issue (the hardware-queue
-sharing of DESIGN section 7 made it exactly as slow once; more than four queues made it 2x slower)."""
+parity of the sample, the `contract` objects (the same protocol in the precision that holds the parity contract on every
+utterance) -- and the same under RCCL (AFX_FORCE_DIST=1: process group + per-step score all-gather at world size 1, the path the
+N > 1 runs take), where the bench TIMES both ways of issuing a step before its timed region and runs the faster one (the
+hardware-queue sharing of DESIGN section 7 made the two-stream form exactly as slow as the one-stream form once; more than four
+queues made it 2x slower: neither may reach the driver's record unnoticed)."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -14,40 +17,79 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 def _bench(*flags, dist=False):
     env = dict(os.environ)
     env.pop("GPU_MAX_HW_QUEUES", None)
     if dist:
-        env.update(AFX_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, capture_output=True, text=True, timeout=600)
+        env.update(AFX_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port())
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     return json.loads(lines[0])
 
 
+def _check_probe(r):
+    """The issue self-check: both forms were timed, and the form the timed region ran is the one that was not slower."""
+    p = r["issue_probe"]
+    assert p["one_stream_ms_per_step"] > 0 and p["two_stream_ms_per_step"] > 0
+    faster = "two_stream" if p["two_stream_ms_per_step"] <= p["one_stream_ms_per_step"] else "one_stream"
+    assert p["issued"] == faster
+    assert r["issue"].startswith("back-end of step i on a side stream") == (faster == "two_stream")
+
+
 def test_bench_line_carries_the_contract():
     d = _bench("--steps", "4", "--warmup", "2", "--cpu-sample", "2")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "config3"):
+                "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "config3", "contract", "issue_probe"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["dtype"] == "fp16" and d["vs_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) / d["value"] < 0.01
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0 and 0 < r["mfma_busy_frac"] < 1
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # a PMC summary either serves exactly the class that was timed, or the line says why it does not (no prefix guessing)
+    assert (r["traffic"] is not None and r["traffic"] > 0) or "traffic_note" in r
+    assert ("mfma_busy_frac" in r and 0 < r["mfma_busy_frac"] < 1) or "holds no launch" in r.get("mfma_busy_note", "") or "absent" in r.get("mfma_busy_note", "")
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["parity_ok"] and d["parity"]["max_abs_dlogit_vs_oracle"] <= 1e-3
+    _check_probe(d)
+    # the contract-holding precision on the headline's own configuration: fp32-level parity, roofline against 2.5 PF / 3
+    k = d["contract"]
+    assert k["dtype"] == "fp16x3" and k["value"] > 0 and k["parity_ok"] and k["parity"]["max_abs_dlogit_vs_oracle"] <= 2e-5
+    assert abs(k["roofline"]["peak"] - 2500.0 / 3) < 1 and 0 < k["roofline"]["frac"] < 1
+    # config 3: lively head; fp16 reports every utterance with the reference's own top-k status, the contract keeps them all
     c = d["config3"]
-    assert c["value"] > 0 and c["roofline"]["frac"] > 0 and c["parity_ok"] and "cpu_baseline" in c
+    assert c["value"] > 0 and c["roofline"]["frac"] > 0 and "cpu_baseline" in c and "lively head" in c["workload"]
+    par = c["parity"]
+    assert len(par["same_topk"]) == par["utterances"] == 2 and len(par["per_utterance"]) == 2
+    if par["utterances_keeping_every_topk_decision"]:
+        assert par["max_where_topk_kept"] <= 1e-3
+    assert par["max_abs_dlogit_vs_oracle"] <= 3e-2 and par["feature_rel_l2_max"] <= 1e-3
+    kc = c["contract"]
+    assert kc["dtype"] == "fp16x3" and kc["value"] > 0 and kc["parity_ok"]
+    assert all(kc["parity"]["same_topk"]) and kc["parity"]["max_abs_dlogit_vs_oracle"] <= 2e-5 and kc["parity"]["feature_rel_l2_max"] <= 2e-5
+    _check_probe(c)
 
 
-def test_bench_under_rccl_keeps_the_two_stream_overlap():
-    two = _bench("--steps", "10", "--warmup", "3", "--cpu-sample", "0", dist=True)
-    one = _bench("--steps", "10", "--warmup", "3", "--cpu-sample", "0", "--no-overlap", dist=True)
-    assert two["issue"].startswith("back-end of step i on a side stream") and one["issue"] == "one stream"
-    print(f"RCCL world 1: student two streams {two['value']:.0f} utt/s, one stream {one['value']:.0f}; "
-          f"config 3 {two['config3']['value']:.0f} / {one['config3']['value']:.0f}")
-    # shared hardware queue: equal; more than four queues: half.  Healthy: +4-6 %.  The bound only rejects the pathologies.
-    assert two["value"] >= 0.99 * one["value"], (two["value"], one["value"])
-    assert two["config3"]["value"] >= 0.99 * one["config3"]["value"], (two["config3"]["value"], one["config3"]["value"])
+def test_bench_under_rccl_issues_the_faster_form():
+    """One bench process under a process group: the probe's two rates and the choice are in the line; the timed region ran the
+    chosen form, so its rate cannot be the pathological one (A/B inside one process, interleaved warm-up: no second box-noise
+    sample, no fixed port)."""
+    d = _bench("--steps", "10", "--warmup", "3", "--cpu-sample", "0", dist=True)
+    for r in (d, d["config3"]):
+        _check_probe(r)
+        p = r["issue_probe"]
+        best = min(p["one_stream_ms_per_step"], p["two_stream_ms_per_step"])
+        # the timed region (10 steps) against the probe of the form it issued (3 steps): the same work, generous noise bound
+        assert r["ms_per_step"] <= 1.25 * best, (r["ms_per_step"], p)
+    print(f"RCCL world 1: student probe {d['issue_probe']}, timed {d['ms_per_step']} ms; config 3 probe {d['config3']['issue_probe']}, "
+          f"timed {d['config3']['ms_per_step']} ms")
+    one = _bench("--steps", "4", "--warmup", "2", "--cpu-sample", "0", "--no-overlap", "--no-config3", dist=True)
+    assert one["issue"] == "one stream" and "issue_probe" not in one

@@ -137,6 +137,39 @@ def test_gemm_8phase_kernel_is_bit_identical_to_the_2stage_kernel(K, M, N, K_):
         check(lib().afx_debug_set(b"gemm_tile", -1))
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "fp16x3"])
+@pytest.mark.parametrize("K_", [1024, 4096])
+@pytest.mark.parametrize("M", [199, 1592, 3184])
+def test_gemm_deep_tile_is_bit_identical_to_the_2stage_tile(K, dtype, M, K_):
+    """gemm_deep_kernel (the 128x64 tile with three K-tile buffers: TWO tiles of LDS-DMA in flight across barriers, a counted
+    vmcnt, both k-steps' fragments requested before the first MFMA) serves the teacher's N = 1024 products -- the hazard
+    class of the 8-phase kernel above, so the same test: the dispatcher's choice at these shapes (the deep tile) against the
+    two-buffer 128x64 tile, bit for bit, over repeated launches, fp32 and operand-type outputs, with residual; fp16 and the
+    split-precision walk.  The per-engine switch of the same choice ("gemm_small_deep") is exercised in test_gpu_models."""
+    from afx._lib import check, lib
+    N = 1024
+    g = torch.Generator().manual_seed(K_ + M)
+    A = torch.randn(M, K_, generator=g)
+    W = torch.randn(N, K_, generator=g) / math.sqrt(K_)
+    if dtype == "fp16":
+        A, W = A.half(), W.half()
+    A, W = A.cuda(), W.cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).cuda()
+    ref = A.float().cpu().double() @ W.float().cpu().double().t() + bias.cpu().double() + R.cpu().double()
+    try:
+        check(lib().afx_debug_set(b"gemm_tile", 5))  # the two-buffer 128x64 tile
+        want_f, want_h = K.gemm(dtype, A, W, bias=bias, resid=R, out_f=True, out_h=True)
+        assert ((want_f.cpu().double() - ref).abs() / (1.0 + ref.abs())).max().item() < (2e-4 if dtype == "fp16" else 3e-6)
+        for forced in (8, -1):  # the deep tile forced, then the dispatcher's own choice at this shape (the deep tile)
+            check(lib().afx_debug_set(b"gemm_tile", forced))
+            for _ in range(12):
+                got_f, got_h = K.gemm(dtype, A, W, bias=bias, resid=R, out_f=True, out_h=True)
+                assert torch.equal(got_f, want_f) and torch.equal(got_h, want_h), forced
+    finally:
+        check(lib().afx_debug_set(b"gemm_tile", -1))
+
+
 @pytest.mark.parametrize("M,N,K_", [(12736, 1024, 1024), (3184, 3072, 1024), (3184, 4096, 1024), (1000, 768, 64), (447, 512, 192)])
 def test_gemm_8phase_short_tiles_are_bit_identical(K, M, N, K_):
     """Tile heights 160 / 192 / 224 / 256 of the 8-phase kernel (the launcher fits the height to one round of the

@@ -688,6 +688,58 @@ def test_ragged_bit_identity_holds_across_tile_families(afx_mod):
         assert (gm[b] - alone).abs().max().item() <= 2e-6
 
 
+def test_deep_tile_switch_is_per_engine_and_changes_no_bit(afx_mod):
+    """"gemm_small_deep" (the deep form of the 128x64 tile for products with at most two tiles per CU -- the teacher's
+    N = 1024 products at batch 16) is a switch of ONE engine: engine A with it off and engine B with it on, driven
+    alternately in one process, each keep their own choice (their profilers say which tile class ran), and the logits are
+    the same bits (same k order per row in both forms)."""
+    engine, synth = afx_mod
+    sd = synth.model_state_dict("XLSR_AASIST", n_layers=2)
+    a = engine.Engine("xlsr_aasist", n_layers=2, dtype="fp16")
+    b = engine.Engine("xlsr_aasist", n_layers=2, dtype="fp16")
+    a.load_state_dict(sd)
+    b.load_state_dict(sd)
+    a.set("gemm_small_deep", 0)
+    wave = synth.waveforms(16, 64000, batch_idx=9).cuda()
+    outs = []
+    for eng, deep in ((a, False), (b, True), (a, False)):
+        eng.profile_begin()
+        outs.append(eng.forward(wave).clone())
+        prof = eng.profile_end()
+        assert (prof["gemm_deep_kernel<128x64>"]["launches"] > 0) == deep, (deep, {k: v["launches"] for k, v in prof.items() if v["launches"]})
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_scoring_loop_runs_forward_hooks(afx_mod, tmp_path):
+    """main.py:211 calls ``model(batch_x)``: nn.Module.__call__, which is what runs forward (pre-)hooks.  The scoring loop's
+    two-stream form calls ``forward_overlapped`` directly -- so it is only taken for a model WITHOUT hooks; with a hook
+    registered the loop goes through ``model(x)`` and the hook sees every batch."""
+    engine, synth = afx_mod
+    from afx import harness
+    from models.conformer_baseline import MyModel
+    sd = synth.model_state_dict("ConformerModel", n_layers=2, n_encoders=2)
+    m = MyModel(device="cuda", ssl_cpkt_path=None, num_layers=2, order="first", n_encoders=2).to("cuda").eval()
+    m.load_state_dict(sd)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 6
+
+        def __getitem__(self, i):
+            return f"utt{i}", synth.waveforms(1, 16000, batch_idx=300 + i)[0], 1
+
+    seen = []
+    assert harness._may_overlap(m)
+    h = m.register_forward_hook(lambda mod, inp, out: seen.append(tuple(out.shape)))
+    assert not harness._may_overlap(m)
+    names, hooked = harness.produce_evaluation_file(DS(), m, "cuda", str(tmp_path / "hooked.txt"), batch_size=2, num_workers=0)
+    assert seen == [(2, 2)] * 3
+    h.remove()
+    assert harness._may_overlap(m)
+    _names, plain = harness.produce_evaluation_file(DS(), m, "cuda", str(tmp_path / "plain.txt"), batch_size=2, num_workers=0)
+    assert hooked == plain and len(seen) == 3  # same bits either way; no hook, no call
+
+
 def test_ragged_ssl_features(afx_mod):
     engine, synth = afx_mod
     sd = synth.ssl_state_dict(2)

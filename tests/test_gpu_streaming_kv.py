@@ -71,6 +71,52 @@ def test_kv_cached_streaming_equals_its_offline_block_causal_restatement(arch, n
         assert torch.equal(s1[0], got[i][1]), i
 
 
+def test_kv_cached_streaming_at_full_depth_24_layers_ring_wrap():
+    """The teacher AS DEPLOYED -- 24 transformer layers -- in the KV-cached mode: 17 hops of one stream (the 16-group ring of
+    every layer wraps), every hop against the offline block-causal restatement.  Same three-part statement as the 2-layer test:
+    feature window within 1e-3 relative L2 at every hop; the back-end on the GPU's own window equal to the oracle back-end;
+    scores within 1e-3 wherever the reference's GraphPool keeps its decisions under the fp16 rounding of 24 layers."""
+    from afx import engine, synth
+    from afx.streaming import KVCachedScorer
+    from oracle import aasist as oa
+    from oracle import models as om
+    from oracle import streaming as ostream
+    n_layers, S, hop, hops = 24, 1, 4000, 17
+    sd = synth.model_state_dict("XLSR_AASIST", n_layers=n_layers)
+    eng = engine.Engine("xlsr_aasist", n_layers=n_layers, dtype="fp16")
+    eng.load_state_dict(sd)
+    stream = torch.cat([synth.waveforms(S, hop, batch_idx=4100 + i) for i in range(hops)], dim=1)
+    wins = []
+    want, sizes = ostream.block_causal_scores(sd, stream, hop, windows=wins)
+    _ssl, head = om.split(sd)
+    sc = KVCachedScorer(eng, sd, S, window=64000, hop=hop)
+    eng.enable_taps()
+    kept, worst_kept, worst_other, worst_feat, worst_backend = 0, 0.0, 0.0, 0.0, 0.0
+    for i in range(hops):
+        s = sc.push(stream[:, i * hop:(i + 1) * hop].cuda()).cpu()
+        d = (s - want[i][:, 1]).abs()
+        f = eng.tap("ssl").cpu().reshape(wins[i].shape)
+        worst_feat = max(worst_feat, ((f[0] - wins[i][0]).norm() / wins[i][0].norm()).item())
+        t_ref, t_mid = {}, {}
+        oa.aasist_backend(head, wins[i], t_ref)
+        mid = oa.aasist_backend(head, f, t_mid)
+        worst_backend = max(worst_backend, (s - mid[:, 1]).abs().max().item())
+        same = all(torch.equal(t_ref["pool_idx"][p][0], t_mid["pool_idx"][p][0]) for p in t_ref["pool_idx"])
+        kept += same
+        if same:
+            worst_kept = max(worst_kept, d[0].item())
+        else:
+            worst_other = max(worst_other, d[0].item())
+    eng.enable_taps(False)
+    eng.check_finite()
+    print(f"24 layers, {hops} hops: feature window rel L2 <= {worst_feat:.1e}; |dscore| <= {worst_kept:.1e} on the {kept} hops that keep "
+          f"every top-k decision, <= {worst_other:.1e} elsewhere; back-end alone <= {worst_backend:.1e}")
+    assert worst_feat <= 1e-3
+    assert worst_kept <= 1e-3
+    assert worst_backend <= 1e-5 and worst_other <= 3e-2
+    assert kept >= hops // 3
+
+
 def test_kv_mode_refuses_what_it_cannot_do():
     from afx import engine, synth
     from afx._lib import AfxError

@@ -56,9 +56,15 @@ def test_config3_teacher_fp16_batch16_every_utterance(oracle48):
           f"elsewhere max {elsewhere:.1e}")
     assert max(r["feat_rel_l2"] for r in rows) <= 1e-3
     assert max(r["backend"] for r in rows) <= 1e-5
-    # profiles/r02_teacher_flip_rate.json: 6 of these 48 keep every decision with this head; a build whose trunk error
-    # grew would keep fewer (the flips are driven by the size of the feature perturbation)
-    assert len(kept) >= 4, "too few utterances keep their decisions to gate anything"
+    # profiles/r02_teacher_flip_rate.json (tools/teacher_flip_rate.py, the same 48 utterances and head): 6 of them keep every
+    # decision at the build's feature error; the flips are driven by the size of the feature perturbation, so a build whose
+    # trunk error grew keeps fewer.  The floor is the recorded count minus one (one near-tie may land either way on another
+    # box's summation order), read from the file rather than written here.
+    import json
+    import os
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_teacher_flip_rate.json")))
+    floor = rec["lively_1.5"]["keep_every_topk_decision"] - 1
+    assert len(kept) >= floor, f"{len(kept)} utterances keep their decisions, the recorded build kept {floor + 1}"
     assert all(r["dlogit"] <= 1e-3 for r in kept), [r for r in kept if r["dlogit"] > 1e-3]
     # where a near-tied pair of nodes does swap, the logit moves by what the reference model makes of the swap: measured
     # <= 9.1e-3 with this head; a coarse absolute bound still catches a back-end that breaks only when the order changes
