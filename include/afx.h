@@ -61,7 +61,11 @@ typedef struct afx_config {
 int afx_create(const afx_config* cfg, afx_handle* out);
 void afx_destroy(afx_handle h);
 const char* afx_last_error(void);
-const char* afx_version(void);
+const char* afx_version(void);   /* "afx <ver> (gfx950) build <id> hip <toolchain version>" */
+const char* afx_build_id(void);  /* hash of the sources the library was built from (tools stamp profiles/ with it) */
+/* HIP_VERSION the library was compiled with / the runtime this process resolved (hipRuntimeGetVersion); afx/_lib.py refuses a
+ * different major version (no reference counterpart: the reference has no native code) */
+int afx_hip_versions(int* build, int* runtime);
 
 /* ---- weights: reference checkpoint key names, without
  * the optional "module." prefix (utils.py:13-43).  `dev_ptr` is a contiguous fp32

@@ -34,6 +34,8 @@ SIGNATURES = {
     "afx_destroy": (None, [_P]),
     "afx_last_error": (C.c_char_p, []),
     "afx_version": (C.c_char_p, []),
+    "afx_build_id": (C.c_char_p, []),
+    "afx_hip_versions": (_I, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "afx_load_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I, _P]),
     "afx_finalize": (_I, [_P, _P]),
     "afx_num_frames": (_I, [_I]),
@@ -108,10 +110,30 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
+        _check_runtime(l)
         _lib = l
         # (no environment hook: the A/B knobs are reached through afx_debug_set / Engine.set by the tools and tests that
         # own the process, never by a stray variable in a product run)
     return _lib
+
+
+def _check_runtime(l):
+    """libafx.so is built by the system's hipcc and runs on whatever HIP runtime the process resolved first -- with torch
+    loaded, the copy bundled in the torch wheel.  The code objects and launch stubs of one major version do not belong on the
+    runtime of another: refuse it.  A runtime OLDER than the toolchain inside one major version (this image: hipcc 7.2 on the
+    wheel's 7.0) works as long as the library sticks to what both know -- said once, as a warning, so that a 'no device' or a
+    launch failure after an image change has a first suspect.  Build with the ROCm the torch wheel carries where possible."""
+    b, r = C.c_int(0), C.c_int(0)
+    if l.afx_hip_versions(C.byref(b), C.byref(r)) != 0:
+        raise AfxError(l.afx_last_error().decode())
+    bm, rm = b.value // 10_000_000, r.value // 10_000_000
+    if bm != rm:
+        raise AfxError(f"libafx.so was built with HIP {bm}.x (HIP_VERSION {b.value}) but this process runs HIP runtime {rm}.x "
+                       f"({r.value}): rebuild the library with the ROCm of the torch wheel (make -C csrc HIPCC=...)")
+    if r.value < b.value:
+        import warnings
+        warnings.warn(f"libafx.so: built with HIP {b.value}, running on the older runtime {r.value} (same major version) -- "
+                      "fine on this image; after an image change rebuild with the runtime's own toolchain first", RuntimeWarning, stacklevel=3)
 
 
 def check(rc):

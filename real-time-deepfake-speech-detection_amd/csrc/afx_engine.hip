@@ -171,7 +171,23 @@ struct afx_engine {
 // ---------------------------------------------------------------------------------
 static void prof_forget(afx_engine* e);
 extern "C" const char* afx_last_error(void) { return g_err; }
-extern "C" const char* afx_version(void) { return "afx 0.1 (gfx950)"; }
+extern "C" const char afx_build_id_str[];  // build_id.gen.c (Makefile): hash of the sources this library was built from
+extern "C" const char* afx_build_id(void) { return afx_build_id_str; }
+extern "C" const char* afx_version(void) {
+  static char v[96] = "";
+  if (!v[0]) snprintf(v, sizeof v, "afx 0.4 (gfx950) build %s hip %d.%d.%d", afx_build_id_str, HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH);
+  return v;
+}
+// The HIP version the library's code objects and launch stubs were compiled against, and the version of the runtime this
+// process actually resolved (a torch wheel bundles its own libamdhip64; afx/_lib.py loads torch first so that the process has
+// ONE runtime): the host side refuses a different major version and warns when the runtime is older than the toolchain.
+extern "C" int afx_hip_versions(int* build, int* runtime) {
+  if (build) *build = HIP_VERSION;
+  int rt = 0;
+  if (hipRuntimeGetVersion(&rt) != hipSuccess) return fail("afx_hip_versions: hipRuntimeGetVersion failed");
+  if (runtime) *runtime = rt;
+  return 0;
+}
 
 extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
   if (!cfg || !out) return fail("afx_create: null argument");
@@ -1545,6 +1561,15 @@ extern "C" int afx_head_from_workspace(afx_handle h, int B, int L, float* logits
   if (ws_bytes < needb) return fail("afx_head_from_workspace: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   if (w.T[6] < 1) return fail("afx_head_from_workspace: %d samples are too few for one output frame", L);
   begin_call(h, &w);
+  // split precision: what afx_trunk_forward left in the workspace for a dense product of the head -- the Conformer head's LL
+  // reads the features' operand copy, which the trunk's final LayerNorm wrote as pair-form rows (run_trunk: P_rownorm) -- is
+  // re-registered here: the registry of which buffers hold pair-form rows lives per call, and this is a second call
+  if (h->s3 && s3_ok(w.ssl_h) && (kD & 31) == 0) {
+    float sc = kS3ScaleBounded;
+    auto it = h->ln_scale.find(h->F("ssl.encoder.layer_norm.weight"));
+    if (it != h->ln_scale.end()) sc = it->second;
+    s3_set(w.ssl_h, sc);
+  }
   return run_head(h, B, w.T[6], w, logits, (hipStream_t)stream);
 }
 

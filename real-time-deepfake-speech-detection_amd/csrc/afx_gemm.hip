@@ -1154,6 +1154,184 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
   return hipGetLastError();
 }
 
+// =======================================================================================
+// gemm4_kernel: the 256x256 tile on FOUR waves -- one wave per SIMD, each owning 128 x 128 outputs, its 256 accumulator
+// registers in the AGPR half of the 512-register budget a lone wave has (the one structural form of
+// the 256-wide product that rounds 1-3 had not measured).  Against the 8-wave kernel above: a third fewer LDS fragment
+// bytes per MFMA (32 ds_read_b128 per 256 MFMAs instead of 24 per 128), four barrier participants instead of eight, no
+// hand-over of the matrix pipe between two waves of a SIMD -- ONE instruction stream carries MFMAs, fragment reads and
+// LDS-DMA, with the fragments of the NEXT k-step requested under the MFMAs of this one.
+//   LDS: two K-tile buffers of [A 256 rows | B 256 rows] x 128 B (the 8-wave kernel's row layout and swizzle), 128 KB.
+//   K-tile t (buffer t & 1), fragments F(t, 0) already in registers:
+//     request F(t, 1)                          (32 ds_read_b128 per wave and k-step: 8 A + 8 B fragments x 2)
+//     64 MFMA on F(t, 0)
+//     32 MFMA on F(t, 1), first half
+//     vmcnt(0) + lgkmcnt(0) + s_barrier        tile t+1 has landed (issued a K-tile ago); everyone is done READING tile t
+//     LDS-DMA of tile t+2 into tile t's buffer; request F(t+1, 0)
+//     32 MFMA on F(t, 1), second half          (under which the new requests land)
+//   One barrier per K-tile, placed inside the MFMA stream.  Same k order per output element as every other tile.
+// Plain K only, fp16 / bf16 (no split-precision walk), 256-row tiles only.
+// =======================================================================================
+template <class HT>
+__global__ __launch_bounds__(256) void gemm4_kernel(GemmArgs p) {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+  constexpr int STAGE = 512 * 128;  // bytes: A rows 0..255, B rows 256..511
+  constexpr int NP = 16;            // 1-KB LDS-DMA pieces per wave and K-tile (64 KB / 4 waves)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int g = blockIdx.z;
+  const T* Ag = (const T*)p.A + (long)g * p.g_a;
+  const T* Wg = (const T*)p.W + (long)g * p.g_w;
+  const int nN = (p.N + 255) / 256, nM = (p.M + 255) / 256;
+  const int nwg = nM * nN;
+  const int nk = p.K >> 6;
+  const T* src[NP];
+  int m0 = 0, n0 = 0;
+  auto setup = [&](int v) {
+    int pm, pn;
+    int L = v;
+    if (p.map_mode >= 1) {
+      const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    }
+    if (p.map_mode == 2) {
+      constexpr int GM = 8;
+      const int width = GM * nN, grp = L / width, first = grp * GM;
+      const int gsz = nM - first < GM ? nM - first : GM;
+      pm = first + (L % width) % gsz;
+      pn = (L % width) / gsz;
+    } else {
+      pm = L / nN;
+      pn = L % nN;
+    }
+    m0 = pm * 256;
+    n0 = pn * 256;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int row = (i * 4 + wave) * 8 + (lane >> 3);   // row of the stage: < 256 A, else B
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      if (i < NP / 2) {  // pieces i * 4 + wave < 32: A rows
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        src[i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
+      } else {
+        int n = n0 + row - 256;
+        n = n < p.N ? n : p.N - 1;
+        src[i] = Wg + (long)n * p.ldw + c * 8;
+      }
+    }
+  };
+  const unsigned lds_base = (unsigned)(size_t)smem;
+  auto dma16 = [&](const T* s_, unsigned lds_off) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + lds_off);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(s_), "s"(dst) : "memory");
+  };
+  auto issue_tile = [&](int buf, int kt) {
+    const long ko = (long)kt * 64;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) dma16(src[i] + ko, buf * STAGE + (i * 4 + wave) * 1024);
+  };
+  const int frow = lane & 15, fsw = (frow >> 1) & 7, kq = lane >> 4;
+  const char* aR = smem + (wr * 128 + frow) * 128;
+  const char* bR = smem + (256 + wc * 128 + frow) * 128;
+  auto read_frags = [&](int buf, int ks, V8 (&af)[8], V8 (&wf)[8]) {
+    const int slot = ((ks * 4 + kq) ^ fsw) * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wf[j] = *(const V8*)(bR + buf * STAGE + j * (16 * 128) + slot);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = *(const V8*)(aR + buf * STAGE + i * (16 * 128) + slot);
+  };
+  f32x4 acc[8][8];
+  auto mfma_rows = [&](int i0, int i1, const V8 (&af)[8], const V8 (&wf)[8]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i >= i0 && i < i1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define AFX_BAR4()                         \
+  do {                                     \
+    __builtin_amdgcn_sched_barrier(0);     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_s_barrier();          \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+  int v = blockIdx.x;
+  setup(v);
+  issue_tile(0, 0);
+  if (nk > 1) issue_tile(1, 1);
+  bool first = true;
+  for (;;) {
+    if (first && nk > 1) wait_vmcnt<NP>();  // K-tile 0 has landed, K-tile 1 may be in flight
+    else wait_vmcnt<0>();                   // (later output tiles: the epilogue's stores sit behind these DMAs in the queue)
+    first = false;
+    AFX_BAR4();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) the compiler can see (as in gemm8_kernel: keeps its own vmcnt(0) out of the loop)
+    V8 fa0[8], fw0[8], fa1[8], fw1[8];
+    read_frags(0, 0, fa0, fw0);
+    for (int t = 0; t < nk; ++t) {
+      const int b = t & 1;
+      read_frags(b, 1, fa1, fw1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_rows(0, 8, fa0, fw0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_rows(0, 4, fa1, fw1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < nk) {
+        wait_vmcnt<0>();                                  // tile t+1 (this wave's pieces) has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment of tile t is in registers
+        AFX_BAR4();
+        if (t + 2 < nk) issue_tile(b, t + 2);
+        read_frags(b ^ 1, 0, fa0, fw0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mfma_rows(4, 8, fa1, fw1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    AFX_BAR4();  // every wave is done reading the last K-tile: the next output tile's DMA may overwrite both buffers
+    const int m0c = m0, n0c = n0;
+    const int vn = v + gridDim.x;
+    if (vn < nwg) {
+      setup(vn);
+      issue_tile(0, 0);
+      if (nk > 1) issue_tile(1, 1);
+    }
+    gemm_epilogue<HT, 256, 256, 2, 2, false, true, false>(p, acc, smem, m0c, n0c, g);
+    if (vn >= nwg) break;
+    v = vn;
+  }
+#undef AFX_BAR4
+}
+
+template <class HT>
+static hipError_t launch_gemm4_t(const GemmArgs& p, int groups, hipStream_t s) {
+  constexpr int lds = 2 * 512 * 128;
+  static LdsLimit lim;
+  if (hipError_t e = lim.ensure((const void*)gemm4_kernel<HT>, lds); e != hipSuccess) return e;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorInvalidDevice;
+  cus &= ~7;
+  if (cus < 8) cus = 8;
+  const int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256);
+  dim3 grid(tiles < cus ? tiles : cus, 1, groups);
+  hipLaunchKernelGGL((gemm4_kernel<HT>), grid, dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
 template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false, bool LEAN = false, bool S3 = false>
 static hipError_t launch_gemm_t(const GemmArgs& p, int groups, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
@@ -1444,6 +1622,7 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
   if (g_tile_override == 8)  // the deep 128x64 tile, forced (tests) -- where its lean epilogue applies
     return plain_k(p) && (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0 && p.m_lo == 0 ? 92 : 0;
 #endif
+  if (g_tile_override == 4) return plain_k(p) && !p.k1 && (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0 ? 4 : 0;  // 4-wave 256x256 (A/B)
   if (g_tile_override == 3) return plain_k(p) ? 7 : 0;  // 8-phase 256x256
   if (g_tile_override >= 0) return g_tile_override == 1 ? 2 : 0;
   // Wave-quantisation model fitted to tools/bench_gemm.py (profiles/r01_gemm_tile_ab*.txt):
@@ -1481,6 +1660,7 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 93: return launch_gemm_deep_t<HT, 128, 128, 2, 2, 3>(p, groups, s);
 #endif
     case 92: return launch_gemm_deep_t<HT, 128, 64, 2, 2, 3>(p, groups, s);
+    case 4: return launch_gemm4_t<HT>(p, groups, s);
     case 7:
       if (g_ph4 == 0) return launch_gemm8_t<HT, 256, 256, false, 8, 3>(p, groups, s);  // default: the three-buffer ring form
 #ifdef AFX_ATTR

@@ -21,6 +21,7 @@ hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
+hipError_t hipRuntimeGetVersion(int* v) { *v = HIP_VERSION; return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "hip_host_shim: error"; }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 

@@ -208,23 +208,26 @@ def test_teacher_to_student_layer_copy_like_main_kd():
     assert (got - ref).abs().max().item() <= 1e-3
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "fp16x3"])
 @pytest.mark.parametrize("arch", ["xlsr_aasist", "conformer"])
-def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_path, arch):
+def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_path, arch, dtype):
     """main.py:199-221 scores batch after batch and reads the scores at the end; afx.harness.produce_evaluation_file issues
     the back-end of batch i (AASIST graph head / Conformer head) on a side stream under the trunk of batch i+1
     (afx_trunk_forward / afx_head_from_workspace, two workspaces alternating).  Same kernels on the same data: every score
     must equal the one-stream forward's bit for bit, over more batches than workspaces, a ragged last batch and changing
-    batch sizes."""
+    batch sizes.  In split precision too: the trunk leaves its features for the Conformer head as a pair-form operand, and the
+    head call -- a second entry into the library, on another stream -- has to know (round 4: it did not, and scored garbage
+    while the one-stream forward was right; found by the overflow guard in bench.py's fp16x3 run)."""
     from afx import engine, harness, synth
     if arch == "xlsr_aasist":
         from models.xlsr_aasist import My_XLSR_AASIST as Cls
         sd = synth.model_state_dict("XLSR_AASIST", n_layers=2, head_scale=1.5)
-        eng = engine.Engine("xlsr_aasist", n_layers=2, dtype="fp16")
+        eng = engine.Engine("xlsr_aasist", n_layers=2, dtype=dtype)
         kw = {}
     else:
         from models.conformer_baseline import MyModel as Cls
         sd = synth.model_state_dict("ConformerModel", n_layers=2, n_encoders=2)
-        eng = engine.Engine("conformer", n_layers=2, dtype="fp16", conf_blocks=2)
+        eng = engine.Engine("conformer", n_layers=2, dtype=dtype, conf_blocks=2)
         kw = dict(n_encoders=2)
     eng.load_state_dict(sd)
     waves = [synth.waveforms(b, 16000, batch_idx=700 + i).cuda() for i, b in enumerate([5, 5, 5, 3, 7, 5, 1])]
@@ -235,6 +238,7 @@ def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_p
         for g, w_ in zip(got, want):
             assert torch.equal(g, w_)
     assert torch.equal(eng.forward(waves[0]), want[0])  # and the one-stream call is unaffected afterwards
+    eng.check_finite()
 
     class Toy(torch.utils.data.Dataset):
         def __len__(self):
@@ -244,6 +248,7 @@ def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_p
             return f"utt{i}", synth.waveforms(1, 16000, batch_idx=900 + i)[0], 0
     model = Cls(device="cuda", ssl_cpkt_path=None, num_layers=2, order="first", **kw).to("cuda").eval()
     model.load_state_dict(sd)
+    model.set_precision(dtype)
     names, scores = harness.produce_evaluation_file(Toy(), model, "cuda", str(tmp_path / "s.txt"), batch_size=4, num_workers=0)
     with torch.no_grad():
         ref = torch.cat([model(torch.stack([Toy()[i][1] for i in range(j, min(j + 4, 13))]).cuda())[:, 1] for j in range(0, 13, 4)]).cpu()

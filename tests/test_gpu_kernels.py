@@ -160,7 +160,7 @@ def test_gemm_deep_tile_is_bit_identical_to_the_2stage_tile(K, dtype, M, K_):
     try:
         check(lib().afx_debug_set(b"gemm_tile", 5))  # the two-buffer 128x64 tile
         want_f, want_h = K.gemm(dtype, A, W, bias=bias, resid=R, out_f=True, out_h=True)
-        assert ((want_f.cpu().double() - ref).abs() / (1.0 + ref.abs())).max().item() < (2e-4 if dtype == "fp16" else 3e-6)
+        assert ((want_f.cpu().double() - ref).abs() / (1.0 + ref.abs())).max().item() < (2e-4 if dtype == "fp16" else 2e-5)
         for forced in (8, -1):  # the deep tile forced, then the dispatcher's own choice at this shape (the deep tile)
             check(lib().afx_debug_set(b"gemm_tile", forced))
             for _ in range(12):

@@ -10,6 +10,9 @@ mkdir -p "$OUT"
 ROOT=$(pwd)
 WL=${WORKLOAD:-conformer_student}   # bench.py --workload (xlsr_aasist = BASELINE config 3)
 : > "$OUT/summary.txt"
+# which build this visit measures (the GPU box has no .git: the Makefile recorded the commit and the source hash at build time)
+echo "== build $(cat real-time-deepfake-speech-detection_amd/lib/build_stamp.json 2>/dev/null)" | tee -a "$OUT/summary.txt"
+cp real-time-deepfake-speech-detection_amd/lib/build_stamp.json "$OUT/build_stamp.json" 2>/dev/null
 
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
 echo "== pytest -m gpu $*" | tee -a "$OUT/summary.txt"
@@ -54,7 +57,12 @@ if gaps:
     with open(out + "/summary.txt", "a") as fh:
         fh.write(f"== inter-kernel gaps: {len(gaps)} gaps, median {gaps[len(gaps)//2]/1e3:.2f} us, mean {sum(gaps)/len(gaps)/1e3:.2f} us, "
                  f"sum {sum(gaps)/1e6:.2f} ms beside {busy/1e6:.2f} ms of kernel time ({sum(gaps)/(sum(gaps)+busy)*100:.1f} % idle)\n")
+try:
+    stamp = open(out + "/build_stamp.json").read().strip()
+except OSError:
+    stamp = "{}"
 with open(out + "/kernel_by_shape.csv", "w") as fh:
+    fh.write("# build " + stamp + "\n")
     fh.write("kernel,grid_x_threads,grid_z,wg_size,calls,avg_us,total_ms\n")
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         fh.write(f'"{k[0]}",{k[1]},{k[2]},{k[3]},{len(v)},{sum(v)/len(v)/1e3:.1f},{sum(v)/1e6:.3f}\n')

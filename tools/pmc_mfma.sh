@@ -53,7 +53,12 @@ for k, d in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("SQ_VALU_MFMA_BUSY
                  f"lds_conflict/active={rec.get('lds_conflict_per_active', float('nan')):.3f}  wait_any/wave_cycle={rec.get('wait_any_per_wave_cycle', float('nan')):.3f}")
 print("\n".join(lines))
 open(out + "/pmc_mfma.txt", "w").write("\n".join(lines) + "\n")
-json.dump({"note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), mean per launch over 3 forwards of workload "
+stamp = {}
+try:
+    stamp = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(out))), "real-time-deepfake-speech-detection_amd", "lib", "build_stamp.json")))
+except Exception:
+    pass
+json.dump({"git": stamp.get("git", "unknown"), "git_dirty": stamp.get("dirty"), "build_id": stamp.get("build_id", "unknown"), "dtype": os.environ.get("AFX_DTYPE", "fp16"), "note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), mean per launch over 3 forwards of workload "
                    + os.environ.get("AFX_WORKLOAD", "conformer_student") + " (tools/pmc_forward.py); raw counter means beside it",
            "kernels": res}, open(out + "/pmc_mfma.json", "w"), indent=1)
 PYEOF

@@ -19,7 +19,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd "$ROOT"
 python3 - "$OUT" <<'PYEOF'
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
@@ -37,7 +37,12 @@ for k, d in sorted(agg.items()):
               "write_bytes_per_launch": 1024 * sum(w) / len(w)}
     print(f"{k[:70]:70s} n={len(f):4d} fetch {res[k]['fetch_bytes_per_launch']/1e6:9.1f} MB  write {res[k]['write_bytes_per_launch']/1e6:9.1f} MB")
 import os
-json.dump({"note": "FETCH_SIZE x2 (gfx950 correction) and WRITE_SIZE, KB -> bytes, mean per launch over 3 forwards of "
+stamp = {}
+try:
+    stamp = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(out))), "real-time-deepfake-speech-detection_amd", "lib", "build_stamp.json")))
+except Exception:
+    pass
+json.dump({"git": stamp.get("git", "unknown"), "git_dirty": stamp.get("dirty"), "build_id": stamp.get("build_id", "unknown"), "dtype": os.environ.get("AFX_DTYPE", "fp16"), "note": "FETCH_SIZE x2 (gfx950 correction) and WRITE_SIZE, KB -> bytes, mean per launch over 3 forwards of "
                    "workload " + os.environ.get("AFX_WORKLOAD", "conformer_student") + " (tools/pmc_forward.py)", "kernels": res}, open(out + "/pmc_traffic.json", "w"), indent=1)
 PYEOF
 find "$OUT" -name "*counter_collection.csv" -size +20M -delete 2>/dev/null
