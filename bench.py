@@ -348,6 +348,9 @@ def main():
         one is what the timed region issues.  Returns (overlapped, probe)."""
         if args.no_overlap:
             return False, None
+        if not w["eng"].overlap_is_bit_stable:  # teacher in fp16x3: Engine.forward_overlapped runs on one stream (engine.py)
+            return False, {"issued": "one_stream", "note": "the two-stream step is disabled for the AASIST back-end in fp16x3: it was "
+                           "measured not to reproduce the one-stream bits (profiles/r04_two_stream_race.txt, DESIGN.md section 7)"}
         n = max(args.warmup, 3)
         ms = {}
         for name, ov in (("two_stream", True), ("one_stream", False)):

@@ -165,6 +165,8 @@ class Engine:
         (afx.harness.produce_evaluation_file does, once, after its last batch)."""
         if self._taps:  # taps are engine-owned copies written by whichever forward runs: one stream only
             return self.forward(wave)
+        if not self.overlap_is_bit_stable:
+            return self.forward(wave)
         x = self._wave(wave)
         B, L = x.shape
         l = lib()
@@ -199,6 +201,17 @@ class Engine:
             slot["head_done"].record(self._side)
             self._last_head = slot["head_done"]
         return out
+
+    @property
+    def overlap_is_bit_stable(self):
+        """False for the ONE combination in which the two-stream step was measured not to reproduce the one-stream bits: the
+        teacher (AASIST back-end) in dtype "fp16x3".  There, with the back-end of batch i running beside it, the trunk of
+        batch i+1 computes ONE frame of conv layer 0 slightly differently in about a third of the batches (logits move by
+        1e-5 .. 6e-4, more where a GraphPool near-tie flips); not when every call is followed by a synchronise, not with
+        another engine's back-end beside it, not in fp16 / fp32, not with the Conformer head -- evidence and what was ruled
+        out (stale workspace, out-of-bounds writes, the back-end itself): profiles/r04_two_stream_race.txt; root cause open
+        (DESIGN.md section 7).  ``forward_overlapped`` runs this combination on one stream: the mode exists to be right."""
+        return not (self.arch == "xlsr_aasist" and self.dtype == "fp16x3")
 
     def join(self):
         """Make torch's current stream wait for every back-end forward_overlapped has put on the side stream (and for

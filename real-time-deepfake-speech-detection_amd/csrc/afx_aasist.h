@@ -77,6 +77,7 @@ using Alloc = std::function<void*(size_t)>;
 
 // prepare derived tensors (BN folds, tap-major conv weights); nullptr or error text
 const char* aasist_finalize(AasistWeights& w, const GetF& get, const Alloc& alloc, hipStream_t s);
+void aasist_set_stop(int v);  // diagnostic knob: return after that many stages of the back-end (0 = all)
 void aasist_carve(int B, int T, const Alloc& take, AasistWs* ws);
 // feats (B,T,1024) fp32 -> logits (B,2); nonfinite (device counter or null): += 1 for every logit that is not finite
 const char* aasist_forward(const AasistWeights& w, const float* feats, int B, int T, AasistWs& ws, float* logits,

@@ -1034,9 +1034,19 @@ void aasist_carve(int B, int T, const Alloc& take, AasistWs* ws) {
     if (e_ != hipSuccess) return hipGetErrorString(e_);    \
   } while (0)
 
+// diagnostic knob (tools/diag_two_stream_which.py): > 0 = the back-end returns after that many of its stages (logits are then
+// whatever the buffer held) -- which stage's kernels disturb a trunk running beside them on another stream
+static int g_aas_stop = 0;
+void aasist_set_stop(int v) { g_aas_stop = v; }
+#define AAS_STAGE()                                   \
+  do {                                                \
+    if (g_aas_stop > 0 && ++stage_ == g_aas_stop) return nullptr; \
+  } while (0)
+
 const char* aasist_forward(const AasistWeights& w, const float* feats, int B, int T, AasistWs& ws, float* logits,
                            hipStream_t s, int* nonfinite) {
   if (!w.ready) return "aasist: weights not finalized";
+  int stage_ = 0;
   int wd, wp, img;
   dims(T, &wd, &wp, &img);
   if (wd < 2) return "aasist: clip too short (need at least 6 SSL frames)";
@@ -1050,6 +1060,7 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
     g.bias = w.LLb; g.out = ws.ll; g.ldo = 128;
     AOK(launch_f32_gemm(g, s));
   }
+  AAS_STAGE();  // 1: LL
   // ---- max-pool + BN + SELU into a 1-channel padded image ---------------------------
   float *X = ws.imgA, *Y = ws.imgB, *D = ws.imgC;
   // Only what no kernel writes has to be zeroed: every conv stores ALL virtual pixels at rows [wp+1, M+wp+1) (zeros
@@ -1060,6 +1071,7 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
   float* x1 = ws.wmap2;  // 1-channel image borrowed from a later buffer
   hipLaunchKernelGGL(pool_bn_selu_kernel, dim3((img + 255) / 256, B + 1), dim3(256), 0, s, ws.ll, T, wd, wp, img,
                      w.bn0_scale, w.bn0_shift, x1, B, 3 * wp + 16, ws.imgA, ws.imgB, ws.imgC, head);
+  AAS_STAGE();  // 2: pooling
   // ---- residual encoder ----------------------------------------------------------------
   {  // block 0 (Cin = 1): conv1+bn2+selu -> Y, downsample -> D, conv2(Y) + D -> X
     const AasistWeights::Block& K = w.blk[0];
@@ -1073,6 +1085,7 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
     g.img = img; g.wp = wp; g.hout = AAS_F; g.wd = wd; g.out = X; g.ldo = K.cout; g.o_off = wp + 1;
     AOK(launch_f32_gemm(g, s));
   }
+  AAS_STAGE();  // 3: residual block 0
   for (int i = 1; i < 6; ++i) {
     const AasistWeights::Block& K = w.blk[i];
     F32GemmArgs g;
@@ -1103,6 +1116,7 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
     }
     g.img = img; g.wp = wp; g.hout = AAS_F; g.wd = wd; g.out = X; g.ldo = K.cout; g.o_off = wp + 1;
     AOK(launch_f32_gemm(g, s));
+    AAS_STAGE();  // 4..8: residual blocks 1..5
   }
   // ---- attention maps: 1x1 convs over the padded image --------------------------------
   {
@@ -1118,6 +1132,7 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
   }
   hipLaunchKernelGGL(att_pool_kernel, dim3(AAS_F + wd, B), dim3(64), 0, s, X, ws.wmap2, img, wp, wd, w.pos_S, ws.eS,
                      ws.eT);
+  AAS_STAGE();  // 9: attention maps + pooling
   // ---- graph layers ---------------------------------------------------------------------
   const int nS = AAS_F / 2, nT = wd / 2 > 0 ? wd / 2 : 1;        // after pool_S / pool_T
   const int nS1 = nS / 2 > 0 ? nS / 2 : 1, nT1 = nT / 2 > 0 ? nT / 2 : 1;  // after pool_h*
@@ -1138,6 +1153,7 @@ const char* aasist_forward(const AasistWeights& w, const float* feats, int B, in
     const PoolArgs pp[2] = {pool_args(w.pS, ws.gS, AAS_F, 64, nS, ws.oS), pool_args(w.pT, ws.gT, wd, 64, nT, ws.oT)};
     launch_pools(pp, 2, B, s);
   }
+  AAS_STAGE();  // 10: GAT + GraphPool of both graphs
   // branch scratch carve
   float* p = ws.br;
   auto take = [&](size_t n) { float* r = p; p += (n + 63) / 64 * 64; return r; };

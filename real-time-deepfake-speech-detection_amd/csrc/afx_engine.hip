@@ -1870,6 +1870,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
     gemm_set_map_mode(value);
     return 0;
   }
+  if (!strcmp(key, "aasist_stop")) {
+    aasist_set_stop(value);
+    return 0;
+  }
   if (!strcmp(key, "gemm_tile")) {
     gemm_set_tile(value);
     return 0;

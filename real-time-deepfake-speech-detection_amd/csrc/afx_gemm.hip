@@ -1171,7 +1171,12 @@ static hipError_t launch_gemm8_t(const GemmArgs& p, int groups, hipStream_t s) {
 //     32 MFMA on F(t, 1), second half          (under which the new requests land)
 //   One barrier per K-tile, placed inside the MFMA stream.  Same k order per output element as every other tile.
 // Plain K only, fp16 / bf16 (no split-precision walk), 256-row tiles only.
+// MEASURED AND NOT SHIPPED (profiles/r04_gemm4_ab.txt): bit-identical rows, 568 / 573 TFLOP/s on QKV / FC1 against the 8-wave
+// kernel's 932 / 927, 1 176 against 1 389 at 8192^3 -- with two K-tile buffers at most one K-tile (64 KB per CU) is in flight,
+// against the 8-wave ring's 96 KB, and a K-tile then costs 1.83 us where the matrix pipe needs 0.98.  The
+// kernel exists in the attribution build only (make attr; tools/diag_gemm4.py, BENCH_SET=w4 tools/bench_gemm.py).
 // =======================================================================================
+#ifdef AFX_ATTR
 template <class HT>
 __global__ __launch_bounds__(256) void gemm4_kernel(GemmArgs p) {
   typedef typename HT::T T;
@@ -1247,16 +1252,16 @@ __global__ __launch_bounds__(256) void gemm4_kernel(GemmArgs p) {
     for (int i = 0; i < 8; ++i) af[i] = *(const V8*)(aR + buf * STAGE + i * (16 * 128) + slot);
   };
   f32x4 acc[8][8];
-  auto mfma_rows = [&](int i0, int i1, const V8 (&af)[8], const V8 (&wf)[8]) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i >= i0 && i < i1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
-      }
-    __builtin_amdgcn_s_setprio(0);
+  // One fragment read / one LDS-DMA piece, so that they can be slipped BETWEEN the MFMAs of the single instruction stream (an
+  // MFMA holds the issue port for a few of its 16 cycles: a read or the five instructions of a DMA fit in the shadow).  Issued
+  // as a block they cost their whole issue time as a matrix-pipe bubble (first version: 508 TFLOP/s on QKV against the 8-wave
+  // kernel's 860 -- profiles/r04_gemm4_ab.txt).
+  auto read_one = [&](int buf, int ks, int q, V8 (&af)[8], V8 (&wf)[8]) {  // q = 0..7 B fragments, 8..15 A fragments
+    const int slot = ((ks * 4 + kq) ^ fsw) * 16;
+    if (q < 8) wf[q] = *(const V8*)(bR + buf * STAGE + q * (16 * 128) + slot);
+    else af[q - 8] = *(const V8*)(aR + buf * STAGE + (q - 8) * (16 * 128) + slot);
   };
+  auto dma_one = [&](int buf, int kt, int i) { dma16(src[i] + (long)kt * 64, buf * STAGE + (i * 4 + wave) * 1024); };
 #define AFX_BAR4()                         \
   do {                                     \
     __builtin_amdgcn_sched_barrier(0);     \
@@ -1284,21 +1289,50 @@ __global__ __launch_bounds__(256) void gemm4_kernel(GemmArgs p) {
     read_frags(0, 0, fa0, fw0);
     for (int t = 0; t < nk; ++t) {
       const int b = t & 1;
-      read_frags(b, 1, fa1, fw1);
+      const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+      // ---- k-step 0: 64 MFMAs on F(t, 0); the 16 reads of F(t, 1) ride behind the first 16
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc[i][j] = HT::mfma(fw0[j], fa0[i], acc[i][j]);
+          if (i < 2) {
+            read_one(b, 1, i * 8 + j, fa1, fw1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       __builtin_amdgcn_sched_barrier(0);
-      mfma_rows(0, 8, fa0, fw0);
+      // ---- k-step 1, first half: 32 MFMAs
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = HT::mfma(fw1[j], fa1[i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_rows(0, 4, fa1, fw1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk) {
-        wait_vmcnt<0>();                                  // tile t+1 (this wave's pieces) has landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment of tile t is in registers
-        AFX_BAR4();
-        if (t + 2 < nk) issue_tile(b, t + 2);
-        read_frags(b ^ 1, 0, fa0, fw0);
-        __builtin_amdgcn_sched_barrier(0);
+      // every fragment of tile t is in registers on EVERY path from here on (a wait the compiler sees: without it the
+      // join behind the conditional below made the second half wait for the NEW reads -- lgkmcnt(3..0) -- on the path that took it)
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+      if (more1) {
+        wait_vmcnt<0>();  // tile t+1 (this wave's pieces) has landed: issued a whole K-tile ago
+        AFX_BAR4();       // ... everyone's has; everyone is done reading tile t
       }
-      mfma_rows(4, 8, fa1, fw1);
+      // ---- k-step 1, second half: 32 MFMAs; behind the first 16 the reads of F(t+1, 0), behind the last 16 the DMA of tile t+2
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 4; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc[i][j] = HT::mfma(fw1[j], fa1[i], acc[i][j]);
+          const int q = (i - 4) * 8 + j;
+          if (q < 16) {
+            if (more1) read_one(b ^ 1, 0, q, fa0, fw0);
+          } else {
+            if (more2) dma_one(b, t + 2, q - 16);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1331,6 +1365,7 @@ static hipError_t launch_gemm4_t(const GemmArgs& p, int groups, hipStream_t s) {
   hipLaunchKernelGGL((gemm4_kernel<HT>), grid, dim3(256), lds, s, p);
   return hipGetLastError();
 }
+#endif  // AFX_ATTR
 
 template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false, bool LEAN = false, bool S3 = false>
 static hipError_t launch_gemm_t(const GemmArgs& p, int groups, hipStream_t s) {
@@ -1622,7 +1657,9 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
   if (g_tile_override == 8)  // the deep 128x64 tile, forced (tests) -- where its lean epilogue applies
     return plain_k(p) && (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0 && p.m_lo == 0 ? 92 : 0;
 #endif
+#ifdef AFX_ATTR
   if (g_tile_override == 4) return plain_k(p) && !p.k1 && (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0 ? 4 : 0;  // 4-wave 256x256 (A/B)
+#endif
   if (g_tile_override == 3) return plain_k(p) ? 7 : 0;  // 8-phase 256x256
   if (g_tile_override >= 0) return g_tile_override == 1 ? 2 : 0;
   // Wave-quantisation model fitted to tools/bench_gemm.py (profiles/r01_gemm_tile_ab*.txt):
@@ -1660,7 +1697,9 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 93: return launch_gemm_deep_t<HT, 128, 128, 2, 2, 3>(p, groups, s);
 #endif
     case 92: return launch_gemm_deep_t<HT, 128, 64, 2, 2, 3>(p, groups, s);
+#ifdef AFX_ATTR
     case 4: return launch_gemm4_t<HT>(p, groups, s);
+#endif
     case 7:
       if (g_ph4 == 0) return launch_gemm8_t<HT, 256, 256, false, 8, 3>(p, groups, s);  // default: the three-buffer ring form
 #ifdef AFX_ATTR

@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "90286387882f";
+const char afx_build_id_str[] = "d9b3c4711839";

@@ -230,7 +230,11 @@ def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_p
         eng = engine.Engine("conformer", n_layers=2, dtype=dtype, conf_blocks=2)
         kw = dict(n_encoders=2)
     eng.load_state_dict(sd)
-    waves = [synth.waveforms(b, 16000, batch_idx=700 + i).cuda() for i, b in enumerate([5, 5, 5, 3, 7, 5, 1])]
+    # (three times round the batch-size list: the one combination that is NOT bit-stable two-stream -- AASIST back-end in
+    # fp16x3, about one batch in three moved, profiles/r04_two_stream_race.txt -- runs one-stream inside forward_overlapped;
+    # every other combination gets 42 concurrent batches here to show it is)
+    waves = [synth.waveforms(b, 16000, batch_idx=700 + i).cuda() for i, b in enumerate([5, 5, 5, 3, 7, 5, 1] * 3)]
+    assert eng.overlap_is_bit_stable == (not (arch == "xlsr_aasist" and dtype == "fp16x3"))
     want = [eng.forward(w).clone() for w in waves]
     for _ in range(2):  # twice: the second pass starts from slots that have a pending head
         got = [eng.forward_overlapped(w) for w in waves]

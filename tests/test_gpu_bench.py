@@ -38,6 +38,9 @@ def _bench(*flags, dist=False):
 def _check_probe(r):
     """The issue self-check: both forms were timed, and the form the timed region ran is the one that was not slower."""
     p = r["issue_probe"]
+    if "note" in p:  # (a combination whose two-stream form is disabled: nothing to choose)
+        assert p["issued"] == "one_stream" and r["issue"] == "one stream"
+        return
     assert p["one_stream_ms_per_step"] > 0 and p["two_stream_ms_per_step"] > 0
     faster = "two_stream" if p["two_stream_ms_per_step"] <= p["one_stream_ms_per_step"] else "one_stream"
     assert p["issued"] == faster
@@ -76,6 +79,8 @@ def test_bench_line_carries_the_contract():
     assert kc["dtype"] == "fp16x3" and kc["value"] > 0 and kc["parity_ok"]
     assert all(kc["parity"]["same_topk"]) and kc["parity"]["max_abs_dlogit_vs_oracle"] <= 2e-5 and kc["parity"]["feature_rel_l2_max"] <= 2e-5
     _check_probe(c)
+    _check_probe(kc)
+    assert kc["issue"] == "one stream"  # (AASIST back-end in fp16x3: the two-stream form is not bit-stable there and is not issued)
 
 
 def test_bench_under_rccl_issues_the_faster_form():

@@ -1,6 +1,7 @@
 """Diagnostic: the 4-wave form of the 256x256 tile (gemm4_kernel: one wave per SIMD, 128x128 outputs per wave, accumulators in
 AGPRs; gemm_tile 4) against the 2-stage 128x128 tile -- bit for bit, over repeated launches -- before tools/bench_gemm.py
-(BENCH_SET=w4) times it against the 8-wave kernel."""
+(BENCH_SET=w4) times it against the 8-wave kernel.  The kernel lives in the ATTRIBUTION build only:
+    make -C real-time-deepfake-speech-detection_amd/csrc attr && AFX_LIB=real-time-deepfake-speech-detection_amd/lib/libafx_attr.so python tools/diag_gemm4.py"""
 import math
 import os
 import sys

@@ -24,6 +24,13 @@ PY
     s3knobs) timeout -k 10 400 python tools/diag_s3_knobs.py > $O/s3_knobs.txt 2>&1; cut -c1-500 $O/s3_knobs.txt;;
     gemm4) timeout -k 10 300 python tools/diag_gemm4.py > $O/gemm4_identity.txt 2>&1; rc=$?; cat $O/gemm4_identity.txt | grep -v amdgpu.ids; if [ $rc -ne 0 ]; then echo "gemm4 identity failed (rc $rc): no timing"; else BENCH_SET=w4 timeout -k 10 600 python tools/bench_gemm.py > $O/gemm4_ab.txt 2>&1; grep -v amdgpu.ids $O/gemm4_ab.txt | cut -c1-300; fi;;
     newtests) timeout -k 10 1000 python -m pytest tests -m gpu -q --timeout 600 -k "deep_tile or overlaps_the_backend or test_gpu_bench or outlier or per_engine or forward_hooks or full_depth" > $O/pytest_new.log 2>&1; tail -8 $O/pytest_new.log | cut -c1-300;;
+    stale) timeout -k 10 300 python tools/diag_s3_stale.py > $O/s3_stale.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/s3_stale.txt | cut -c1-300;;
+    headrace) timeout -k 10 300 python tools/diag_head_race.py > $O/head_race.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/head_race.txt | cut -c1-300;;
+    guard) timeout -k 10 300 python tools/diag_ws_guard.py > $O/ws_guard.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/ws_guard.txt | cut -c1-300;;
+    bisect) for k in 1 2 3 5 8 9 10 0; do timeout -k 10 100 python tools/diag_two_stream_which.py fp16x3 $k 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(\|   batch" | cut -c1-260 | tee -a $O/bisect.txt; done;;
+    which1) timeout -k 10 300 python tools/diag_two_stream_which.py fp16x3 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(\|workspace bytes differ" | cut -c1-330 | tee $O/which1.txt;;
+    which) for d in fp16x3 fp16; do timeout -k 10 200 python tools/diag_two_stream_which.py $d 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-400 | tee -a $O/two_stream_which.txt; done;;
+    conv0race) timeout -k 10 200 python tools/diag_conv0_race.py 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-300 | tee $O/conv0_race.txt;;
     *) echo "unknown step $step";;
   esac
 done
