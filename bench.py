@@ -289,6 +289,7 @@ def main():
                     help="fp16 (default; no environment override) / bf16 matrix-core operands, fp32 = exact mode, fp16x3 = split precision")
     ap.add_argument("--cpu-sample", type=int, default=8, help="utterances timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="back-end on the trunk's stream (no head / trunk overlap across steps)")
+    ap.add_argument("--force-overlap", action="store_true", help="issue the two-stream form without the probe (diagnostics: tools/diag_queue_cliff.sh)")
     ap.add_argument("--no-config3", action="store_true", help="skip the teacher (BASELINE configs[2]/[3]) side measurement")
     ap.add_argument("--allow-parity-miss", action="store_true", help="report, do not fail, when the parity sample misses 1e-3")
     args = ap.parse_args()
@@ -348,6 +349,8 @@ def main():
         one is what the timed region issues.  Returns (overlapped, probe)."""
         if args.no_overlap:
             return False, None
+        if args.force_overlap:
+            return True, None
         if not w["eng"].overlap_is_bit_stable:  # teacher in fp16x3: Engine.forward_overlapped runs on one stream (engine.py)
             return False, {"issued": "one_stream", "note": "the two-stream step is disabled for the AASIST back-end in fp16x3: it was "
                            "measured not to reproduce the one-stream bits (profiles/r04_two_stream_race.txt, DESIGN.md section 7)"}
