@@ -89,17 +89,21 @@ class IncrementalScorer(SlidingWindowScorer):
     window % hop == 0, and an engine built without fused pre-emphasis (the reference's scoring loop applies none,
     main.py:208-214; its reflect pad at the window's first sample would make frame 0 window-dependent)."""
 
+    _exact_conv_ok = False  # fp32 / fp16x3 engines: only the KV-cached subclass (it never calls the strided tail entry point)
+
     def __init__(self, engine, state_dict, n_streams, window=64000, hop=4000):
         super().__init__(engine, n_streams, window, hop, device=engine.device)
         if hop % 160 or window % hop:
             raise ValueError("exact reuse needs hop % 160 == 0 (the stride of conv layer 5) and window % hop == 0")
-        if engine.dtype in ("fp32", "fp16x3"):
+        if engine.dtype in ("fp32", "fp16x3") and not self._exact_conv_ok:
             raise ValueError("the incremental scorer runs the half-precision conv kernels (fp16 / bf16 engines)")
         if getattr(engine, "extractor_mode", "layer_norm") != "layer_norm":
             raise ValueError("the group-norm extractor normalises layer 0 over the whole window: nothing is reusable")
         if getattr(engine, "pre_emphasis", False):
             raise ValueError("engine-side pre-emphasis makes the window's first frame position-dependent: not reusable")
-        self.eng, self.dt = engine, engine.dtype
+        # (an fp16x3 engine's conv feature extractor runs here as it does inside the engine's exact path: fp32 operands on the
+        # fp32 matrix instruction + a LayerNorm pass -- a dozen new frames per hop, its cost does not matter)
+        self.eng, self.dt = engine, ("fp32" if engine.dtype in ("fp32", "fp16x3") else engine.dtype)
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         pre = "ssl_model.model.feature_extractor.conv_layers."
         dev = engine.device
@@ -151,10 +155,20 @@ class IncrementalScorer(SlidingWindowScorer):
             if i == 0:
                 y = K.conv0_packed(self.dt, xin, self.pack0, self.w0, self.cb[0], self.lg[0], self.lb[0])
             else:
-                _, y = K.conv_ln_act(self.dt, xin, self.cw[i], k, s, self.cb[i], self.lg[i], self.lb[i], out_f=False, out_h=True)
+                y = self._conv_ln_gelu(xin, self.cw[i], k, s, self.cb[i], self.lg[i], self.lb[i])
             if i < 5:
                 x = torch.cat([self.carry[i + 1], y], dim=1)
         return y
+
+    def _conv_ln_gelu(self, xin, wp, k, s, bias, gamma, beta, fp32_out=False):
+        """Conv1d(512 -> 512) + LayerNorm + GELU on (S, Tin, 512) frames: one fused kernel for the half-precision operand types;
+        product + LayerNorm pass for fp32 operands (the exact path of the engine)."""
+        if self.dt == "fp32":
+            y = K.conv_gemm("fp32", xin, wp, k, s, bias=bias)
+            of, _ = K.rownorm("fp32", y.reshape(-1, 512), gamma, beta, act="gelu", out_f=True)
+            return of.reshape(y.shape)
+        of, oh = K.conv_ln_act(self.dt, xin, wp, k, s, bias, gamma, beta, out_f=fp32_out, out_h=not fp32_out)
+        return of if fp32_out else oh
 
     def _push(self, chunk):
         self._store(chunk)
@@ -184,7 +198,11 @@ class KVCachedScorer(IncrementalScorer):
     Conv layers 0-5 advance exactly as in IncrementalScorer; layer 6 advances the same way (its stride-2 window over
     the layer-5 frames carries 0 or 1 frame between hops), giving the 12 or 13 new frames a 250-ms chunk completes."""
 
+    _exact_conv_ok = True  # dtype "fp16x3": every hop within 1e-3 of the offline restatement whatever the top-k gaps (round 4)
+
     def __init__(self, engine, state_dict, n_streams, window=64000, hop=4000):
+        if engine.dtype == "fp32":
+            raise ValueError("the KV-cached mode runs fp16 / bf16 / fp16x3 engines")
         super().__init__(engine, state_dict, n_streams, window, hop)
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         pre = "ssl_model.model.feature_extractor.conv_layers.6."
@@ -209,7 +227,7 @@ class KVCachedScorer(IncrementalScorer):
         self.carry6 = x[:, n_out * 2:].contiguous()
         if n_out == 0:
             return None
-        f6, _ = K.conv_ln_act(self.dt, x[:, : n_out * 2].contiguous(), self.cw6, 2, 2, self.cb6, self.lg6, self.lb6, out_f=True, out_h=False)
+        f6 = self._conv_ln_gelu(x[:, : n_out * 2].contiguous(), self.cw6, 2, 2, self.cb6, self.lg6, self.lb6, fp32_out=True)
         self.frames += n_out
         return self.kv.step(f6)[:, 1]
 

@@ -300,13 +300,18 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 4 : 2) void mhsa_kernel(const typ
 // Same work split, masks and softmax as mhsa_kernel; one workgroup per CU (114 KB of LDS: two K images, two V^T images).
 // It replaces the fp32 VALU attention in that mode (93 -> ~20 us per layer at B = 16); exact mode ("fp32") keeps the VALU kernel.
 // ---------------------------------------------------------------------------------------
-template <int KS, int NW>
+// RING (round 4; the KV-cached streaming mode in dtype "fp16x3" -- NOT a reference function, see mhsa_kernel's RING): `qkv` is the
+// per-stream ring of 256 fp32 [q | k | v] slots in 16-slot groups; the ONE query tile ring.q_tile attends to every valid slot.
+template <int KS, int NW, bool RING = false>
 __global__ __launch_bounds__(64 * NW, 2) void mhsa_split_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int H,
-                                                                 float scale, const int* __restrict__ lens, int out_pairs, float out_scale) {
+                                                                 float scale, const int* __restrict__ lens, int out_pairs, float out_scale,
+                                                                 MhsaRing ring) {
   typedef _Float16 Tt;
   typedef f16x8 V8;
   typedef f16x4 V4;
   constexpr int NKT = KS * 2, KEYS = KS * 32;
+  constexpr int ATT_KEYS = KS <= 7 ? afx::ATT_KEYS : KS * 32;                 // (8 steps = the ring's 256 slots)
+  constexpr int ATT_VT_STRIDE = KS <= 7 ? afx::ATT_VT_STRIDE : KS * 32 + 8;
   __shared__ __attribute__((aligned(16))) char k_lds[2][ATT_KEYS * 128];        // [hi / lo][key][64 halfs], swizzled rows
   __shared__ __attribute__((aligned(16))) Tt vt_lds[2][64 * ATT_VT_STRIDE];     // [hi / lo][dim][key]
   __shared__ __attribute__((aligned(16))) float mask_lds[ATT_KEYS];
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mhsa_split_kernel(const float* __r
     for (int idx = tid; idx < KEYS * 8; idx += NT) {
       const int key = idx >> 3, c = idx & 7;
       f32x4 k0 = f32x4{0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
-      if (key < T) {
+      if (RING ? (key & 15) < ring.cnt[(key >> 4) & 15] : key < T) {
         k0 = *(const f32x4*)(kbase + (long)key * ld + c * 8);
         k1 = *(const f32x4*)(kbase + (long)key * ld + c * 8 + 4);
         v0 = *(const f32x4*)(vbase + (long)key * ld + c * 8);
@@ -352,13 +357,13 @@ __global__ __launch_bounds__(64 * NW, 2) void mhsa_split_kernel(const float* __r
       }
     }
   }
-  for (int i = tid; i < KEYS; i += 64 * NW) mask_lds[i] = i < T ? 0.f : -1e30f;
+  for (int i = tid; i < KEYS; i += 64 * NW) mask_lds[i] = (RING ? (i & 15) < ring.cnt[(i >> 4) & 15] : i < T) ? 0.f : -1e30f;
   __syncthreads();
   const int ql = lane & 15, g = lane >> 4;
   const int nqt_all = (T + 15) >> 4;
   const int per_z = (nqt_all + (int)gridDim.z - 1) / (int)gridDim.z;
-  const int qt_first = (int)blockIdx.z * per_z;
-  const int nqt = min(nqt_all, qt_first + per_z);
+  const int qt_first = RING ? ring.q_tile : (int)blockIdx.z * per_z;
+  const int nqt = RING ? ring.q_tile + 1 : min(nqt_all, qt_first + per_z);
   for (int qt = qt_first + wave; qt < nqt; qt += NW) {
     const int q0 = qt * 16;
     int qrow = q0 + ql;
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mhsa_split_kernel(const float* __r
     }
     const int q = q0 + ql;
     if (q < T) {
-      const long eoff = ((long)b * Trow + q) * (H * 64) + h * 64;
+      const long eoff = (RING ? (long)b * 16 + (q - 16 * ring.q_tile) : (long)b * Trow + q) * (H * 64) + h * 64;
       if (out_pairs) {  // the output projection's A operand: the pair form of out_scale x value in place of the fp32 row
         _Float16* hp = (_Float16*)out + 2 * eoff;  // (eoff % 64 == 0: a head's 64 columns are two whole 32-element groups)
 #pragma unroll
@@ -677,9 +682,26 @@ const char* launch_mhsa_split(const float* qkv, float* out, int B, int T, int H,
   if (T <= 0 || T > ATT_KEYS || B <= 0 || B > 65535 || H <= 0) return "mhsa_split: 1..224 frames";
   const float scale = 0.125f;
   dim3 grid(H, B, (long)H * B < 256 && T > 64 ? 2 : 1);
-  if (T <= 64) hipLaunchKernelGGL((mhsa_split_kernel<2, 4>), grid, dim3(256), 0, s, qkv, out, T, H, scale, lens, out_pairs ? 1 : 0, out_scale);
-  else if (T <= 128) hipLaunchKernelGGL((mhsa_split_kernel<4, 4>), grid, dim3(256), 0, s, qkv, out, T, H, scale, lens, out_pairs ? 1 : 0, out_scale);
-  else hipLaunchKernelGGL((mhsa_split_kernel<7, 7>), grid, dim3(448), 0, s, qkv, out, T, H, scale, lens, out_pairs ? 1 : 0, out_scale);
+  const MhsaRing none = {};
+  if (T <= 64) hipLaunchKernelGGL((mhsa_split_kernel<2, 4>), grid, dim3(256), 0, s, qkv, out, T, H, scale, lens, out_pairs ? 1 : 0, out_scale, none);
+  else if (T <= 128) hipLaunchKernelGGL((mhsa_split_kernel<4, 4>), grid, dim3(256), 0, s, qkv, out, T, H, scale, lens, out_pairs ? 1 : 0, out_scale, none);
+  else hipLaunchKernelGGL((mhsa_split_kernel<7, 7>), grid, dim3(448), 0, s, qkv, out, T, H, scale, lens, out_pairs ? 1 : 0, out_scale, none);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// the ring form in split precision: fp32 [q | k | v] slots in, fp32 rows (or pair-form rows) out -- (S, 16, H*64)
+const char* launch_mhsa_ring_split(const float* ring, float* out, int S, int H, int q_tile, const int* cnt, hipStream_t s, bool out_pairs,
+                                   float out_scale) {
+  if (S <= 0 || S > 65535 || H <= 0 || q_tile < 0 || q_tile > 15) return "mhsa_ring: bad shape";
+  MhsaRing r;
+  r.q_tile = q_tile;
+  for (int i = 0; i < 16; ++i) {
+    if (cnt[i] < 0 || cnt[i] > 16) return "mhsa_ring: a group holds at most 16 frames";
+    r.cnt[i] = (unsigned char)cnt[i];
+  }
+  hipLaunchKernelGGL((mhsa_split_kernel<8, 4, true>), dim3(H, S, 1), dim3(256), 0, s, ring, out, 256, H, 0.125f, nullptr, out_pairs ? 1 : 0,
+                     out_scale, r);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

