@@ -555,7 +555,7 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
                             "final_layer_norm.weight", "final_layer_norm.bias"})
         if (need(h, L + k)) return 1;
     }
-    if (!gn && h->dt != AFX_DT_FP32) {  // conv layer 0 as the split-precision fp16 matrix-core operand
+    if (!gn && (h->dt != AFX_DT_FP32 || h->s3)) {  // conv layer 0 as the split-precision fp16 matrix-core operand
       if (!h->conv0pack && !(h->conv0pack = h->dalloc(conv0_pack_bytes()))) return fail("afx_finalize: device allocation failed");
       KOK(launch_conv0_pack(h->F("ssl.feature_extractor.conv_layers.0.0.weight"), h->F("ssl.feature_extractor.conv_layers.0.0.bias"),
                             h->conv0pack, s));
@@ -1035,6 +1035,17 @@ static int run_trunk(afx_engine* e, const float* wave, int B, int L, Ws& w, hipS
       if (gn)  // wav2vec2-base: GroupNorm over time per (utterance, channel), two passes over the cheap convolution
         return launch_conv0_groupnorm(wave, B, L, T[0], cf(0, ".0.weight"), cf(0, ".2.weight"), cf(0, ".2.bias"), kLnEps,
                                       w.gn_stats, w.bufA, dt, s);
+      if (e->s3) {  // split precision: the same matrix-core kernel as the fp16 engines; its rows leave as conv layer 1's pair-form operand
+        float sc = 0.f;
+        if (s3_ok(w.bufA)) {
+          sc = kS3ScaleBounded;  // (LayerNorm + GELU output: bounded by the LayerNorm's gains -- the scale finalize chose for it)
+          auto it = e->ln_scale.find(cf(0, ".2.1.weight"));
+          if (it != e->ln_scale.end()) sc = it->second;
+        }
+        s3_set(w.bufA, sc);
+        return launch_conv0(wave, B, L, T[0], cf(0, ".0.weight"), cf(0, ".0.bias"), cf(0, ".2.1.weight"), cf(0, ".2.1.bias"),
+                            e->cfg.pre_emphasis, e->cfg.pre_emphasis_coef, w.bufA, DT_FP16X3, s, e->conv0pack, sc);
+      }
       return launch_conv0(wave, B, L, T[0], cf(0, ".0.weight"), cf(0, ".0.bias"), cf(0, ".2.1.weight"),
                           cf(0, ".2.1.bias"), e->cfg.pre_emphasis, e->cfg.pre_emphasis_coef, w.bufA, dt, s, e->conv0pack);
     }));

@@ -261,13 +261,17 @@ __global__ __launch_bounds__(256) void conv0_pack_kernel(const float* __restrict
   }
 }
 
+// HT = F32T (round 4): the split-precision engines ("fp16x3") run this kernel too -- its products are hi / lo fp16 pairs already --
+// with the fp32-accurate erf-GELU and fp32 rows out, or, pair_scale > 0, the rows leave as conv layer 1's PAIR-FORM operand
+// (afx_kernels.h) scaled by that power of two: no fp32 round trip and no split launch over the stack's largest activation.
 template <class HT>
 __global__ __launch_bounds__(256, 2) void conv0_split_kernel(const float* __restrict__ wave, int L, int T0,
                                                           const _Float16* __restrict__ pack, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int pre_emph, float pre_coef,
-                                                          typename HT::T* __restrict__ out) {
+                                                          typename HT::T* __restrict__ out, float pair_scale) {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
+  constexpr bool F32 = std::is_same<T, float>::value;
   __shared__ float xs[C0M_FB * 5 + 16];
   __shared__ __attribute__((aligned(16))) _Float16 xop[C0M_FB * 32];  // per frame: the 32 k-values of its B operand
   __shared__ float Gs[C0M_FB];
@@ -372,16 +376,43 @@ __global__ __launch_bounds__(256, 2) void conv0_split_kernel(const float* __rest
           va[r] = fmaf(acc[2 * cp][r] * rstd, g0[r], b0[r]);
           vb[r] = fmaf(acc[2 * cp + 1][r] * rstd, g1[r], b1[r]);
         }
-        gelu_poly8(va, vb);
+        if constexpr (F32) {  // fp32 results: the fp32-accurate erf form (the polynomial is sized for fp16 outputs)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            va[r] = gelu_erf(va[r]);
+            vb[r] = gelu_erf(vb[r]);
+          }
+        } else {
+          gelu_poly8(va, vb);
+        }
       }
-      V8 h;
+      float w8[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va[r]), __float_as_uint(vb[r]), false, false);
-        h[r] = (T)__uint_as_float(sw[0]);
-        h[4 + r] = (T)__uint_as_float(sw[1]);
+        w8[r] = __uint_as_float(sw[0]);
+        w8[4 + r] = __uint_as_float(sw[1]);
       }
-      if (f < T0) *(V8*)(orow + cp * 32 + cb) = h;
+      if (f >= T0) continue;
+      if constexpr (F32) {
+        if (pair_scale > 0.f) {  // columns cp * 32 + cb .. + 7 of the row's pair form: inside one 32-element group
+          f16x8 hi, lo;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const float sv = w8[r] * pair_scale;
+            hi[r] = (_Float16)sv;
+            lo[r] = (_Float16)(sv - (float)hi[r]);
+          }
+          _Float16* hp = (_Float16*)orow + cp * 64 + cb;
+          *(f16x8*)hp = hi;
+          *(f16x8*)(hp + 32) = lo;
+          continue;
+        }
+      }
+      V8 h;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) h[r] = (T)w8[r];
+      *(V8*)(orow + cp * 32 + cb) = h;
     }
   }
 }
@@ -510,16 +541,24 @@ size_t conv0_groupnorm_stats_floats(int B, int T0) { return (size_t)B * (((size_
 
 const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w, const float* bias,
                          const float* gamma, const float* beta, int pre_emph, float pre_coef, void* out_h,
-                         int dtype, hipStream_t s, const void* wpack) {
+                         int dtype, hipStream_t s, const void* wpack, float pair_scale) {
   if (B <= 0 || L < 10 || T0 != (L - 10) / 5 + 1) return "conv0: bad shape";
+  if (dtype == DT_FP16X3) {  // the split-precision engines: fp32 rows (or conv layer 1's pair-form operand) out
+    if (!wpack) return "conv0 (fp16x3): the packed operand block is missing";
+    dim3 grid((T0 + C0M_FB - 1) / C0M_FB, B);
+    hipLaunchKernelGGL(conv0_split_kernel<F32T>, grid, dim3(256), 0, s, wave, L, T0, (const _Float16*)wpack, gamma, beta, pre_emph,
+                       pre_coef, (float*)out_h, pair_scale);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+  }
   if (dtype != DT_FP32 && g_conv0_mfma == 1 && wpack) {  // split precision on the fp16 matrix pipe (packed operand given)
     dim3 grid((T0 + C0M_FB - 1) / C0M_FB, B);
     if (dtype == DT_BF16)
       hipLaunchKernelGGL(conv0_split_kernel<BF16>, grid, dim3(256), 0, s, wave, L, T0, (const _Float16*)wpack, gamma, beta,
-                         pre_emph, pre_coef, (__bf16*)out_h);
+                         pre_emph, pre_coef, (__bf16*)out_h, 0.f);
     else
       hipLaunchKernelGGL(conv0_split_kernel<FP16>, grid, dim3(256), 0, s, wave, L, T0, (const _Float16*)wpack, gamma, beta,
-                         pre_emph, pre_coef, (_Float16*)out_h);
+                         pre_emph, pre_coef, (_Float16*)out_h, 0.f);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
   }

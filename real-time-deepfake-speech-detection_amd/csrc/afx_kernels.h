@@ -108,7 +108,9 @@ bool gemm_set_nodma(int v);     // timing-only knob (attribution build, -DAFX_AT
 // conv layer 0 (Cin=1,k=10,s=5) + LayerNorm(512) + erf-GELU; optional pre-emphasis.
 const char* launch_conv0(const float* wave, int B, int L, int T0, const float* w /*[512][10]*/,
                          const float* bias, const float* gamma, const float* beta, int pre_emph,
-                         float pre_coef, void* out_h, int dtype, hipStream_t s, const void* wpack = nullptr);
+                         float pre_coef, void* out_h, int dtype, hipStream_t s, const void* wpack = nullptr, float pair_scale = 0.f);
+// dtype DT_FP16X3 (the split-precision engines): the packed-operand kernel with fp32 rows out, or -- pair_scale > 0 -- the rows as conv
+// layer 1's pair-form operand scaled by that power of two
 // wpack: the layer's weights + bias as the split-precision fp16 MFMA operand (conv0_pack_bytes() bytes, built once per
 // checkpoint by launch_conv0_pack); with it the half-precision engines run the layer on the fp16 matrix pipe at fp32 accuracy
 size_t conv0_pack_bytes();

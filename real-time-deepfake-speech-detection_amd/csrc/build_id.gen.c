@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "5d02bacc80a6";
+const char afx_build_id_str[] = "712918d965bc";
