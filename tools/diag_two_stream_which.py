@@ -32,7 +32,7 @@ torch.cuda.synchronize()
 stop = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 l.afx_debug_set(b"aasist_stop", stop)
 print(f"back-end stops after stage {stop} (0 = whole back-end)", flush=True)
-for rep in range(3):
+for rep in range(int(os.environ.get('DIAG_PASSES', '3'))):
     for i in range(N):
         check(l.afx_trunk_forward(eng._h, ptr(waves[i]), B, L, ptr(slots[i]), nbytes, C.c_void_p(cur.cuda_stream)))
         ev = torch.cuda.Event()
