@@ -351,9 +351,9 @@ def main():
             return False, None
         if args.force_overlap:
             return True, None
-        if not w["eng"].overlap_is_bit_stable:  # teacher in fp16x3: Engine.forward_overlapped runs on one stream (engine.py)
-            return False, {"issued": "one_stream", "note": "the two-stream step is disabled for the AASIST back-end in fp16x3: it was "
-                           "measured not to reproduce the one-stream bits (profiles/r04_two_stream_race.txt, DESIGN.md section 7)"}
+        if not w["eng"].overlap_is_bit_stable:  # (a combination whose two-stream form does not reproduce the one-stream bits: engine.py)
+            return False, {"issued": "one_stream", "note": "the two-stream step is disabled for this engine: it was measured not to "
+                           "reproduce the one-stream bits (Engine.overlap_is_bit_stable, DESIGN.md section 7)"}
         n = max(args.warmup, 3)
         ms = {}
         for name, ov in (("two_stream", True), ("one_stream", False)):

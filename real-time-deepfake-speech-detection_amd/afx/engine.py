@@ -204,14 +204,16 @@ class Engine:
 
     @property
     def overlap_is_bit_stable(self):
-        """False for the ONE combination in which the two-stream step was measured not to reproduce the one-stream bits: the
-        teacher (AASIST back-end) in dtype "fp16x3".  There, with the back-end of batch i running beside it, the trunk of
-        batch i+1 computes ONE frame of conv layer 0 slightly differently in about a third of the batches (logits move by
-        1e-5 .. 6e-4, more where a GraphPool near-tie flips); not when every call is followed by a synchronise, not with
-        another engine's back-end beside it, not in fp16 / fp32, not with the Conformer head -- evidence and what was ruled
-        out (stale workspace, out-of-bounds writes, the back-end itself): profiles/r04_two_stream_race.txt; root cause open
-        (DESIGN.md section 7).  ``forward_overlapped`` runs this combination on one stream: the mode exists to be right."""
-        return not (self.arch == "xlsr_aasist" and self.dtype == "fp16x3")
+        """Whether ``forward_overlapped`` reproduces ``forward``'s bits for this engine (False: it runs on one stream).
+        History (round 4): the teacher (AASIST back-end) in dtype "fp16x3" did NOT -- with the back-end of batch i beside it,
+        the trunk of batch i+1 computed ONE frame of conv layer 0 differently in about a third of the batches
+        (profiles/r04_two_stream_race.txt: not stale memory, no out-of-bounds write, gone under a synchronise per call, the
+        back-end itself stable; root cause not identified).  The kernel that showed it, ``conv0_kernel<F32T>`` followed by a
+        split launch over its output, left the fp16x3 path when conv layer 0 moved to the matrix-core kernel that writes conv
+        layer 1's pair-form operand: 0 differences in 105 concurrent batches since (same tool), and 0 in 120 for the exact
+        mode, which still runs the VALU kernel.  Every combination is therefore True again; the property stays as the switch
+        a future finding flips, and tests/test_gpu_aasist.py compares 42 concurrent batches per combination on every run."""
+        return True
 
     def join(self):
         """Make torch's current stream wait for every back-end forward_overlapped has put on the side stream (and for

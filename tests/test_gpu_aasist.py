@@ -208,7 +208,7 @@ def test_teacher_to_student_layer_copy_like_main_kd():
     assert (got - ref).abs().max().item() <= 1e-3
 
 
-@pytest.mark.parametrize("dtype", ["fp16", "fp16x3"])
+@pytest.mark.parametrize("dtype", ["fp16", "fp16x3", "fp32"])
 @pytest.mark.parametrize("arch", ["xlsr_aasist", "conformer"])
 def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_path, arch, dtype):
     """main.py:199-221 scores batch after batch and reads the scores at the end; afx.harness.produce_evaluation_file issues
@@ -230,11 +230,11 @@ def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_p
         eng = engine.Engine("conformer", n_layers=2, dtype=dtype, conf_blocks=2)
         kw = dict(n_encoders=2)
     eng.load_state_dict(sd)
-    # (three times round the batch-size list: the one combination that is NOT bit-stable two-stream -- AASIST back-end in
-    # fp16x3, about one batch in three moved, profiles/r04_two_stream_race.txt -- runs one-stream inside forward_overlapped;
-    # every other combination gets 42 concurrent batches here to show it is)
+    # (three times round the batch-size list, twice: 42 concurrent batches per combination.  Round 4 found the AASIST back-end in
+    # fp16x3 NOT bit-stable here -- about one batch in three moved, profiles/r04_two_stream_race.txt -- while conv layer 0 of that
+    # mode was the exact path's VALU kernel + a split launch; since it runs the matrix-core kernel, 0 of 105)
     waves = [synth.waveforms(b, 16000, batch_idx=700 + i).cuda() for i, b in enumerate([5, 5, 5, 3, 7, 5, 1] * 3)]
-    assert eng.overlap_is_bit_stable == (not (arch == "xlsr_aasist" and dtype == "fp16x3"))
+    assert eng.overlap_is_bit_stable
     want = [eng.forward(w).clone() for w in waves]
     for _ in range(2):  # twice: the second pass starts from slots that have a pending head
         got = [eng.forward_overlapped(w) for w in waves]
