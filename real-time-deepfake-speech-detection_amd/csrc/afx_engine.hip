@@ -928,8 +928,7 @@ static const char* P_gemm(const GemmArgs& g_in, int dt, int groups, hipStream_t 
     // the result as the NEXT product's A operand, where only products read the buffer (pair-form rows in place of fp32 rows);
     // a LayerNorm epilogue bounds its output (the larger scale), anything else is unbounded in a trained checkpoint
     if (g.out_h) {
-      const bool pairs_out = s3_ok(g.out_h) && (g.N & 7) == 0 && (g.g_n & 7) == 0 && (g.ldo_h & 31) == 0 &&
-                             (g.act == ACT_NONE || g.act == ACT_GELU) && g.out_h != g.A;
+      const bool pairs_out = s3_ok(g.out_h) && (g.N & 7) == 0 && (g.g_n & 7) == 0 && (g.ldo_h & 31) == 0 && g.out_h != g.A;
       q.oh_pairs = pairs_out ? 1 : 0;
       q.oh_scale = g.ln_gamma ? kS3ScaleBounded : kS3ScaleFree;
       s3_set(g.out_h, pairs_out ? q.oh_scale : 0.f);
@@ -960,7 +959,7 @@ static void begin_call(afx_engine* e, const Ws* w) {
   t_ln_scale = &e->ln_scale;
   t_s3planes = w ? w->s3planes : nullptr;
   t_s3bytes = w ? w->s3bytes : 0;
-  if (w) s3_begin({w->bufA, w->bufB, w->feats_h, w->hbuf, w->att, w->ff, w->xpad, w->hc, w->ssl_h});
+  if (w) s3_begin({w->bufA, w->bufB, w->feats_h, w->hbuf, w->att, w->ff, w->xpad, w->hc, w->ssl_h, w->hid});
   else s3_begin({});
 }
 

@@ -1552,8 +1552,8 @@ static const char* check_gemm(const GemmArgs& p, int groups) {
   if (p.kchunk <= 0 || p.kchunk % 64) return "gemm: kchunk must be a positive multiple of 64";
   if (p.rpb <= 0) return "gemm: rows-per-batch must be positive";
   if (!p.out_f && !p.out_h) return "gemm: no output";
-  if (p.oh_pairs && (!p.k1 || (p.N & 7) || (p.g_n & 7) || (p.act != ACT_NONE && p.act != ACT_GELU) || (p.ldo_h & 31) || !p.out_h))
-    return "gemm: pair-form output goes with the lean split-precision epilogue (N % 8 == 0, no / GELU activation, row stride % 32 == 0)";
+  if (p.oh_pairs && (!p.k1 || (p.N & 7) || (p.g_n & 7) || (p.ldo_h & 31) || !p.out_h))
+    return "gemm: pair-form output goes with the wide-store split-precision epilogue (N % 8 == 0, row stride % 32 == 0)";
   if (p.k1) {
     if (p.k1 % 32 || p.K != 2 * p.k1 || !p.pre_scale || !(p.a_inv > 0.f) || (p.oh_pairs && !(p.oh_scale > 0.f)))
       return "gemm: split precision needs pair-form operands (K = 2 k1 halfs, k1 % 32 == 0), the column scales and the operand scales";

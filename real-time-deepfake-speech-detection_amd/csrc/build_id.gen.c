@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "712918d965bc";
+const char afx_build_id_str[] = "eebd15dbe0a7";
