@@ -1365,6 +1365,212 @@ static hipError_t launch_gemm4_t(const GemmArgs& p, int groups, hipStream_t s) {
   hipLaunchKernelGGL((gemm4_kernel<HT>), grid, dim3(256), lds, s, p);
   return hipGetLastError();
 }
+// gemm5_kernel: the 4-wave 256x256 tile again, this time built around BYTES IN FLIGHT.  gemm4_kernel above showed that the loop
+// is paced by how many operand bytes a CU has outstanding (64 KB: 1.83 us per K-tile, the 8-wave ring's 96 KB: 1.57, matrix pipe:
+// 0.98).  Here LDS is a ring of FIVE stages of one k-step each (32 k: [A 256 rows | B 256 rows] x 64 B = 32 KB), and a stage is
+// only in use while its fragments travel to registers -- the free arch VGPRs of the AGPR-accumulator wave hold the current and
+// the next k-step's fragments (128 registers) -- so three to four stages (96-128 KB per CU) are in flight at any time.
+//   k-step t (64 MFMAs per wave on F(t), in registers):
+//     vmcnt: stage t+1 has landed (stages t+2, t+3 stay in flight)   s_barrier: ... for every wave; stage t-1 is free
+//     behind MFMAs 0..15: the 16 fragment reads of F(t+1)            behind MFMAs 16..23: the 8 LDS-DMA pieces of stage t+4 (into t-1's slot)
+// 64-byte LDS rows: chunk c of row r at slot c ^ ((r >> 1) & 3) -- conflict-free for ds_read_b128's lane groups (brute-forced).
+// Same k order per output element as every other tile.  Plain K, fp16 / bf16, 256-row tiles.  Attribution build (make attr).
+template <class HT>
+__global__ __launch_bounds__(256) void gemm5_kernel(GemmArgs p) {
+  typedef typename HT::T T;
+  typedef typename HT::V8 V8;
+  constexpr int NST = 5, STAGE = 512 * 64, NP = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int g = blockIdx.z;
+  const T* Ag = (const T*)p.A + (long)g * p.g_a;
+  const T* Wg = (const T*)p.W + (long)g * p.g_w;
+  const int nN = (p.N + 255) / 256, nM = (p.M + 255) / 256;
+  const int nwg = nM * nN;
+  const int nks = p.K >> 5;  // k-steps of 32
+  const T* src[NP];
+  int m0 = 0, n0 = 0;
+  auto setup = [&](int v) {
+    int pm, pn;
+    int L = v;
+    if (p.map_mode >= 1) {
+      const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    }
+    if (p.map_mode == 2) {
+      constexpr int GM = 8;
+      const int width = GM * nN, grp = L / width, first = grp * GM;
+      const int gsz = nM - first < GM ? nM - first : GM;
+      pm = first + (L % width) % gsz;
+      pn = (L % width) / gsz;
+    } else {
+      pm = L / nN;
+      pn = L % nN;
+    }
+    m0 = pm * 256;
+    n0 = pn * 256;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int row = (i * 4 + wave) * 16 + (lane >> 2);  // row of the stage: < 256 A, else B (pieces i < 4 are A rows)
+      const int c = (lane & 3) ^ ((row >> 1) & 3);
+      if (i < NP / 2) {
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        src[i] = Ag + (long)(m / p.rpb) * p.a_batch + (long)(m % p.rpb) * p.a_row + c * 8;
+      } else {
+        int n = n0 + row - 256;
+        n = n < p.N ? n : p.N - 1;
+        src[i] = Wg + (long)n * p.ldw + c * 8;
+      }
+    }
+  };
+  const unsigned lds_base = (unsigned)(size_t)smem;
+  auto dma16 = [&](const T* s_, unsigned lds_off) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + lds_off);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(s_), "s"(dst) : "memory");
+  };
+  auto dma_one = [&](int st, int ks, int i) { dma16(src[i] + (long)ks * 32, st * STAGE + (i * 4 + wave) * 1024); };
+  auto issue_stage = [&](int st, int ks) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) dma_one(st, ks, i);
+  };
+  const int frow = lane & 15, kq = lane >> 4;
+  const int slot = (kq ^ ((frow >> 1) & 3)) * 16;
+  const char* aR = smem + (wr * 128 + frow) * 64 + slot;
+  const char* bR = smem + (256 + wc * 128 + frow) * 64 + slot;
+  auto read_one = [&](int st, int q, V8 (&af)[8], V8 (&wf)[8]) {  // q = 0..7 B fragments, 8..15 A fragments
+    if (q < 8) wf[q] = *(const V8*)(bR + st * STAGE + q * (16 * 64));
+    else af[q - 8] = *(const V8*)(aR + st * STAGE + (q - 8) * (16 * 64));
+  };
+  f32x4 acc[8][8];
+#define AFX_BAR5()                         \
+  do {                                     \
+    __builtin_amdgcn_sched_barrier(0);     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_s_barrier();          \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+  // one k-step: 64 MFMAs on (fa, fw); behind them the reads of the next k-step's fragments into (na, nw) and the DMA of k-step t+4.
+  // MORE1 / MORE4 are compile-time (is there a k-step t+1 / t+4): the steady-state body carries no branch between its MFMAs
+  // (with run-time tests the compiler turned every slipped-in read / DMA into a branch and shuffled fragments through AGPRs).
+  auto kstep = [&](auto more1_c, auto more4_c, int behind, int t, int rd, int wrs, const V8 (&fa)[8], const V8 (&fw)[8], V8 (&na)[8],
+                   V8 (&nw)[8]) {
+    constexpr bool MORE1 = decltype(more1_c)::value, MORE4 = decltype(more4_c)::value;
+    if constexpr (MORE1) {
+      if constexpr (MORE4) wait_vmcnt<2 * NP>();  // stage t+1 has landed; t+2, t+3 stay in flight
+      else if (behind >= 2) wait_vmcnt<2 * NP>();
+      else if (behind == 1) wait_vmcnt<NP>();
+      else wait_vmcnt<0>();
+      AFX_BAR5();  // ... for every wave; every wave is done with stage t-1 (its fragments were consumed in k-step t-1)
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc[i][j] = HT::mfma(fw[j], fa[i], acc[i][j]);
+        const int q = i * 8 + j;
+        if (q < 16) {
+          if constexpr (MORE1) read_one(rd, q, na, nw);
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (q < 16 + NP) {
+          if constexpr (MORE4) dma_one(wrs, t + 4, q - 16);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int v = blockIdx.x;
+  setup(v);
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < nks) issue_stage(st, st);
+  bool first = true;
+  for (;;) {
+    if (first) {  // stage 0 has landed; up to three more stages in flight
+      const int inflight = (nks < NST - 1 ? nks : NST - 1) - 1;
+      if (inflight >= 3) wait_vmcnt<3 * NP>();
+      else if (inflight == 2) wait_vmcnt<2 * NP>();
+      else if (inflight == 1) wait_vmcnt<NP>();
+      else wait_vmcnt<0>();
+    } else {
+      wait_vmcnt<0>();  // (later output tiles: the epilogue's stores sit behind the prologue's DMAs in the queue)
+    }
+    first = false;
+    AFX_BAR5();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) the compiler can see (keeps its own vmcnt(0) out of the loop; as in gemm8_kernel)
+    V8 fa0[8], fw0[8], fa1[8], fw1[8];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) read_one(0, q, fa0, fw0);
+    int rd = 1, wrs = NST - 1;  // slot of k-step t+1 (read next); slot of k-step t+4 (written next) = the slot of k-step t-1
+    auto adv = [&] {
+      rd = rd + 1 == NST ? 0 : rd + 1;
+      wrs = wrs + 1 == NST ? 0 : wrs + 1;
+    };
+    const std::true_type Y{};
+    const std::false_type N_{};
+    int t = 0;
+    // steady state, two k-steps per iteration (the two fragment sets swap roles): every k-step has a t+1 and a t+4
+    for (; t + 5 < nks; t += 2) {
+      kstep(Y, Y, 2, t, rd, wrs, fa0, fw0, fa1, fw1);
+      adv();
+      kstep(Y, Y, 2, t + 1, rd, wrs, fa1, fw1, fa0, fw0);
+      adv();
+    }
+    // tail (nks is even: K % 64 == 0): the remaining k-steps in pairs, no more DMA once t + 4 >= nks
+    for (; t < nks; t += 2) {
+      if (t + 4 < nks) kstep(Y, Y, 2, t, rd, wrs, fa0, fw0, fa1, fw1);
+      else kstep(Y, N_, nks - 2 - t, t, rd, wrs, fa0, fw0, fa1, fw1);
+      adv();
+      if (t + 2 < nks) {
+        if (t + 5 < nks) kstep(Y, Y, 2, t + 1, rd, wrs, fa1, fw1, fa0, fw0);
+        else kstep(Y, N_, nks - 3 - t, t + 1, rd, wrs, fa1, fw1, fa0, fw0);
+      } else {
+        kstep(N_, N_, 0, t + 1, rd, wrs, fa1, fw1, fa0, fw0);
+      }
+      adv();
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    AFX_BAR5();  // every wave is done reading: the next output tile's DMA may overwrite the ring
+    const int m0c = m0, n0c = n0;
+    const int vn = v + gridDim.x;
+    if (vn < nwg) {
+      setup(vn);
+#pragma unroll
+      for (int st = 0; st < NST - 1; ++st)
+        if (st < nks) issue_stage(st, st);
+    }
+    gemm_epilogue<HT, 256, 256, 2, 2, false, true, false>(p, acc, smem, m0c, n0c, g);
+    if (vn >= nwg) break;
+    v = vn;
+  }
+#undef AFX_BAR5
+}
+
+template <class HT>
+static hipError_t launch_gemm5_t(const GemmArgs& p, int groups, hipStream_t s) {
+  constexpr int lds = 5 * 512 * 64;
+  static LdsLimit lim;
+  if (hipError_t e = lim.ensure((const void*)gemm5_kernel<HT>, lds); e != hipSuccess) return e;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorInvalidDevice;
+  cus &= ~7;
+  if (cus < 8) cus = 8;
+  const int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256);
+  dim3 grid(tiles < cus ? tiles : cus, 1, groups);
+  hipLaunchKernelGGL((gemm5_kernel<HT>), grid, dim3(256), lds, s, p);
+  return hipGetLastError();
+}
 #endif  // AFX_ATTR
 
 template <class HT, int BM, int BN, int WR, int WC, bool ROWLN = false, bool LEAN = false, bool S3 = false>
@@ -1659,6 +1865,7 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
 #endif
 #ifdef AFX_ATTR
   if (g_tile_override == 4) return plain_k(p) && !p.k1 && (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0 ? 4 : 0;  // 4-wave 256x256 (A/B)
+  if (g_tile_override == 10) return plain_k(p) && !p.k1 && (p.act == ACT_NONE || p.act == ACT_GELU) && (p.N & 7) == 0 ? 5 : 0;  // ... with the 5-stage ring
 #endif
   if (g_tile_override == 3) return plain_k(p) ? 7 : 0;  // 8-phase 256x256
   if (g_tile_override >= 0) return g_tile_override == 1 ? 2 : 0;
@@ -1699,6 +1906,7 @@ static hipError_t dispatch(const GemmArgs& p, int tile, int groups, hipStream_t 
     case 92: return launch_gemm_deep_t<HT, 128, 64, 2, 2, 3>(p, groups, s);
 #ifdef AFX_ATTR
     case 4: return launch_gemm4_t<HT>(p, groups, s);
+    case 5: return launch_gemm5_t<HT>(p, groups, s);
 #endif
     case 7:
       if (g_ph4 == 0) return launch_gemm8_t<HT, 256, 256, false, 8, 3>(p, groups, s);  // default: the three-buffer ring form

@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "eebd15dbe0a7";
+const char afx_build_id_str[] = "951c13367211";

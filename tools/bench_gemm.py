@@ -34,7 +34,8 @@ SHAPES = [
 SETS = {
     "tile": [("128x128", ("gemm_tile", 0)), ("256x256", ("gemm_tile", 1))],
     "8ph": [("128x128", ("gemm_tile", 0)), ("256x256 2-stage", ("gemm_tile", 1)), ("256x256 8-phase", ("gemm_tile", 3))],
-    "w4": [("default dispatch", ("gemm_tile", -1)), ("8-phase 256-wide (fitted)", ("gemm_tile", 3)), ("4-wave 256x256 (AGPR acc)", ("gemm_tile", 4))],
+    "w4": [("default dispatch", ("gemm_tile", -1)), ("8-phase 256-wide (fitted)", ("gemm_tile", 3)), ("4-wave 256x256 (AGPR acc)", ("gemm_tile", 4)),
+           ("4-wave, 5-stage ring", ("gemm_tile", 10))],
     "small": [("default", ("gemm_tile", -1)), ("128x128", ("gemm_tile", 0)), ("128x64", ("gemm_tile", 5)), ("8-phase 256x256", ("gemm_tile", 3))],
     "split": [("single kernel", ("gemm_split", 0)), ("rounds + remainder", ("gemm_split", 1))],
     "map": [("map0", ("gemm_map", 0)), ("map1", ("gemm_map", 1)), ("map2", ("gemm_map", 2))],

@@ -22,12 +22,13 @@ for M, N, K_ in ((1000, 768, 64), (515, 512, 192), (300, 256, 128), (2048, 1024,
     R = torch.randn(M, N, generator=g).cuda()
     check(lib().afx_debug_set(b"gemm_tile", 0))
     want_f, want_h = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
-    check(lib().afx_debug_set(b"gemm_tile", 4))
-    same = True
-    for _ in range(8):
-        got_f, got_h = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
-        same = same and torch.equal(got_f, want_f) and torch.equal(got_h, want_h)
-    check(lib().afx_debug_set(b"gemm_tile", -1))
-    print(f"M {M} N {N} K {K_}: 4-wave tile bit-identical to the 2-stage tile over 8 launches: {same}" + ("" if same else f"  max |d| {(got_f - want_f).abs().max().item():.3e}"), flush=True)
-    ok = ok and same
+    for tile, name in ((4, "4-wave tile (two K-tile buffers)"), (10, "4-wave tile (5-stage ring)")):
+        check(lib().afx_debug_set(b"gemm_tile", tile))
+        same = True
+        for _ in range(8):
+            got_f, got_h = K.gemm("fp16", A, W, bias=bias, act="gelu", resid=R, out_f=True, out_h=True)
+            same = same and torch.equal(got_f, want_f) and torch.equal(got_h, want_h)
+        check(lib().afx_debug_set(b"gemm_tile", -1))
+        print(f"M {M} N {N} K {K_}: {name} bit-identical to the 2-stage tile over 8 launches: {same}" + ("" if same else f"  max |d| {(got_f - want_f).abs().max().item():.3e}"), flush=True)
+        ok = ok and same
 sys.exit(0 if ok else 1)
