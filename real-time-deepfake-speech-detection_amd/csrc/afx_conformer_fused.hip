@@ -66,26 +66,48 @@ struct ChunkDesc {  // NT x KS fragment blocks of matrix W: rows n0 .. n0 + 16 N
 };
 
 // the static weight-chunk sequence of each chain (must match the compute order below)
-template <int STAGE>
+// Split precision (S3): the weights are the engine's pair-form rows (hi / lo halves interleaved per 32 k: 2 ldw halfs per row,
+// afx_kernels.h::s3_pair_index), a fragment block is 1 KB of hi + 1 KB of lo halves, and a chunk is ONE group of three output
+// tiles (<= 15 blocks x 2 = 30 of the 32 DMA slots): every chunk of the fp16 sequence becomes nt / 3 chunks.
+template <int STAGE, bool S3>
 __device__ __forceinline__ ChunkDesc chunk_of(const ConfChainArgs& p, int idx) {
-  auto ff = [&](int c) {  // 12 chunks: W1 part, W2 part, ...
-    const int part = c >> 1;
-    return (c & 1) ? ChunkDesc{p.ff_w2, p.FFp, 0, 3 * part, ET, 3} : ChunkDesc{p.ff_w1, p.Ep, part * HT6 * 16, 0, HT6, EK};
-  };
-  auto rows6 = [&](const void* W, int ld, int c, int tiles) {  // N = 16 tiles, six tiles per chunk (the last may be shorter)
-    const int left = tiles - 6 * c;
-    return ChunkDesc{W, ld, c * 96, 0, left < 6 ? left : 6, EK};
-  };
-  if constexpr (STAGE == 0) return idx < 12 ? ff(idx) : rows6(p.w_a, p.Ep, idx - 12, 3 * ET);
-  else if constexpr (STAGE == 1) return idx < 2 ? rows6(p.w_a, p.Ep, idx, ET) : rows6(p.w_b, p.Ep, idx - 2, 4 * ET);
-  else return idx < 3 ? ChunkDesc{p.w_a, p.ld_w_a, 0, 3 * idx, ET, 3} : ff(idx - 3);
+  if constexpr (S3) {
+    auto ff = [&](int c) {  // 30 chunks: per part W1 tiles 0-2, 3-5, then W2 tiles 0-2, 3-5, 6-8 of that part's 3 k-steps
+      const int part = c / 5, r = c - 5 * part;
+      return r < 2 ? ChunkDesc{p.ff_w1, p.Ep, part * HT6 * 16 + r * 48, 0, 3, EK} : ChunkDesc{p.ff_w2, p.FFp, (r - 2) * 48, 3 * part, 3, 3};
+    };
+    auto rows3 = [&](const void* W, int ld, int c) { return ChunkDesc{W, ld, c * 48, 0, 3, EK}; };
+    if constexpr (STAGE == 0) return idx < 30 ? ff(idx) : rows3(p.w_a, p.Ep, idx - 30);
+    else if constexpr (STAGE == 1) return idx < 3 ? rows3(p.w_a, p.Ep, idx) : rows3(p.w_b, p.Ep, idx - 3);
+    else return idx < 9 ? ChunkDesc{p.w_a, p.ld_w_a, (idx % 3) * 48, 3 * (idx / 3), 3, 3} : ff(idx - 9);
+  } else {
+    auto ff = [&](int c) {  // 12 chunks: W1 part, W2 part, ...
+      const int part = c >> 1;
+      return (c & 1) ? ChunkDesc{p.ff_w2, p.FFp, 0, 3 * part, ET, 3} : ChunkDesc{p.ff_w1, p.Ep, part * HT6 * 16, 0, HT6, EK};
+    };
+    auto rows6 = [&](const void* W, int ld, int c, int tiles) {  // N = 16 tiles, six tiles per chunk (the last may be shorter)
+      const int left = tiles - 6 * c;
+      return ChunkDesc{W, ld, c * 96, 0, left < 6 ? left : 6, EK};
+    };
+    if constexpr (STAGE == 0) return idx < 12 ? ff(idx) : rows6(p.w_a, p.Ep, idx - 12, 3 * ET);
+    else if constexpr (STAGE == 1) return idx < 2 ? rows6(p.w_a, p.Ep, idx, ET) : rows6(p.w_b, p.Ep, idx - 2, 4 * ET);
+    else return idx < 3 ? ChunkDesc{p.w_a, p.ld_w_a, 0, 3 * idx, ET, 3} : ff(idx - 3);
+  }
 }
-template <int STAGE> constexpr int kChunks = STAGE == 0 ? 12 + 5 : STAGE == 1 ? 2 + 6 : 3 + 12;
+template <int STAGE, bool S3> constexpr int kChunks = S3 ? (STAGE == 0 ? 30 + 9 : STAGE == 1 ? 3 + 12 : 9 + 30)
+                                                         : (STAGE == 0 ? 12 + 5 : STAGE == 1 ? 2 + 6 : 3 + 12);
 
-template <class HT, int STAGE>
+template <class HT, int STAGE, bool S3>
 struct Chain {
   typedef typename HT::T T;
   typedef typename HT::V8 V8;
+  // the A operand of one 32-wide k-step: this lane's 8 consecutive k; in split precision their hi and lo halves
+  // (x ~ h + l, |l| <= ulp(h) / 2: the product is h.wh + l.wh + h.wl, three matrix-core passes; `l` is untouched otherwise)
+  struct AF {
+    V8 h, l;
+  };
+  static constexpr int NCH = kChunks<STAGE, S3>;
+  static constexpr int PRM_PIECES = S3 ? 16 : 8;  // 1-KB pieces of the parameter block(s)
 
   const ConfChainArgs& p;
   int lane, wave, r16, kq, kb;
@@ -101,39 +123,44 @@ struct Chain {
     smem = lds;
     lds_base = (unsigned)(size_t)lds;
     prm = (const float*)(lds + PARAMS);
+    scl = prm + kChainParamFloats;
   }
-  const float* prm;
+  const float *prm, *scl;
 
   // ---- weight stream -------------------------------------------------------------------
   __device__ __forceinline__ void issue(int idx) {  // exactly 32 / NWAVE LDS-DMA instructions per wave
     if constexpr ((CHAIN_DBG & 1) != 0) {
       if (idx >= RING - 1) return;
     }
-    const ChunkDesc d = chunk_of<STAGE>(p, idx);
+    const ChunkDesc d = chunk_of<STAGE, S3>(p, idx);
     const int nb = d.nt * d.ks;
+    constexpr int KW = S3 ? 64 : 32;  // halfs per k-step in a weight row (pair form: 32 hi + 32 lo)
+    const long ldw = S3 ? 2L * d.ldw : d.ldw;
     const unsigned dst0 = lds_base + (idx & (RING - 1)) * BUFSZ;
-    const T* src0 = (const T*)d.W + (long)(d.n0 + r16) * d.ldw + d.k0 * 32 + kb;
+    const T* src0 = (const T*)d.W + (long)(d.n0 + r16) * ldw + d.k0 * KW + kb;
 #pragma unroll
     for (int i = 0; i < 32 / NWAVE; ++i) {
       const int b = i * NWAVE + wave;
-      const bool valid = b < nb;
-      const int j = d.ks == 3 ? (b * 11) >> 5 : (b * 13) >> 6;  // b / ks for b < 32, ks in {3, 5}
-      const int k = b - j * d.ks;
-      const T* src = valid ? src0 + (long)j * 16 * d.ldw + k * 32 : src0;
+      const bool lo = S3 && b >= nb;           // slots nb .. 2 nb - 1: the lo halves of blocks 0 .. nb - 1
+      const int blk = lo ? b - nb : b;
+      const bool valid = S3 ? b < 2 * nb : b < nb;
+      const int j = d.ks == 3 ? (blk * 11) >> 5 : (blk * 13) >> 6;  // blk / ks for blk < 32, ks in {3, 5}
+      const int k = blk - j * d.ks;
+      const T* src = valid ? src0 + (long)j * 16 * ldw + k * KW + (lo ? 32 : 0) : src0;
       unsigned keep;
       const unsigned dst = __builtin_amdgcn_readfirstlane(valid ? dst0 + b * 1024 : lds_base + DUMP);
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     }
   }
-  // The per-column vectors (biases, LayerNorm gamma/beta: one packed 8-KB block per chain) ride
-  // the same DMA stream -- one instruction per wave, first in the queue.  Nothing in the chain
+  // The per-column vectors (biases, LayerNorm gamma/beta: one packed 8-KB block per chain; split precision: a second
+  // 8-KB block with the weight rows' scales) ride the same DMA stream, first in the queue.  Nothing in the chain
   // is a compiler-visible global load: the DMAs are issued from inline asm, so a compiler wait
   // for one of its own loads would be vmcnt(0) and drain the weight ring every time (measured:
   // 36 us per chain with the bias vectors read from global inside the chain).
   __device__ __forceinline__ void prologue() {
 #pragma unroll
-    for (int pb = 0; pb < 8 / NWAVE; ++pb) {  // the 8-KB parameter block: 1-KB pieces
+    for (int pb = 0; pb < PRM_PIECES / NWAVE; ++pb) {  // 1-KB pieces
       unsigned keep;
       const int piece = pb * NWAVE + wave;
       const float* src = p.params + piece * 256 + lane * 4;
@@ -141,7 +168,7 @@ struct Chain {
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     }
-    static_assert(kChunks<STAGE> >= RING - 1 && 8 * 256 == kChainParamFloats, "prologue shape");
+    static_assert(NCH >= RING - 1 && 8 * 256 == kChainParamFloats && 8 * 256 == kChainScaleFloats, "prologue shape");
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i) issue(i);
     chain_wait_vmcnt<3 * DPW>();  // the parameter block (oldest) has landed; 3 chunks stay in flight
@@ -153,7 +180,7 @@ struct Chain {
   // lane's fragment base inside chunk i.
   __device__ __forceinline__ const char* next_chunk() {
     const int i = consumed++;
-    const int after = kChunks<STAGE> - 1 - i;  // chunks issued behind this one
+    const int after = NCH - 1 - i;  // chunks issued behind this one
     if constexpr ((CHAIN_DBG & 1) == 0) {
       if (after >= 2) chain_wait_vmcnt<2 * DPW>();
       else if (after == 1) chain_wait_vmcnt<DPW>();
@@ -161,7 +188,7 @@ struct Chain {
     }
     if constexpr ((CHAIN_DBG & 4) == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (i + RING - 1 < kChunks<STAGE>) issue(i + RING - 1);
+    if (i + RING - 1 < NCH) issue(i + RING - 1);
     return smem + (i & (RING - 1)) * BUFSZ + lane * 16;
   }
 
@@ -170,7 +197,7 @@ struct Chain {
   // wave of the SIMD fills the read latency.  The sched_barriers pin that shape: left alone,
   // hipcc emits read -> wait -> MFMA on one accumulator at a time.
   template <int NT, int KS, bool ACCUM>
-  __device__ __forceinline__ void gemm_impl(const V8* a, const char* wb, f32x4* acc) const {
+  __device__ __forceinline__ void gemm_impl(const AF* a, const char* wb, f32x4* acc) const {
     static_assert(NT % 3 == 0, "tiles are processed in groups of 3");
     constexpr int NG = NT / 3;
 #pragma unroll
@@ -189,40 +216,105 @@ struct Chain {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
           if constexpr ((CHAIN_DBG & 2) != 0) asm volatile("" :: "v"(w[t][k]));
-          else c[t] = HT::mfma(w[t][k], a[k], c[t]);
+          else c[t] = HT::mfma(w[t][k], a[k].h, c[t]);
         }
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[g * 3 + t] = c[t];
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  template <int NT, int KS>
-  __device__ __forceinline__ void gemm(const V8* a, const char* wb, f32x4* acc) const {
-    gemm_impl<NT, KS, false>(a, wb, acc);
+  // Split precision: ONE chunk = three output tiles, hi blocks (t KS + k) then lo blocks (3 KS + t KS + k).  k outside,
+  // the next k-step's six fragments (hi / lo of three tiles) are read under the nine MFMAs of this one -- the chain runs
+  // one wave per SIMD, nobody else covers the read latency.  Passes per k-step: wh.ah, wh.al, wl.ah, tiles inside.
+  template <int KS, bool ACCUM>
+  __device__ __forceinline__ void gemm3_split(const AF* a, const char* wb, f32x4* acc) const {
+    V8 wh[2][3], wl[2][3];
+    auto load = [&](int buf, int k) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        wh[buf][t] = *(const V8*)(wb + (t * KS + k) * 1024);
+        wl[buf][t] = *(const V8*)(wb + ((3 + t) * KS + k) * 1024);
+      }
+    };
+    f32x4 c[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) c[t] = ACCUM ? acc[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+    load(0, 0);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      if (k + 1 < KS) load((k + 1) & 1, k + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) c[t] = HT::mfma(wh[k & 1][t], a[k].h, c[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) c[t] = HT::mfma(wh[k & 1][t], a[k].l, c[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) c[t] = HT::mfma(wl[k & 1][t], a[k].h, c[t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = c[t];
   }
-  template <int NT, int KS>
-  __device__ __forceinline__ void gemm_acc(const V8* a, const char* wb, f32x4* acc) const {
-    gemm_impl<NT, KS, true>(a, wb, acc);
+  // acc[0 .. NT) (=|+=) A . W^T for the next NT output tiles of the weight stream (the chunk(s) are taken here)
+  template <int NT, int KS, bool ACCUM = false>
+  __device__ __forceinline__ void mm(const AF* a, f32x4* acc) {
+    if constexpr (S3) {
+#pragma unroll
+      for (int g = 0; g < NT / 3; ++g) gemm3_split<KS, ACCUM>(a, next_chunk(), acc + 3 * g);
+    } else {
+      gemm_impl<NT, KS, ACCUM>(a, next_chunk(), acc);
+    }
   }
   // N = 16 TILES output columns of a K = 160 product, six tiles per weight chunk
   template <int TILES>
-  __device__ __forceinline__ void gemm_rows6(const V8* a, f32x4* acc) {
+  __device__ __forceinline__ void gemm_rows6(const AF* a, f32x4* acc) {
 #pragma unroll
-    for (int c = 0; c < TILES / 6; ++c) gemm<6, EK>(a, next_chunk(), acc + 6 * c);
-    if constexpr (TILES % 6 != 0) gemm<TILES % 6, EK>(a, next_chunk(), acc + 6 * (TILES / 6));
+    for (int c = 0; c < TILES / 6; ++c) mm<6, EK>(a, acc + 6 * c);
+    if constexpr (TILES % 6 != 0) mm<TILES % 6, EK>(a, acc + 6 * (TILES / 6));
+  }
+  // split precision: the accumulators carry the weight rows' power-of-two scales; `off` = the scale of acc[0]'s column 0
+  template <int NT>
+  __device__ __forceinline__ void descale(f32x4* acc, int off) const {
+    if constexpr (S3) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] *= *(const f32x4*)(scl + off + j * 16 + kq * 4);
+    }
   }
 
   // ---- row math ------------------------------------------------------------------------
   // two adjacent accumulator tiles -> this lane's 8 consecutive k of the 32-wide step
-  __device__ __forceinline__ V8 pack_pair(f32x4 a, f32x4 b) const {
-    V8 h;
+  __device__ __forceinline__ AF pack_pair(f32x4 a, f32x4 b) const {
+    AF f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[r]), __float_as_uint(b[r]), false, false);
-      h[r] = (T)__uint_as_float(sw[0]);
-      h[4 + r] = (T)__uint_as_float(sw[1]);
+      const float u = __uint_as_float(sw[0]), v = __uint_as_float(sw[1]);
+      f.h[r] = (T)u;
+      f.h[4 + r] = (T)v;
+      if constexpr (S3) {
+        f.l[r] = (T)(u - (float)f.h[r]);
+        f.l[4 + r] = (T)(v - (float)f.h[4 + r]);
+      }
     }
-    return h;
+    return f;
+  }
+  // 8 consecutive k of an operand row as it lies in memory (split precision: fp32 values, split here)
+  __device__ __forceinline__ AF load_frag(const void* base, long row, long ld, int k0) const {
+    AF f;
+    if constexpr (S3) {
+      const float* src = (const float*)base + row * ld + k0;
+      const f32x4 u = *(const f32x4*)src, v = *(const f32x4*)(src + 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f.h[r] = (T)u[r];
+        f.h[4 + r] = (T)v[r];
+        f.l[r] = (T)(u[r] - (float)f.h[r]);
+        f.l[4 + r] = (T)(v[r] - (float)f.h[4 + r]);
+      }
+    } else {
+      f.h = *(const V8*)((const T*)base + row * ld + k0);
+    }
+    return f;
   }
   __device__ __forceinline__ void layernorm(const f32x4 (&x)[ET], const float* __restrict__ g, const float* __restrict__ b,
                                             f32x4 (&y)[ET]) const {
@@ -246,17 +338,28 @@ struct Chain {
       for (int r = 0; r < 4; ++r) y[j][r] = fmaf((x[j][r] - mean) * rstd, gg[r], bb[r]);
     }
   }
-  __device__ __forceinline__ void frags_of_rows(const f32x4 (&y)[ET], V8 (&a)[EK]) const {
+  __device__ __forceinline__ void frags_of_rows(const f32x4 (&y)[ET], AF (&a)[EK]) const {
 #pragma unroll
     for (int t = 0; t < 4; ++t) a[t] = pack_pair(y[2 * t], y[2 * t + 1]);
     a[4] = pack_pair(y[8], f32x4{0.f, 0.f, 0.f, 0.f});
   }
+  // split precision keeps fp32 accuracy in the activation too: v_exp + v_rcp + one Newton step (<= 1 ulp of the sigmoid)
+  static __device__ __forceinline__ float swish_of(float x) {
+    if constexpr (S3) {
+      const float d = 1.0f + __builtin_amdgcn_exp2f(fminf(x * -1.4426950408889634f, 126.0f));
+      float r = __builtin_amdgcn_rcpf(d);
+      r = fmaf(fmaf(-d, r, 1.0f), r, r);
+      return x * r;
+    } else {
+      return swish_fast(x);
+    }
+  }
 
-  // x += 1/2 (W2 swish(W1 LN(x) + b1) + b2): the macaron feed-forward half step (12 weight chunks)
+  // x += 1/2 (W2 swish(W1 LN(x) + b1) + b2): the macaron feed-forward half step (12 weight chunks; split precision: 30)
   __device__ __forceinline__ void feed_forward(f32x4 (&x)[ET]) {
     f32x4 y[ET];
     layernorm(x, prm + CP_FF_G, prm + CP_FF_B, y);
-    V8 a[EK];
+    AF a[EK];
     frags_of_rows(y, a);
     f32x4 o[ET];
 #pragma unroll
@@ -264,8 +367,9 @@ struct Chain {
 #pragma unroll
     for (int part = 0; part < 6; ++part) {
       f32x4 h[HT6];
-      gemm<HT6, EK>(a, next_chunk(), h);
-      V8 hf[3];
+      mm<HT6, EK>(a, h);
+      descale<HT6>(h, CS_FF1 + part * HT6 * 16);
+      AF hf[3];
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const int c0 = part * HT6 * 16 + t * 32 + kq * 4;
@@ -273,13 +377,14 @@ struct Chain {
         f32x4 u = h[2 * t] + ba, v = h[2 * t + 1] + bb;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          u[r] = swish_fast(u[r]);
-          v[r] = swish_fast(v[r]);
+          u[r] = swish_of(u[r]);
+          v[r] = swish_of(v[r]);
         }
         hf[t] = pack_pair(u, v);
       }
-      gemm_acc<ET, 3>(hf, next_chunk(), o);
+      mm<ET, 3, true>(hf, o);
     }
+    descale<ET>(o, CS_FF2);
 #pragma unroll
     for (int j = 0; j < ET; ++j) {
       const f32x4 bb = *(const f32x4*)(prm + CP_FF_B2 + j * 16 + kq * 4);
@@ -290,12 +395,12 @@ struct Chain {
 
 }  // namespace
 
-template <class HT, int STAGE>
+template <class HT, int STAGE, bool S3>
 __global__ __launch_bounds__(64 * NWAVE) void conf_chain_kernel(ConfChainArgs p) {
-  typedef typename HT::T T;
-  typedef typename HT::V8 V8;
+  typedef Chain<HT, STAGE, S3> C;
+  typedef typename C::AF AF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  Chain<HT, STAGE> c(p, smem);
+  C c(p, smem);
   // every wave takes part in the weight fills and barriers; rows past M are clamped and not stored
   const long row = ((long)blockIdx.x * NWAVE + c.wave) * 16 + c.r16;
   const bool ok = row < p.M;
@@ -304,17 +409,20 @@ __global__ __launch_bounds__(64 * NWAVE) void conf_chain_kernel(ConfChainArgs p)
   f32x4 x[ET];
 #pragma unroll
   for (int j = 0; j < ET; ++j) x[j] = *(const f32x4*)(p.x_in + rc * p.E + j * 16 + c.kq * 4);
-  V8 ain[ET];  // stage 1: attention output (5 k-steps), stage 2: depthwise-conv output (9 k-steps)
+  AF ain[ET];  // stage 1: attention output (5 k-steps), stage 2: depthwise-conv output (9 k-steps)
   if constexpr (STAGE != 0) {
 #pragma unroll
-    for (int t = 0; t < (STAGE == 1 ? EK : ET); ++t) ain[t] = *(const V8*)((const T*)p.in_h + rc * p.ld_in_h + t * 32 + c.kb);
+    for (int t = 0; t < (STAGE == 1 ? EK : ET); ++t) ain[t] = c.load_frag(p.in_h, rc, p.ld_in_h, t * 32 + c.kb);
   }
   // the row loads are consumed (compiler-placed waits) before the DMA stream starts
 #pragma unroll
   for (int j = 0; j < ET; ++j) asm volatile("" : "+v"(x[j]));
   if constexpr (STAGE != 0) {
 #pragma unroll
-    for (int t = 0; t < (STAGE == 1 ? EK : ET); ++t) asm volatile("" : "+v"(ain[t]));
+    for (int t = 0; t < (STAGE == 1 ? EK : ET); ++t) {
+      asm volatile("" : "+v"(ain[t].h));
+      if constexpr (S3) asm volatile("" : "+v"(ain[t].l));
+    }
   }
   c.prologue();
 
@@ -326,14 +434,16 @@ __global__ __launch_bounds__(64 * NWAVE) void conf_chain_kernel(ConfChainArgs p)
     }
     f32x4 y[ET];
     c.layernorm(x, c.prm + CP_LN2_G, c.prm + CP_LN2_B, y);
-    V8 a[EK];
+    AF a[EK];
     c.frags_of_rows(y, a);
     // q | k | v: 3 x 144 columns (27 tiles), no bias; six tiles per weight chunk, the last one three
 #pragma unroll
     for (int part = 0; part < 5; ++part) {
       f32x4 q[6];
-      if (part < 4) c.template gemm<6, EK>(a, c.next_chunk(), q);
-      else c.template gemm<3, EK>(a, c.next_chunk(), q);
+      if (part < 4) c.template mm<6, EK>(a, q);
+      else c.template mm<3, EK>(a, q);
+      if (part < 4) c.template descale<6>(q, CS_A + part * 96);
+      else c.template descale<3>(q, CS_A + part * 96);
       if (ok) {
 #pragma unroll
         for (int j = 0; j < (part < 4 ? 6 : 3); ++j) *(f32x4*)(p.out2 + row * p.ld_out2 + (part * 6 + j) * 16 + c.kq * 4) = q[j];
@@ -341,11 +451,12 @@ __global__ __launch_bounds__(64 * NWAVE) void conf_chain_kernel(ConfChainArgs p)
     }
   } else if constexpr (STAGE == 1) {
     // attention output (operand type, row stride ld_in_h, pad columns zero) -> out-projection
-    V8 a[EK];
+    AF a[EK];
 #pragma unroll
     for (int t = 0; t < EK; ++t) a[t] = ain[t];
     f32x4 o[ET];
     c.template gemm_rows6<ET>(a, o);
+    c.template descale<ET>(o, CS_A);
 #pragma unroll
     for (int j = 0; j < ET; ++j) x[j] += o[j] + *(const f32x4*)(c.prm + CP_BA + j * 16 + c.kq * 4);
     if (ok) {
@@ -359,7 +470,8 @@ __global__ __launch_bounds__(64 * NWAVE) void conf_chain_kernel(ConfChainArgs p)
 #pragma unroll
     for (int part = 0; part < 6; ++part) {
       f32x4 gl[6];
-      c.template gemm<6, EK>(a, c.next_chunk(), gl);
+      c.template mm<6, EK>(a, gl);
+      c.template descale<6>(gl, CS_B + part * 96);
       if (ok) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -370,12 +482,13 @@ __global__ __launch_bounds__(64 * NWAVE) void conf_chain_kernel(ConfChainArgs p)
     }
   } else {
     // depthwise-conv output (operand type, 288 columns) -> pointwise conv 2 -> residual
-    const V8* a = ain;
+    const AF* a = ain;
     f32x4 o[ET];
 #pragma unroll
     for (int j = 0; j < ET; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kc = 0; kc < 3; ++kc) c.template gemm_acc<ET, 3>(a + 3 * kc, c.next_chunk(), o);
+    for (int kc = 0; kc < 3; ++kc) c.template mm<ET, 3, true>(a + 3 * kc, o);
+    c.template descale<ET>(o, CS_A);
 #pragma unroll
     for (int j = 0; j < ET; ++j) x[j] += o[j] + *(const f32x4*)(c.prm + CP_BA + j * 16 + c.kq * 4);
     c.feed_forward(x);
@@ -388,24 +501,27 @@ __global__ __launch_bounds__(64 * NWAVE) void conf_chain_kernel(ConfChainArgs p)
   }
 }
 
-template <class HT, int STAGE>
+template <class HT, int STAGE, bool S3>
 static hipError_t launch_conf_chain_t(const ConfChainArgs& p, hipStream_t s) {
-  constexpr int lds = PARAMS + kChainParamFloats * 4;
+  constexpr int lds = PARAMS + (kChainParamFloats + (S3 ? kChainScaleFloats : 0)) * 4;
   static LdsLimit lim;
-  if (hipError_t e = lim.ensure((const void*)conf_chain_kernel<HT, STAGE>, lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((conf_chain_kernel<HT, STAGE>), dim3((unsigned)((p.M + 16 * NWAVE - 1) / (16 * NWAVE))), dim3(64 * NWAVE), lds, s, p);
+  if (hipError_t e = lim.ensure((const void*)conf_chain_kernel<HT, STAGE, S3>, lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((conf_chain_kernel<HT, STAGE, S3>), dim3((unsigned)((p.M + 16 * NWAVE - 1) / (16 * NWAVE))), dim3(64 * NWAVE), lds, s, p);
   return hipGetLastError();
 }
 
+// dtype DT_FP16X3: fp32 operand rows in (in_h), pair-form weights (+ the scale block behind the parameter block), fp32 out
 const char* launch_conf_chain(const ConfChainArgs& p, int stage, int dtype, hipStream_t s) {
   if (p.E != 16 * ET || p.Ep < 32 * EK || p.FFp != 4 * 16 * ET) return "conf_chain: the fused Conformer chains are built for emb 144 / ff 576";
   if (dtype == DT_FP32) return "conf_chain: half-precision operands only";
   if (p.M <= 0 || stage < 0 || stage > 2) return "conf_chain: bad arguments";
   hipError_t e;
-  if (dtype == DT_BF16)
-    e = stage == 0 ? launch_conf_chain_t<BF16, 0>(p, s) : stage == 1 ? launch_conf_chain_t<BF16, 1>(p, s) : launch_conf_chain_t<BF16, 2>(p, s);
+  if (dtype == DT_FP16X3)
+    e = stage == 0 ? launch_conf_chain_t<FP16, 0, true>(p, s) : stage == 1 ? launch_conf_chain_t<FP16, 1, true>(p, s) : launch_conf_chain_t<FP16, 2, true>(p, s);
+  else if (dtype == DT_BF16)
+    e = stage == 0 ? launch_conf_chain_t<BF16, 0, false>(p, s) : stage == 1 ? launch_conf_chain_t<BF16, 1, false>(p, s) : launch_conf_chain_t<BF16, 2, false>(p, s);
   else
-    e = stage == 0 ? launch_conf_chain_t<FP16, 0>(p, s) : stage == 1 ? launch_conf_chain_t<FP16, 1>(p, s) : launch_conf_chain_t<FP16, 2>(p, s);
+    e = stage == 0 ? launch_conf_chain_t<FP16, 0, false>(p, s) : stage == 1 ? launch_conf_chain_t<FP16, 1, false>(p, s) : launch_conf_chain_t<FP16, 2, false>(p, s);
   return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
 

@@ -264,7 +264,7 @@ extern "C" int afx_create(const afx_config* cfg, afx_handle* out) {
       ok &= (B.pw2 = e->walloc(e->E, e->C2p)) != nullptr;
       ok &= (B.bn_scale = (float*)e->dalloc((size_t)e->C2 * 4)) != nullptr;
       ok &= (B.bn_shift = (float*)e->dalloc((size_t)e->C2 * 4)) != nullptr;
-      for (int st = 0; st < 3; ++st) ok &= (B.chain_prm[st] = (float*)e->dalloc(kChainParamFloats * 4)) != nullptr;
+      for (int st = 0; st < 3; ++st) ok &= (B.chain_prm[st] = (float*)e->dalloc((kChainParamFloats + kChainScaleFloats) * 4)) != nullptr;
       ok &= (B.rel_h = e->dalloc((size_t)1025 * 64 * e->hsz)) != nullptr;
     }
   }
@@ -601,7 +601,7 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
           HIP_OK(hipMemcpyAsync(h->blk[b].chain_prm[st] + off, h->F(B + name), (size_t)n * 4, hipMemcpyDeviceToDevice, s));
           return 0;
         };
-        for (int st = 0; st < 3; ++st) HIP_OK(hipMemsetAsync(h->blk[b].chain_prm[st], 0, kChainParamFloats * 4, s));
+        for (int st = 0; st < 3; ++st) HIP_OK(hipMemsetAsync(h->blk[b].chain_prm[st], 0, (kChainParamFloats + kChainScaleFloats) * 4, s));
         for (int st = 0; st < 3; st += 2) {  // stages 0 and 2 carry a feed-forward module
           const std::string ff = st == 0 ? "ff1" : "ff2";
           if (put(st, CP_FF_G, ff + ".fn.norm.weight", 144) || put(st, CP_FF_B, ff + ".fn.norm.bias", 144) ||
@@ -614,6 +614,17 @@ extern "C" int afx_finalize(afx_handle h, void* stream) {
             put(2, CP_LN2_G, "post_norm.weight", 144) || put(2, CP_LN2_B, "post_norm.bias", 144) ||
             put(2, CP_BA, "conv.net.7.bias", 144))
           return 1;
+        if (h->s3) {  // the weight rows' scales, per output column, behind the parameter block (ChainScaleOffsets)
+          ConfBlock& K = h->blk[b];
+          auto sc = [&](int st, int off, const void* w, int rows, int kp) -> int {
+            HIP_OK(hipMemcpyAsync(K.chain_prm[st] + kChainParamFloats + off, h->wscale(w, rows, kp), (size_t)rows * 4, hipMemcpyDeviceToDevice, s));
+            return 0;
+          };
+          if (sc(0, CS_FF1, K.ff1_w1, h->FF, h->Ep) || sc(0, CS_FF2, K.ff1_w2, h->E, h->FFp) || sc(0, CS_A, K.wqkv, 3 * h->inner, h->Ep) ||
+              sc(1, CS_A, K.wout, h->E, h->Ep) || sc(1, CS_B, K.pw1, 2 * h->C2, h->Ep) ||
+              sc(2, CS_A, K.pw2, h->E, h->C2p) || sc(2, CS_FF1, K.ff2_w1, h->FF, h->Ep) || sc(2, CS_FF2, K.ff2_w2, h->E, h->FFp))
+            return 1;
+        }
       }
     }
     if (head_only) {
@@ -1203,7 +1214,9 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
   // K-padding columns of the operand buffers must read as zero (the fused chains only read past
   // the real columns of the attention output: 144 -> 160)
   const size_t hs = dtype_size(dt);
-  const bool fused = e->fuse_conformer && dt != DT_FP32 && E == 144 && e->inner == E && e->FFp == 4 * E;
+  // (split precision: the chains take fp32 operand rows and the pair-form weights; dt is DT_FP32 for every other kernel)
+  const bool fused = e->fuse_conformer && (dt != DT_FP32 || e->s3) && E == 144 && e->inner == E && e->FFp == 4 * E && e->C2 == 2 * E;
+  const int chain_dt = e->s3 ? DT_FP16X3 : dt;
   HIP_OK(hipMemsetAsync(w.ao, 0, (size_t)M * Ep * hs, s));
   if (!fused) {
     HIP_OK(hipMemsetAsync(w.hc, 0, (size_t)M * Ep * hs, s));
@@ -1224,7 +1237,7 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     c.params = K.chain_prm[0];
     c.w_a = K.wqkv; c.ld_w_a = Ep;
     c.out2 = w.qkv32; c.ld_out2 = 3 * e->inner;
-    KOK(timed(PC_CONF_CHAIN, ff_fl + 2.0 * M * E * 3 * e->inner, s, [&] { return launch_conf_chain(c, 0, dt, s); }));
+    KOK(timed(PC_CONF_CHAIN, ff_fl + 2.0 * M * E * 3 * e->inner, s, [&] { return launch_conf_chain(c, 0, chain_dt, s); }));
     KOK(timed(PC_CONF_ATTN, 6.0 * B * e->heads * (double)N * N * e->dh, s, [&] {
       if (e->conf_attn_mfma && dt != DT_FP32 && e->dh == 36)
         return launch_conf_attn_mfma(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner, K.rel_h, 512, B, N, e->heads,
@@ -1237,7 +1250,7 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     c.w_a = K.wout;
     c.w_b = K.pw1;
     c.out2 = w.glu32; c.ld_out2 = 2 * e->C2;
-    KOK(timed(PC_CONF_CHAIN, 2.0 * M * E * (e->inner + 2 * e->C2), s, [&] { return launch_conf_chain(c, 1, dt, s); }));
+    KOK(timed(PC_CONF_CHAIN, 2.0 * M * E * (e->inner + 2 * e->C2), s, [&] { return launch_conf_chain(c, 1, chain_dt, s); }));
     KOK(timed(PC_CONF_DWCONV, 2.0 * B * N * e->C2 * e->ck, s, [&] {
       return launch_conf_dwconv(w.glu32, 2 * e->C2, e->F(P + "conv.net.4.conv.weight"),
                                 e->F(P + "conv.net.4.conv.bias"), K.bn_scale, K.bn_shift, B, N, e->C2, e->ck, w.u,
@@ -1248,7 +1261,7 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
     c.w_a = K.pw2; c.ld_w_a = e->C2p;
     ff(K.ff2_w1, K.ff2_w2);
     c.w_b = nullptr; c.out2 = nullptr;
-    KOK(timed(PC_CONF_CHAIN, ff_fl + 2.0 * M * e->C2 * E, s, [&] { return launch_conf_chain(c, 2, dt, s); }));
+    KOK(timed(PC_CONF_CHAIN, ff_fl + 2.0 * M * e->C2 * E, s, [&] { return launch_conf_chain(c, 2, chain_dt, s); }));
     if (e->taps_on) {
       const std::string nm = "block" + std::to_string(b);
       if (tap(e, nm.c_str(), w.xc, (size_t)M * E, false, s)) return 1;

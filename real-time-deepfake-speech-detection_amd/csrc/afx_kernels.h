@@ -221,6 +221,11 @@ const char* launch_conf_dwconv(const float* x, long ldx, const float* w /*[C][k]
 enum ChainParamOffsets { CP_FF_G = 0, CP_FF_B = 144, CP_FF_B1 = 288, CP_FF_B2 = 864, CP_LN2_G = 1008, CP_LN2_B = 1152,
                          CP_BA = 1296, CP_BB = 1440 };
 constexpr int kChainParamFloats = 2048;
+// split precision (DT_FP16X3): a second block behind it, the per-output-column powers of two that undo the weight rows' scaling
+// (afx_frontend.hip::split_weight_rows_kernel): feed-forward W1 (576) and W2 (144), W_a (<= 432), W_b (576)
+constexpr int kChainScaleFloats = 2048;
+enum ChainScaleOffsets { CS_FF1 = 0, CS_FF2 = 576, CS_A = 720, CS_B = 1152 };
+static_assert(CS_B + 576 <= kChainScaleFloats, "scale block");
 struct ConfChainArgs {
   int M, E, Ep, FFp;        // rows; emb (144); weight row strides of the K = E and K = 4E matrices
   const float* x_in;        // (M, E) fp32 residual rows

@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "951c13367211";
+const char afx_build_id_str[] = "baf4171166b0";

@@ -138,6 +138,34 @@ def test_fp32_conformer_student_logits(dtype):
     assert err <= 1e-5
 
 
+def test_split_precision_conformer_chains_against_the_per_op_path():
+    """dtype "fp16x3": the Conformer block's row-local chains fused (afx_conformer_fused.hip, S3 form: pair-form weights
+    streamed through LDS, the fp32 rows split into hi / lo halves in registers, three matrix-core passes per k-step) against
+    the same engine with ``fuse_conformer`` off (one split-precision GEMM / LayerNorm launch per op) and against the fp32
+    oracle, block by block; a batch whose row count is not a multiple of the chains' 64-row workgroups."""
+    from afx import engine, synth
+    from oracle import models
+    sd = synth.model_state_dict("ConformerModel", n_layers=2)
+    wave = synth.waveforms(3, 40000, batch_idx=5)  # 3 x 125 token rows = 375
+    taps = {}
+    ref = models.conformer_forward(sd, wave, taps=taps)
+    outs = {}
+    for fused in (1, 0):
+        eng = engine.Engine("conformer", n_layers=2, dtype="fp16x3")
+        eng.load_state_dict(sd)
+        eng.set("fuse_conformer", fused)
+        eng.enable_taps()
+        got = eng.forward(wave.cuda()).cpu()
+        eng.check_finite()
+        outs[fused] = got
+        for b in range(4):
+            e = rel_l2(eng.tap(f"block{b}"), taps[f"block{b}"])
+            assert e < 2e-6, f"fused={fused} block{b}: rel L2 {e:.3e}"
+        assert (got - ref).abs().max().item() <= 1e-5
+    print(f"fp16x3 Conformer head: fused chains max|dlogit| {(outs[1] - ref).abs().max().item():.2e}, per-op {(outs[0] - ref).abs().max().item():.2e}, "
+          f"fused vs per-op {(outs[1] - outs[0]).abs().max().item():.2e}")
+
+
 def test_fp32_teacher_every_utterance_within_tolerance():
     """XLSR_AASIST end to end with no reduced precision: every utterance (not just the
     well-conditioned ones, cf. test_teacher_model_end_to_end) holds the score tolerance, and the graph
