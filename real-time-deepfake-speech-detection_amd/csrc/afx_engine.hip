@@ -1472,7 +1472,7 @@ extern "C" int afx_kv_step(afx_kv* k, const float* feats6, int n, float* logits,
   if (e->s3) {  // split precision: the chunk's products take pair-form operands written by their producers, or converted into the scratch
     t_s3planes = w.s3planes;
     t_s3bytes = w.s3bytes;
-    s3_begin({w.feats_h, w.hbuf, w.att, w.ff, w.xpad});
+    s3_begin({w.feats_h, w.hbuf, w.att, w.ff, w.xpad, (char*)w.xpad + (size_t)kKvHist * kD * e->hsz});  // (+ the chunk's view of the padded rows)
   }
   const size_t hs = e->hsz;
   k->cnt[group] = n;
@@ -1489,33 +1489,36 @@ extern "C" int afx_kv_step(afx_kv* k, const float* feats6, int n, float* logits,
     GemmArgs g = plain_gemm(w.feats_h, kC, e->projw, kC, M, kD, kC);
     g.rpb = n; g.a_batch = (long)n * kC; g.a_row = kC;
     g.bias = e->F("ssl.post_extract_proj.bias");
-    g.out_f = w.xp; g.ldo_f = kD; g.o_batch_rows = Tp; g.o_row_off = kKvHist;
+    g.out_f = w.x; g.ldo_f = kD;  // the chunk's residual rows, dense (S, n, 1024)
     g.out_h = w.xpad; g.ldo_h = kD; g.oh_batch_rows = Tp + kPosK; g.oh_row_off = kPosPad + kKvHist;
     KOK(launch_gemm(g, dt, 1, s));
     KOK(timed(PC_MISC, 0, s, [&] { return launch_zero_pad_rows(w.xpad, S, Tp, kD, kPosPad, kPosK - kPosPad, dt, s, nullptr); }));
   }
+  // The positional conv of the chunk's n frames ONLY (round 4: it used to run over all 64 + n rows of the padded layout and
+  // keep the last n -- 6x the work at n = 13): output frame j reads rows [64 + j, 192 + j) of the stream's padded rows, i.e. rows
+  // [j, j + 128) from the first cached frame on.
+  void* xchunk = (char*)w.xpad + (size_t)kKvHist * xrow;
   if (!e->s3) {
     PosConvArgs pc;
     memset(&pc, 0, sizeof pc);
-    pc.xpad = w.xpad; pc.xpad_batch = (long)(Tp + kPosK) * kD; pc.W = e->posw; pc.bias = e->F("ssl.encoder.pos_conv.0.bias");
-    pc.x = w.xp; pc.B = S; pc.T = Tp;
-    KOK(timed(PC_POSCONV, 2.0 * S * Tp * kD * (kD / kPosG) * kPosK, s, [&] { return launch_posconv(pc, dt, s); }));
+    pc.xpad = xchunk; pc.xpad_batch = (long)(Tp + kPosK) * kD; pc.W = e->posw; pc.bias = e->F("ssl.encoder.pos_conv.0.bias");
+    pc.x = w.x; pc.B = S; pc.T = n;
+    KOK(timed(PC_POSCONV, 2.0 * S * n * kD * (kD / kPosG) * kPosK, s, [&] { return launch_posconv(pc, dt, s); }));
   } else {  // split precision: the grouped product of run_trunk (chunked K over the time-padded pair-form rows)
     const int cpg = kD / kPosG;
-    s3_set(w.xpad, kS3ScaleFree);  // (history rows copied in above + the rows the projection just wrote: pair form, scale 1)
-    GemmArgs g = plain_gemm(w.xpad, 0, e->posw, (long)cpg * kPosK, S * Tp, cpg, cpg * kPosK);
-    g.rpb = Tp; g.a_batch = (long)(Tp + kPosK) * kD; g.a_row = kD;
+    s3_set(xchunk, kS3ScaleFree);  // (history rows copied in above + the rows the projection just wrote: pair form, scale 1)
+    GemmArgs g = plain_gemm(xchunk, 0, e->posw, (long)cpg * kPosK, S * n, cpg, cpg * kPosK);
+    g.rpb = n; g.a_batch = (long)(Tp + kPosK) * kD; g.a_row = kD;
     g.kchunk = cpg; g.kchunk_stride = kD;
     g.g_a = cpg; g.g_w = (long)cpg * cpg * kPosK; g.g_n = cpg;
     g.bias = e->F("ssl.encoder.pos_conv.0.bias");
     g.act = ACT_GELU;
-    g.resid = w.xp; g.ldr = kD;
-    g.out_f = w.xp; g.ldo_f = kD; g.o_batch_rows = Tp; g.oh_batch_rows = Tp;
+    g.resid = w.x; g.ldr = kD;
+    g.out_f = w.x; g.ldo_f = kD;
     KOK(launch_gemm(g, dt, kPosG, s));
   }
-  // the newest 64 projected frames become the next chunk's left context; the chunk's rows leave the padded layout
+  // the newest 64 projected frames become the next chunk's left context
   HIP_OK(hipMemcpy2DAsync(k->hist, kKvHist * xrow, (char*)w.xpad + (size_t)(kPosPad + n) * xrow, xpad_pitch, kKvHist * xrow, S, hipMemcpyDeviceToDevice, s));
-  HIP_OK(hipMemcpy2DAsync(w.x, (size_t)n * kD * 4, w.xp + (size_t)kKvHist * kD, (size_t)Tp * kD * 4, (size_t)n * kD * 4, S, hipMemcpyDeviceToDevice, s));
   for (int l = 0; l < e->cfg.n_layers; ++l) {
     const std::string P = "ssl.encoder.layers." + std::to_string(l) + ".";
     void* ring = (char*)k->rings + (size_t)l * S * kKvSlots * 3 * kD * hs;

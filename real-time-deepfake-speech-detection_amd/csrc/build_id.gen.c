@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "baf4171166b0";
+const char afx_build_id_str[] = "9e21f4fc5730";
