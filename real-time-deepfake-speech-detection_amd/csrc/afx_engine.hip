@@ -1489,7 +1489,7 @@ extern "C" int afx_kv_step(afx_kv* k, const float* feats6, int n, float* logits,
     GemmArgs g = plain_gemm(w.feats_h, kC, e->projw, kC, M, kD, kC);
     g.rpb = n; g.a_batch = (long)n * kC; g.a_row = kC;
     g.bias = e->F("ssl.post_extract_proj.bias");
-    g.out_f = w.x; g.ldo_f = kD;  // the chunk's residual rows, dense (S, n, 1024)
+    g.out_f = w.x; g.ldo_f = kD; g.o_batch_rows = n;  // the chunk's residual rows, dense (S, n, 1024)
     g.out_h = w.xpad; g.ldo_h = kD; g.oh_batch_rows = Tp + kPosK; g.oh_row_off = kPosPad + kKvHist;
     KOK(launch_gemm(g, dt, 1, s));
     KOK(timed(PC_MISC, 0, s, [&] { return launch_zero_pad_rows(w.xpad, S, Tp, kD, kPosPad, kPosK - kPosPad, dt, s, nullptr); }));
@@ -1514,7 +1514,7 @@ extern "C" int afx_kv_step(afx_kv* k, const float* feats6, int n, float* logits,
     g.bias = e->F("ssl.encoder.pos_conv.0.bias");
     g.act = ACT_GELU;
     g.resid = w.x; g.ldr = kD;
-    g.out_f = w.x; g.ldo_f = kD;
+    g.out_f = w.x; g.ldo_f = kD; g.o_batch_rows = n; g.oh_batch_rows = n;
     KOK(launch_gemm(g, dt, kPosG, s));
   }
   // the newest 64 projected frames become the next chunk's left context
@@ -1943,6 +1943,10 @@ extern "C" int afx_debug_set(const char* key, int value) {
   }
   if (!strcmp(key, "gemm_small_deep")) {
     gemm_set_small_deep(value);
+    return 0;
+  }
+  if (!strcmp(key, "gemm_s3_small")) {
+    gemm_set_s3_small(value);
     return 0;
   }
   if (!strcmp(key, "gemm_split")) {

@@ -1788,6 +1788,8 @@ bool gemm_is_narrow(int N) { return N <= 64 || (N > 128 && N < 256 && N % 128 !=
 // those fit ONE round of it.  Returns the number of leading rows (0: no split).
 static int g_split = 1;  // A/B knob
 void gemm_set_split(int v) { g_split = v; }
+static int g_s3_small = 0;  // A/B knob (split precision, small-M products): 0 = the fp16 dispatch's choice (deep 128x64), 1 = 128x128 2-stage, 2 = 128x64 2-stage
+void gemm_set_s3_small(int v) { g_s3_small = v; }
 static int gemm_split_rows(const GemmArgs& p, int groups) {
   constexpr int kCUs = 256;
   if (!g_split || groups != 1 || p.ln_gamma || !plain_k(p) || p.rpb < p.M || gemm_is_narrow(p.N)) return 0;
@@ -1875,6 +1877,7 @@ int gemm_tile_of(const GemmArgs& p, int groups) {
   const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   const long b256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   if (b128 < 384) {  // small batches: halve the tile to spread over the chip
+    if (p.k1 && g_s3_small) return g_s3_small == 1 ? 0 : 1;
     // at most two 128x64 tiles per CU (b128 <= 256: the teacher's N = 1024 products at B <= 16): the deep form of that tile --
     // three K-tile buffers, counted vmcnt, both k-steps' fragments requested ahead of the MFMAs -- FC2 at M = 16 x 199 50.3 ->
     // 43.3 us, out-proj 19.4 -> 17.7; at M = 8 x 199 41.6 -> 31.8 (tools/diag_deep_tiles.py).  With three workgroups per CU

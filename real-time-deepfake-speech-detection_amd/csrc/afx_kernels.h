@@ -87,6 +87,7 @@ const char* launch_gemm(const GemmArgs& p, int dtype, int groups, hipStream_t s)
 const char* launch_gemm_f32(const GemmArgs& p, int groups, hipStream_t s);  // afx_gemm_f32.hip (DT_FP32 operands)
 bool gemm_is_narrow(int N);  // true: the 128x64 tile instance serves this N
 int gemm_tile_of(const GemmArgs& p, int groups);  // tile instance id (afx_gemm.hip)
+void gemm_set_s3_small(int v);  // A/B knob: split-precision small-M products (0 default, 1 = 128x128, 2 = 128x64 2-stage)
 void gemm_set_map_mode(int m);  // A/B knob: -1 default, else force map_mode
 void gemm_set_small_deep(int v);  // A/B knob: 1 (default) = deep form of the 128x64 tile at <= two tiles per CU
 void gemm_set_tile(int t);      // A/B knob: -1 default, 0: 128x128 tile, 1: 256x256 tile

@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "9e21f4fc5730";
+const char afx_build_id_str[] = "f129c2a13365";

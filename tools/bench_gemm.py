@@ -15,6 +15,7 @@ from afx._lib import lib, check  # noqa: E402
 DT = os.environ.get("AFX_DTYPE", "fp16")
 TD = torch.float16 if DT == "fp16" else torch.bfloat16
 B = 64
+VENDOR = None
 # name, kind, dims
 SHAPES = [
     ("conv1 M=409536 K=1536 N=512", "conv", (B, 12799, 3, 2)),
@@ -41,6 +42,9 @@ SETS = {
     "map": [("map0", ("gemm_map", 0)), ("map1", ("gemm_map", 1)), ("map2", ("gemm_map", 2))],
     "nt": [("A default", ("gemm_a_nt", 0)), ("A nt", ("gemm_a_nt", 1))],
     "deep": [("2-stage", ("gemm_deep", 0)), ("8-phase", ("gemm_deep", 2))],
+    # the vendor library on the same operands (torch.nn.functional.linear -> hipBLASLt / rocBLAS: bias epilogue only, no GELU, its own
+    # choice of kernel per shape): a reference point for what the hardware gives these shapes, not a candidate for the path
+    "vendor": [("this repository (bias + GELU epilogue)", ("gemm_tile", -1)), ("vendor library (bias only)", "vendor")],
     "epi": [("narrow stores", ("gemm_nodma", 16)), ("wide stores", ("gemm_nodma", 0))],  # attribution build only (AFX_LIB=.../libafx_attr.so)
 }
 VARIANTS = SETS[os.environ.get("BENCH_SET", "tile")]
@@ -71,20 +75,30 @@ def make(kind, dims):
     a = torch.randn(M, Kk, generator=g, device="cuda").to(TD)
     w = (torch.randn(N, Kk, generator=g, device="cuda") * 0.03).to(TD)
     bias = torch.randn(N, generator=g, device="cuda")
+    global VENDOR
+    bias_h = bias.to(TD)
+    VENDOR = lambda: torch.nn.functional.linear(a, w, bias_h)
     return (lambda: K.gemm(DT, a, w, bias=bias, act="gelu", out_f=False, out_h=True)), 2.0 * M * N * Kk
 
 
 def main():
     rounds, reps = 5, 10
     for name, kind, dims in SHAPES:
+        if kind != "lin" and any(kv == "vendor" for _, kv in VARIANTS):
+            continue
         fn, flops = make(kind, dims)
+        mine = fn
         times = {v: [] for v, _ in VARIANTS}
         for _ in range(2):
             fn()
         for _ in range(rounds):
             for v, kv in VARIANTS:
-                for key, val in (kv if isinstance(kv, list) else [kv]):
-                    check(lib().afx_debug_set(key.encode(), val))
+                if kv == "vendor":
+                    fn = VENDOR
+                else:
+                    fn = mine
+                    for key, val in (kv if isinstance(kv, list) else [kv]):
+                        check(lib().afx_debug_set(key.encode(), val))
                 fn()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

@@ -25,6 +25,8 @@ PY
     gemm4) export AFX_LIB=$PWD/real-time-deepfake-speech-detection_amd/lib/libafx_attr.so; timeout -k 10 300 python tools/diag_gemm4.py > $O/gemm4_identity.txt 2>&1; rc=$?; cat $O/gemm4_identity.txt | grep -v amdgpu.ids; if [ $rc -ne 0 ]; then echo "gemm4 identity failed (rc $rc): no timing"; else BENCH_SET=w4 timeout -k 10 600 python tools/bench_gemm.py > $O/gemm4_ab.txt 2>&1; grep -v amdgpu.ids $O/gemm4_ab.txt | cut -c1-300; fi;;
     s3chain) timeout -k 10 600 python -m pytest tests -m gpu -q --timeout 300 -s -k "split_precision_conformer_chains or fp32_conformer_student or ragged_batch_in_split or conformer_student_scores or myconformer or conformer_head_alone" > $O/pytest_s3chain.log 2>&1; rc=$?; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/pytest_s3chain.log | tail -12 | cut -c1-300; if [ $rc -ne 0 ]; then echo "tests failed (rc $rc): no timing"; else timeout -k 10 300 python tools/diag_s3_chain.py > $O/s3_chain.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/s3_chain.txt | cut -c1-400; fi;;
     kvchunk) timeout -k 10 900 python -m pytest tests/test_gpu_streaming_kv.py -q --timeout 600 > $O/pytest_kv.log 2>&1; rc=$?; tail -4 $O/pytest_kv.log | cut -c1-300; if [ $rc -ne 0 ]; then echo "tests failed (rc $rc): no timing"; else timeout -k 10 500 python tools/stream_bench.py --workload conformer_student --modes kv-cached > $O/rtf_student.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/rtf_student.txt | cut -c1-300; timeout -k 10 500 python tools/stream_bench.py --workload xlsr_aasist --streams 1 64 512 --modes kv-cached > $O/rtf_teacher.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/rtf_teacher.txt | cut -c1-300; fi;;
+    s3small) timeout -k 10 400 python tools/diag_s3_small.py > $O/s3_small.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/s3_small.txt | cut -c1-300;;
+    vendor) BENCH_SET=vendor timeout -k 10 400 python tools/bench_gemm.py > $O/vendor_gemm.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/vendor_gemm.txt | cut -c1-300;;
     newtests) timeout -k 10 1000 python -m pytest tests -m gpu -q --timeout 600 -k "deep_tile or overlaps_the_backend or test_gpu_bench or outlier or per_engine or forward_hooks or full_depth" > $O/pytest_new.log 2>&1; tail -8 $O/pytest_new.log | cut -c1-300;;
     stale) timeout -k 10 300 python tools/diag_s3_stale.py > $O/s3_stale.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/s3_stale.txt | cut -c1-300;;
     headrace) timeout -k 10 300 python tools/diag_head_race.py > $O/head_race.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/head_race.txt | cut -c1-300;;
