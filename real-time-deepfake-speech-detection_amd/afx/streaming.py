@@ -151,7 +151,7 @@ class IncrementalScorer(SlidingWindowScorer):
             self.carry[i] = x[:, n_out * s:].contiguous()  # the unconsumed tail: k - s frames in steady state
             if n_out == 0:
                 return None
-            xin = x[:, : (n_out - 1) * s + k].contiguous()
+            xin = x  # (the kernels derive n_out from the row count themselves and read nothing past the last window: no slice copy)
             if i == 0:
                 y = K.conv0_packed(self.dt, xin, self.pack0, self.w0, self.cb[0], self.lg[0], self.lb[0])
             else:
@@ -227,7 +227,7 @@ class KVCachedScorer(IncrementalScorer):
         self.carry6 = x[:, n_out * 2:].contiguous()
         if n_out == 0:
             return None
-        f6 = self._conv_ln_gelu(x[:, : n_out * 2].contiguous(), self.cw6, 2, 2, self.cb6, self.lg6, self.lb6, fp32_out=True)
+        f6 = self._conv_ln_gelu(x, self.cw6, 2, 2, self.cb6, self.lg6, self.lb6, fp32_out=True)  # ((Tin - 2) // 2 + 1 = n_out rows)
         self.frames += n_out
         return self.kv.step(f6)[:, 1]
 
