@@ -12,6 +12,15 @@ run() {  # name, lib suffix, DIAG_SIDE
   AFX_LIB=$L/libafx$2.so DIAG_SIDE=$3 timeout -k 10 240 python tools/diag_two_stream_which.py fp16x3 1 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(\|workspace bytes differ from" | cut -c1-400 | tee -a $O/race.txt
   rc=${PIPESTATUS[0]}; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "killed (rc $rc): stopping"; exit $rc; fi
 }
+if [ "${2:-}" = "aggressor" ]; then
+  run "baseline kernel, chip-filling elementwise kernel beside the trunk (VALU + memory, no matrix instruction)" "" valu
+  run "baseline kernel, vendor fp16 matrix-core GEMM beside the trunk" "" mm16
+  run "baseline kernel, vendor fp32 GEMM beside the trunk" "" mm32
+  run "baseline kernel, the back-end's first kernel beside the trunk (again)" "" ""
+  run "conv0 without packed fp32 math, the back-end's first kernel beside the trunk (again)" _nopk ""
+  run "conv0 without packed fp32 math, vendor fp16 matrix-core GEMM beside the trunk" _nopk mm16
+  exit 0
+fi
 run "baseline (build 26d8841), back-end's first kernel beside the trunk" "" ""
 run "conv0 reduction by ds_bpermute (no DPP, no permlane swap)" _red1 ""
 run "conv0 reduction with s_nop 7 around the permlane swaps" _red2 ""
