@@ -195,6 +195,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+// Keeps a scalar fp32 chain out of the vectoriser's packed forms (v_pk_fma_f32 ...).  The tap loops of the VALU conv-layer-0 kernels
+// broadcast one sample to two channels' accumulators; packed, hipcc emits `v_pk_fma_f32 v[d:d+1], w, v[d:d+1], acc op_sel:[0,1,0]`
+// -- the destination pair overwrites the sample pair whose HIGH register the LOW result reads -- and on MI355X that form returned
+// wrong low halves in lanes 48-63 (one wave-instruction in ~1e5) whenever an fp16 MFMA kernel ran beside it (round 4, DESIGN.md
+// section 7; tools/scan_pk_hazard.py refuses the form in the built library).
+__device__ __forceinline__ void scalar_only(float& a) { asm volatile("" : "+v"(a)); }
+
 // Full-wave (64-lane) all-reduce without LDS traffic.  __shfl_xor lowers to ds_bpermute
 // (an LDS-crossbar round trip + lgkmcnt wait per step -- six of them per reduction made the
 // LayerNorm statistics the most expensive part of conv0/rownorm).  Here: four DPP steps

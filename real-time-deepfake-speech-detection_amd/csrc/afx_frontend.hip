@@ -67,7 +67,10 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
     for (int i = 0; i < 8; ++i) {
       float a = bi[i];
 #pragma unroll
-      for (int j = 0; j < 10; ++j) a = fmaf(wr[i][j], xv[j], a);
+      for (int j = 0; j < 10; ++j) {
+        a = fmaf(wr[i][j], xv[j], a);
+        scalar_only(a);
+      }
       v[i] = a;
       sum += a;
     }
@@ -456,6 +459,8 @@ __global__ __launch_bounds__(256) void conv0_gn_stats_kernel(const float* __rest
       const float xv = xs[f * 5 + j];
       a0 = fmaf(w0[j], xv, a0);
       a1 = fmaf(w1[j], xv, a1);
+      scalar_only(a0);
+      scalar_only(a1);
     }
     s0 += a0; q0 = fmaf(a0, a0, q0);
     s1 += a1; q1 = fmaf(a1, a1, q1);
@@ -512,6 +517,8 @@ __global__ __launch_bounds__(256) void conv0_gn_apply_kernel(const float* __rest
       for (int j = 0; j < 10; ++j) {
         a0 = fmaf(wr[i][j], xv[j], a0);
         a1 = fmaf(wr[i + 1][j], xv[j], a1);
+        scalar_only(a0);
+        scalar_only(a1);
       }
       const f32x2_t yin = f32x2_t{fmaf(a0, sc[i], sh[i]), fmaf(a1, sc[i + 1], sh[i + 1])};
       const f32x2_t y = sizeof(T) == 4 ? gelu_erf2(yin) : gelu_poly2(yin);

@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "f129c2a13365";
+const char afx_build_id_str[] = "402930274202";

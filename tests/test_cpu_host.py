@@ -358,3 +358,19 @@ def test_track_routing_and_checkpoint_sweep_like_main(tmp_path):
     assert len(res) == 2
     assert (tmp_path / "s" / "LA19_3_acc_97.pt.txt").read_text().split("\n")[1] == "u1 2.0"
     assert (tmp_path / "s" / "LA19_4_acc_98.pt.txt").read_text().split("\n")[1] == "u1 3.0"
+
+
+def test_built_library_holds_no_in_place_cross_half_packed_fp32_op():
+    """tools/scan_pk_hazard.py on the library this suite loads: no kernel may contain a packed fp32 op that overwrites the register
+    pair whose HIGH register its LOW result reads -- the instruction form behind round 4's two-stream defect."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "real-time-deepfake-speech-detection_amd", "lib", "libafx.so")
+    if not (os.path.exists(lib) and shutil.which("objcopy") and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump")):
+        pytest.skip("needs the built library, objcopy and the ROCm llvm-objdump")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "scan_pk_hazard.py"), lib], capture_output=True, text=True, timeout=600)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "refused): 0 in 0 kernels" in out.stdout

@@ -1,0 +1,103 @@
+"""Scan the device code of the built library for the packed-fp32 instruction form that produced wrong values on MI355X when an fp16
+matrix-core kernel ran beside it ("the two-stream defect", profiles/r04_two_stream_race.txt):
+
+    v_pk_{fma,mul,add}_f32  v[d:d+1], ..., v[d:d+1], ...  op_sel:[..1..]
+
+i.e. a packed fp32 op whose DESTINATION pair is also a SOURCE pair, with that source's op_sel bit set (the LOW half of the result is
+computed from the HIGH register of the pair it overwrites).  Observed: lanes 48-63 of the low result wrong, one wave-instruction in
+~1e5, only while another wave's fp16 MFMAs were in flight on the chip (the vendor library's GEMM as well as this repository's), never
+with the same arithmetic issued as scalar v_fma_f32.  The mirror form (high half reads the low register: op_sel_hi bit clear) sits in
+every GEMM epilogue of this library (20-32 per kernel), runs beside MFMAs by construction and has never moved a bit; it is listed,
+not refused.
+
+    python tools/scan_pk_hazard.py [path/to/libafx.so]     exit status 1 if any kernel holds the refused form
+"""
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+PK = re.compile(r"^\s*(v_pk_(?:fma|mul|add)_f32)\s+v\[(\d+):(\d+)\],\s*(.*?)(?://.*)?$")
+
+
+def code_objects(lib, tmp):
+    """gfx950 code objects of every translation unit linked into `lib` (the .hip_fatbin section: one offload bundle per unit)."""
+    fat = os.path.join(tmp, "fat.bin")
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
+    data = open(fat, "rb").read()
+    starts, i = [], 0
+    while (j := data.find(MAGIC, i)) >= 0:
+        starts.append(j)
+        i = j + 1
+    out = []
+    for n, a in enumerate(starts):
+        b = starts[n + 1] if n + 1 < len(starts) else len(data)
+        part, co = os.path.join(tmp, f"b{n}.fat"), os.path.join(tmp, f"b{n}.co")
+        open(part, "wb").write(data[a:b])
+        r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            f"--input={part}", f"--output={co}"], capture_output=True, text=True)
+        if r.returncode == 0 and os.path.getsize(co) > 0:
+            out.append(co)
+    return out
+
+
+def scan(lib):
+    total, refused, mirror = collections.Counter(), collections.Counter(), collections.Counter()
+    with tempfile.TemporaryDirectory() as tmp:
+        cos = code_objects(lib, tmp)
+        if not cos:
+            raise SystemExit(f"{lib}: no gfx950 code object found")
+        for co in cos:
+            dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], capture_output=True, text=True, check=True).stdout
+            kern = None
+            for line in dis.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\w+)>:", line)
+                if m:
+                    kern = m.group(1)
+                    continue
+                m = PK.match(line)
+                if not m or kern is None:
+                    continue
+                op, d0, d1, rest = m.groups()
+                total[kern] += 1
+                nsrc = 3 if "fma" in op else 2
+                srcs = [t.strip().lstrip("-|").rstrip("|") for t in re.split(r"\s+op_sel", rest)[0].split(",")][:nsrc]
+                sel = re.search(r"op_sel:\[([\d,]+)\]", rest)
+                selh = re.search(r"op_sel_hi:\[([\d,]+)\]", rest)
+                sel = [int(x) for x in sel.group(1).split(",")] if sel else [0] * nsrc
+                selh = [int(x) for x in selh.group(1).split(",")] if selh else [1] * nsrc
+                for i, s in enumerate(srcs):
+                    if s == f"v[{d0}:{d1}]":
+                        if i < len(sel) and sel[i] == 1:
+                            refused[kern] += 1
+                        elif i < len(selh) and selh[i] == 0:
+                            mirror[kern] += 1
+    return total, refused, mirror
+
+
+def demangle(name):
+    try:
+        r = subprocess.run(["c++filt", name], capture_output=True, text=True)
+        return (r.stdout.strip() or name)[:120]
+    except OSError:
+        return name
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "real-time-deepfake-speech-detection_amd", "lib", "libafx.so")
+    total, refused, mirror = scan(lib)
+    print(f"{os.path.basename(lib)}: {len(total)} kernels hold packed-fp32 ops ({sum(total.values())} instructions); "
+          f"in-place with the LOW half reading the HIGH register (refused): {sum(refused.values())} in {len(refused)} kernels; "
+          f"mirror form (listed): {sum(mirror.values())} in {len(mirror)} kernels")
+    for k, n in sorted(refused.items(), key=lambda kv: -kv[1]):
+        print(f"  REFUSED x{n:3d}  {demangle(k)}")
+    return 1 if refused else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
