@@ -206,13 +206,13 @@ class Engine:
     def overlap_is_bit_stable(self):
         """Whether ``forward_overlapped`` reproduces ``forward``'s bits for this engine (False: it runs on one stream).
         History (round 4): the teacher (AASIST back-end) in dtype "fp16x3" did NOT -- with the back-end of batch i beside it,
-        the trunk of batch i+1 computed ONE frame of conv layer 0 differently in about a third of the batches
-        (profiles/r04_two_stream_race.txt: not stale memory, no out-of-bounds write, gone under a synchronise per call, the
-        back-end itself stable; root cause not identified).  The kernel that showed it, ``conv0_kernel<F32T>`` followed by a
-        split launch over its output, left the fp16x3 path when conv layer 0 moved to the matrix-core kernel that writes conv
-        layer 1's pair-form operand: 0 differences in 105 concurrent batches since (same tool), and 0 in 120 for the exact
-        mode, which still runs the VALU kernel.  Every combination is therefore True again; the property stays as the switch
-        a future finding flips, and tests/test_gpu_aasist.py compares 42 concurrent batches per combination on every run."""
+        the trunk of batch i+1 computed ONE frame of conv layer 0 differently in about a third of the batches.  Bisected
+        (profiles/r04_two_stream_race.txt): the victim was the VALU ``conv0_kernel<F32T>``'s packed fp32
+        tap loop, the trigger any fp16 GEMM kernel started beside it (the vendor library's as well), the same kernel with a
+        scalar loop is immune.  That kernel left the fp16x3 path (conv layer 0 runs on the matrix cores there), the tap loops
+        of the VALU conv-layer-0 kernels are scalar, and tests/test_gpu_aasist.py compares 42 concurrent batches per
+        (head, precision) combination plus the VALU-kernel engines beside vendor GEMMs on every run.  Every combination is
+        therefore True; the property stays as the switch a future finding flips."""
         return True
 
     def join(self):

@@ -195,11 +195,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-// Keeps a scalar fp32 chain out of the vectoriser's packed forms (v_pk_fma_f32 ...).  The tap loops of the VALU conv-layer-0 kernels
-// broadcast one sample to two channels' accumulators; packed, hipcc emits `v_pk_fma_f32 v[d:d+1], w, v[d:d+1], acc op_sel:[0,1,0]`
-// -- the destination pair overwrites the sample pair whose HIGH register the LOW result reads -- and on MI355X that form returned
-// wrong low halves in lanes 48-63 (one wave-instruction in ~1e5) whenever an fp16 MFMA kernel ran beside it (round 4, DESIGN.md
-// section 7; tools/scan_pk_hazard.py refuses the form in the built library).
+// Keeps a scalar fp32 chain out of the vectoriser's packed forms (v_pk_fma_f32 ...).  Round 4: conv0_kernel<F32T>,
+// compiled with its 10-tap loop packed, returned wrong LOW halves in lanes 48-63 of a channel pair (about one frame in 1e5) whenever an
+// fp16 GEMM kernel -- this library's or the vendor's -- started beside it on another stream; compiled with the loop scalar it never did
+// (0 of 48 batches beside the vendor GEMM that moved 21 of 24 before).  The packed loop's last writers of those elements are
+// `v_pk_fma_f32 v[d:d+1], w, v[d:d+1], acc op_sel:[0,1,0]` (the destination overwrites the sample pair whose HIGH register the LOW result
+// reads); isolated in tools/pk_hazard_probe.hip that form alone does NOT fail, so the mechanism is not pinned to it -- the tap loops of the
+// VALU conv-layer-0 kernels are scalar regardless, and tools/scan_pk_hazard.py keeps the form out of the built library.
 __device__ __forceinline__ void scalar_only(float& a) { asm volatile("" : "+v"(a)); }
 
 // Full-wave (64-lane) all-reduce without LDS traffic.  __shfl_xor lowers to ds_bpermute

@@ -362,7 +362,8 @@ def test_track_routing_and_checkpoint_sweep_like_main(tmp_path):
 
 def test_built_library_holds_no_in_place_cross_half_packed_fp32_op():
     """tools/scan_pk_hazard.py on the library this suite loads: no kernel may contain a packed fp32 op that overwrites the register
-    pair whose HIGH register its LOW result reads -- the instruction form behind round 4's two-stream defect."""
+    pair whose HIGH register its LOW result reads -- the form that sat where round 4's two-stream defect showed (a conservative guard:
+    DESIGN.md section 7 says what is and is not established about it)."""
     import shutil
     import subprocess
     import sys

@@ -263,13 +263,13 @@ def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_p
 
 @pytest.mark.parametrize("dtype,mode", [("fp32", "layer_norm"), ("fp16", "group_norm"), ("fp16x3", "group_norm")])
 def test_valu_conv0_kernels_are_exact_beside_a_matrix_core_kernel(dtype, mode):
-    """The root cause of round 4's two-stream defect (profiles/r04_two_stream_race.txt, tools/pk_hazard_probe.hip): on MI355X a
-    packed fp32 instruction that overwrites the register pair whose HIGH register its LOW result reads returned wrong low halves
-    in lanes 48-63 while an fp16 MFMA kernel -- the vendor library's GEMM as well as this repository's -- ran beside it.  hipcc
-    emitted that form in the 10-tap loops of the VALU conv-layer-0 kernels (exact mode's ``conv0_kernel<F32T>``, the group-norm
-    extractor's ``conv0_gn_*``); with the vendor's fp16 GEMM beside the trunk 7 of 8 batches moved.  The loops are scalar now
-    (``scalar_only``), ``tools/scan_pk_hazard.py`` refuses the form in the built library, and this is the run-time guard: the
-    trunk's features beside a stream of vendor fp16 GEMMs equal the features computed alone, bit for bit, 24 batches x 2."""
+    """Round 4's two-stream defect, narrowed (profiles/r04_two_stream_race.txt): the VALU conv-layer-0 kernel, compiled with its
+    10-tap loop in packed fp32 math, returned wrong low halves in lanes 48-63 of a frame whenever an fp16 GEMM kernel -- the vendor
+    library's as well as this repository's -- started beside it (the vendor's GEMM moved 21 of 24 batches); compiled with the loop
+    scalar it never moved.  The kernels that hold such a loop (exact mode's ``conv0_kernel<F32T>``, the group-norm extractor's
+    ``conv0_gn_*``) are scalar there now (``scalar_only``) and this is the run-time guard: the trunk's features beside a stream of
+    vendor fp16 GEMMs equal the features computed alone, bit for bit, 24 batches x 2.  (The instruction-level mechanism is not
+    pinned down: tools/pk_hazard_probe.hip does not reproduce it in isolation.)"""
     from afx import engine, synth
     sd = synth.ssl_state_dict(1, extractor_mode=mode) if mode == "group_norm" else synth.ssl_state_dict(1)
     eng = engine.Engine("ssl", n_layers=1, dtype=dtype, extractor_mode=mode)

@@ -1,16 +1,17 @@
-// Stand-alone reproducer of the defect behind the "two-stream step is not bit-stable" finding of round 4 (DESIGN.md section 7,
-// profiles/r04_two_stream_race.txt): on MI355X a packed fp32 op whose destination pair is also a source pair, with that source's
-// op_sel bit set (the LOW half of the result is computed from the HIGH register of the pair being overwritten),
+// Isolation attempt for the "two-stream step is not bit-stable" finding of round 4 (profiles/r04_two_stream_race.txt).
+// What is established on the engine (tools/r04_race.sh): conv0_kernel<F32T>, compiled with its 10-tap loop in packed fp32 math, returns
+// wrong LOW halves in lanes 48-63 when an fp16 GEMM kernel starts beside it; compiled scalar it does not.  The last writers of the
+// elements that move have the form
 //
 //     v_pk_fma_f32 v[d:d+1], v[a:a+1], v[d:d+1], v[c:c+1] op_sel:[0,1,0]
 //
-// occasionally returns a wrong LOW half in lanes 48-63 while another kernel's fp16 MFMAs are in flight on the chip.  hipcc emits
-// the form on its own when it vectorises a scalar-times-two-accumulators loop (the 10-tap loop of the VALU conv-layer-0 kernels).
-//
-// The probe runs three forms of the instruction in a victim kernel -- A: the form above; B: the mirror (high half reads the LOW
-// register of the overwritten pair, op_sel_hi:[1,0,1]); N: form A's operand selects with a destination that is NOT a source --
-// checks every result against the same arithmetic issued as scalar v_fma_f32, and counts mismatches per lane and half: alone, with a
-// VALU-only kernel beside it, and with an fp16 MFMA kernel beside it (second stream).
+// (the destination pair overwrites the source pair whose HIGH register the LOW result reads).  This probe asks whether that form is
+// sufficient: forms A (above), B (the mirror: high half reads the LOW register, op_sel_hi:[1,0,1]), N (A's selects, destination distinct
+// from every source) and S (the compiled kernel's own sequence: the pair fresh from LDS, three packed readers, the in-place writer last),
+// each checked against scalar v_fma_f32 on the same inputs -- alone, beside a VALU kernel, beside a register-only fp16 MFMA kernel and
+// beside an fp16 MFMA kernel streaming its operands from memory.  RESULT on MI355X (profiles/r04_pk_hazard_probe.txt): 0 wrong results
+// in 3.9e8 wave-instructions in every case -- the form alone is NOT sufficient; what else the real pairing has (kernels starting and
+// retiring beside the victim, the GEMMs' AGPR / LDS use, ...) is open.
 //
 //   hipcc --offload-arch=gfx950 -O2 tools/pk_hazard_probe.hip -o /tmp/pk_hazard_probe && /tmp/pk_hazard_probe
 #include <hip/hip_runtime.h>

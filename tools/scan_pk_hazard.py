@@ -1,14 +1,16 @@
-"""Scan the device code of the built library for the packed-fp32 instruction form that produced wrong values on MI355X when an fp16
-matrix-core kernel ran beside it ("the two-stream defect", profiles/r04_two_stream_race.txt):
+"""Scan the device code of the built library for the packed-fp32 instruction form that sat where round 4's two-stream defect showed
+(profiles/r04_two_stream_race.txt):
 
     v_pk_{fma,mul,add}_f32  v[d:d+1], ..., v[d:d+1], ...  op_sel:[..1..]
 
 i.e. a packed fp32 op whose DESTINATION pair is also a SOURCE pair, with that source's op_sel bit set (the LOW half of the result is
-computed from the HIGH register of the pair it overwrites).  Observed: lanes 48-63 of the low result wrong, one wave-instruction in
-~1e5, only while another wave's fp16 MFMAs were in flight on the chip (the vendor library's GEMM as well as this repository's), never
-with the same arithmetic issued as scalar v_fma_f32.  The mirror form (high half reads the low register: op_sel_hi bit clear) sits in
-every GEMM epilogue of this library (20-32 per kernel), runs beside MFMAs by construction and has never moved a bit; it is listed,
-not refused.
+computed from the HIGH register of the pair it overwrites).  conv0_kernel<F32T>, compiled with its tap loop packed, returned wrong LOW
+halves in lanes 48-63 (one frame in ~1e5) whenever an fp16 GEMM kernel started beside it; the elements that moved are exactly those
+whose last writer has this form, and the kernel compiled with a scalar loop never moved.  Isolated (tools/pk_hazard_probe.hip) the form
+alone does NOT fail, so this scan is a conservative guard, not a proof: hipcc emitted the form in seven kernels (the VALU conv-layer-0
+family), all of them now scalar in that loop, and the scan keeps it from coming back unnoticed.  The mirror form (high half reads the
+low register: op_sel_hi bit clear) sits in every GEMM epilogue of this library (20-32 per kernel), runs beside MFMAs by construction
+and has never moved a bit; it is listed, not refused.
 
     python tools/scan_pk_hazard.py [path/to/libafx.so]     exit status 1 if any kernel holds the refused form
 """
