@@ -1,5 +1,8 @@
 #!/usr/bin/env bash
 # Two-stream defect, bisected on the build that showed it (git worktree _old = 26d8841, conv0_kernel<F32T> in the fp16x3 path):
+# (set-up, not part of the repository's tree: git worktree add _old 26d8841 && (cd _old && git apply ../tools/r04_race_variants.patch) &&
+#  make -C _old/real-time-deepfake-speech-detection_amd/csrc && for v in red1:-DC0_RED=1 red2:-DC0_RED=2 nopk:-DC0_NOPK=1; do
+#  make -C _old/real-time-deepfake-speech-detection_amd/csrc variant NAME=${v%%:*} DEFS=${v#*:}; done)
 # variants of that kernel (reduction by ds_bpermute; s_nop around the permlane swaps; no packed fp32 math) and of what runs beside the
 # trunk (the back-end's first kernel; any small kernel; nothing).  usage: bash tools/r04_race.sh <tag>
 set -u
