@@ -202,7 +202,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // `v_pk_fma_f32 v[d:d+1], w, v[d:d+1], acc op_sel:[0,1,0]` (the destination overwrites the sample pair whose HIGH register the LOW result
 // reads); isolated in tools/pk_hazard_probe.hip that form alone does NOT fail, so the mechanism is not pinned to it -- the tap loops of the
 // VALU conv-layer-0 kernels are scalar regardless, and tools/scan_pk_hazard.py keeps the form out of the built library.
+#ifdef AFX_C0_PACKED  // diagnostics only (make variant NAME=c0pk DEFS=-DAFX_C0_PACKED; tools/diag_conv0_pk.py): the loops as hipcc packs them
+__device__ __forceinline__ void scalar_only(float&) {}
+#else
 __device__ __forceinline__ void scalar_only(float& a) { asm volatile("" : "+v"(a)); }
+#endif
 
 // Full-wave (64-lane) all-reduce without LDS traffic.  __shfl_xor lowers to ds_bpermute
 // (an LDS-crossbar round trip + lgkmcnt wait per step -- six of them per reduction made the

@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "5165d4fa6769";
+const char afx_build_id_str[] = "394921446e70";
