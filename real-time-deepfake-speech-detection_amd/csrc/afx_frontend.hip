@@ -74,6 +74,10 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
       v[i] = a;
       sum += a;
     }
+#ifdef AFX_C0_KEEPX  // diagnostics only (with AFX_C0_PACKED): the samples stay live past the loop, so the packed loop cannot write
+#pragma unroll       // an accumulator over the sample pair it reads -- packed math WITHOUT the in-place cross-half form
+    for (int j = 0; j < 10; ++j) asm volatile("" ::"v"(xv[j]), "v"(sum));  // (after the last accumulation: it needs `sum`)
+#endif
     const float mean = wave_sum(sum) * (1.0f / 512.0f);
     float sq = 0.f;
 #pragma unroll

@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "394921446e70";
+const char afx_build_id_str[] = "d1d1e3fb9044";

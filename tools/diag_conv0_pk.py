@@ -33,16 +33,29 @@ def mats(n, dt):
 cases = [("nothing beside", None, 0), ("fp16 GEMM 512^3 x 16 (short launches)", mats(512, torch.float16), 16),
          ("fp16 GEMM 2048^3 x 2", mats(2048, torch.float16), 2), ("fp16 GEMM 8192^3 x 1 (one long launch)", mats(8192, torch.float16), 1),
          ("bf16 GEMM 2048^3 x 2", mats(2048, torch.bfloat16), 2), ("fp32 GEMM 2048^3 x 1", mats(2048, torch.float32), 1)]
+# this library's own GEMM kernels as aggressors: the 8-wave 256-wide tile (160 KB of LDS: nothing shares its CU) and a small tile
+ga, gw = torch.randn(4096, 1024, device="cuda").half(), (torch.randn(4096, 1024, device="cuda") * 0.03).half()
+sa, sw = torch.randn(2048, 1024, device="cuda").half(), (torch.randn(256, 1024, device="cuda") * 0.03).half()
+cases += [("afx 256-wide tile 4096x4096x1024 x 2", ("afx", ga, gw), 2), ("afx small tile 2048x256x1024 x 8", ("afx", sa, sw), 8)]
+
+
+def beside(m):
+    if m[0] == "afx":
+        K.gemm("fp16", m[1], m[2], out_f=False, out_h=True)
+    else:
+        torch.mm(m[0], m[1], out=m[2])
+
+
 for name, m, reps in cases:
     if m is not None:
-        torch.mm(m[0], m[1], out=m[2])
+        beside(m)
     torch.cuda.synchronize()
     bad, rows_bad, lanes = 0, 0, set()
     for it in range(60):
         if m is not None:
             with torch.cuda.stream(side):
                 for _ in range(reps):
-                    torch.mm(m[0], m[1], out=m[2])
+                    beside(m)
         out = K.conv0("fp32", wave, w.reshape(512, 10), b, g, be)
         torch.cuda.synchronize()
         if not torch.equal(out, ref):
