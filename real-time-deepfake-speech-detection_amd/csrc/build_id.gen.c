@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "d1d1e3fb9044";
+const char afx_build_id_str[] = "725db11312d5";
