@@ -30,6 +30,7 @@ PY
     pkprobe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/pk_hazard_probe.hip -o /tmp/pk_hazard_probe > $O/pk_probe_build.log 2>&1 && timeout -k 10 300 /tmp/pk_hazard_probe > $O/pk_hazard_probe.txt 2>&1; cat $O/pk_hazard_probe.txt | cut -c1-260; python tools/scan_pk_hazard.py | tee $O/scan_pk.txt; timeout -k 10 600 python -m pytest tests/test_gpu_aasist.py -q --timeout 300 -k "valu_conv0_kernels or overlaps_the_backend" > $O/pytest_pk.log 2>&1; tail -5 $O/pytest_pk.log | cut -c1-300;;
     c0pk) timeout -k 10 300 python tools/diag_conv0_pk.py 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-300 | tee $O/conv0_pk_product.txt; AFX_LIB=$PWD/real-time-deepfake-speech-detection_amd/lib/libafx_c0pk.so timeout -k 10 300 python tools/diag_conv0_pk.py 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-300 | tee $O/conv0_pk_packed.txt; AFX_LIB=$PWD/real-time-deepfake-speech-detection_amd/lib/libafx_c0pkx.so timeout -k 10 300 python tools/diag_conv0_pk.py 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-300 | tee $O/conv0_pk_packed_not_in_place.txt;;
     nopkbench) for rep in 1 2; do for vn in ${VARIANTS:-product _allpk _nopkall}; do v=$vn; [ "$vn" = product ] && v=""; L=$PWD/real-time-deepfake-speech-detection_amd/lib/libafx$v.so; AFX_LIB=$L timeout -k 10 300 python bench.py --cpu-sample 0 --steps 30 --warmup 5 2> $O/nopk_bench.err | python3 -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); c=d['config3']; k=d.get('contract',{}); print('lib', '$v' or 'product', 'student', d['value'], d['ms_per_step'], 'one/two', d['issue_probe'].get('one_stream_ms_per_step'), d['issue_probe'].get('two_stream_ms_per_step'), '| teacher', c['value'], c['ms_per_step'], '| contract', k.get('value'), c.get('contract',{}).get('value'))" | tee -a $O/nopk_bench.txt; done; done;;
+    pkunits) timeout -k 10 500 python tools/diag_pk_units.py 40 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-200 | tee $O/pk_units.txt;;
     newtests) timeout -k 10 1000 python -m pytest tests -m gpu -q --timeout 600 -k "deep_tile or overlaps_the_backend or test_gpu_bench or outlier or per_engine or forward_hooks or full_depth" > $O/pytest_new.log 2>&1; tail -8 $O/pytest_new.log | cut -c1-300;;
     stale) timeout -k 10 300 python tools/diag_s3_stale.py > $O/s3_stale.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/s3_stale.txt | cut -c1-300;;
     headrace) timeout -k 10 300 python tools/diag_head_race.py > $O/head_race.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/head_race.txt | cut -c1-300;;
