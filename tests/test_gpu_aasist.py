@@ -291,3 +291,44 @@ def test_valu_conv0_kernels_are_exact_beside_a_matrix_core_kernel(dtype, mode):
         torch.cuda.synchronize()
         moved += [(rep, i) for i, (g, w_) in enumerate(zip(got, want)) if not torch.equal(g, w_)]
     assert not moved, f"{len(moved)} of 48 batches moved beside the GEMM stream: {moved[:8]}"
+
+
+def test_packed_math_matrix_core_kernels_are_exact_beside_vendor_gemms():
+    """The other side of round 4's build split: the GEMM tiles, the attention kernels and the fused Conformer
+    chains keep their packed fp32 epilogue / softmax math.  They run it beside MFMAs by construction; this puts them beside the
+    neighbours that moved 45-57 of 60 launches of the packed VALU conv0 kernel -- the vendor library's 2048^3 fp16 / bf16 GEMMs on a
+    second stream -- and compares every output with the first one, bit for bit (tools/diag_pk_units.py is the long form:
+    profiles/r04_pk_units_beside_vendor_gemm.txt, 0 of 40 in 30 cases)."""
+    from afx import engine, kernels as K, synth
+    g = torch.Generator(device="cuda").manual_seed(3)
+
+    def rnd(*shape, dt=torch.float32, scale=1.0):
+        return (torch.randn(*shape, generator=g, device="cuda") * scale).to(dt)
+    a_big, w_fc1, b_fc1 = rnd(12736, 1024, dt=torch.float16), rnd(4096, 1024, dt=torch.float16, scale=0.03), rnd(4096)
+    a_t, w_out, b_out, resid = rnd(3184, 1024, dt=torch.float16), rnd(1024, 1024, dt=torch.float16, scale=0.03), rnd(1024), rnd(3184, 1024)
+    qkv = rnd(16 * 199, 3072, dt=torch.float16)
+    eng = engine.Engine("conformer", n_layers=1, dtype="fp16", conf_blocks=2)
+    eng.load_state_dict(synth.model_state_dict("ConformerModel", n_layers=1, n_encoders=2))
+    feats = rnd(16, 199, 1024)
+    victims = {"256-wide tile + GELU": lambda: K.gemm("fp16", a_big, w_fc1, bias=b_fc1, act="gelu", out_f=False, out_h=True)[1],
+               "deep tile + residual": lambda: K.gemm("fp16", a_t, w_out, bias=b_out, resid=resid, out_f=True, out_h=False)[0],
+               "attention": lambda: K.mhsa("fp16", qkv, 16, 199, 16),
+               "Conformer head": lambda: eng.head(feats)}
+    side = torch.cuda.Stream()
+    moved = {}
+    for dt in (torch.float16, torch.bfloat16):
+        a, b = (torch.randn(2048, 2048, device="cuda").to(dt) for _ in range(2))
+        c = torch.empty(2048, 2048, device="cuda", dtype=dt)
+        torch.mm(a, b, out=c)
+        for name, fn in victims.items():
+            ref = fn().clone()
+            torch.cuda.synchronize()
+            for _ in range(12):
+                with torch.cuda.stream(side):
+                    torch.mm(a, b, out=c)
+                    torch.mm(a, b, out=c)
+                out = fn()
+                torch.cuda.synchronize()
+                if not torch.equal(out, ref):
+                    moved[(name, str(dt))] = moved.get((name, str(dt)), 0) + 1
+    assert not moved, moved
