@@ -31,6 +31,20 @@ PY
     c0pk) timeout -k 10 300 python tools/diag_conv0_pk.py 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-300 | tee $O/conv0_pk_product.txt; AFX_LIB=$PWD/real-time-deepfake-speech-detection_amd/lib/libafx_c0pk.so timeout -k 10 300 python tools/diag_conv0_pk.py 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-300 | tee $O/conv0_pk_packed.txt; AFX_LIB=$PWD/real-time-deepfake-speech-detection_amd/lib/libafx_c0pkx.so timeout -k 10 300 python tools/diag_conv0_pk.py 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-300 | tee $O/conv0_pk_packed_not_in_place.txt;;
     nopkbench) for rep in 1 2; do for vn in ${VARIANTS:-product _allpk _nopkall}; do v=$vn; [ "$vn" = product ] && v=""; L=$PWD/real-time-deepfake-speech-detection_amd/lib/libafx$v.so; AFX_LIB=$L timeout -k 10 300 python bench.py --cpu-sample 0 --steps 30 --warmup 5 2> $O/nopk_bench.err | python3 -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); c=d['config3']; k=d.get('contract',{}); print('lib', '$v' or 'product', 'student', d['value'], d['ms_per_step'], 'one/two', d['issue_probe'].get('one_stream_ms_per_step'), d['issue_probe'].get('two_stream_ms_per_step'), '| teacher', c['value'], c['ms_per_step'], '| contract', k.get('value'), c.get('contract',{}).get('value'))" | tee -a $O/nopk_bench.txt; done; done;;
     pkunits) timeout -k 10 500 python tools/diag_pk_units.py 40 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-200 | tee $O/pk_units.txt;;
+    vendornames) R=$PWD; (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/$O/vn -- python3 $R/tools/diag_vendor_kernel_names.py > $R/$O/vn.log 2>&1); python3 - $O <<'PYEOF'
+import csv, glob, sys, collections
+seen = collections.OrderedDict()
+for f in glob.glob(sys.argv[1] + "/vn/**/*kernel_trace.csv", recursive=True):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    for r in rows:
+        n = r["Kernel_Name"]
+        if n.startswith("Cijk") or "gemm" in n.lower() or "Custom_" in n:
+            k = (n, r["Grid_Size_X"], r["Workgroup_Size_X"], r.get("LDS_Block_Size", r.get("LDS_Block_Size_v", "")), r.get("VGPR_Count", ""), r.get("Accum_VGPR_Count", ""))
+            seen.setdefault(k, [0, 0]); seen[k][0] += 1; seen[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+for (n, gx, wg, lds, vg, ag), (c, t) in seen.items():
+    print(f"x{c} {t / c / 1e3:8.1f} us  grid {gx} wg {wg} lds {lds} vgpr {vg} agpr {ag}  {n[:200]}")
+PYEOF
+    ;;
     newtests) timeout -k 10 1000 python -m pytest tests -m gpu -q --timeout 600 -k "deep_tile or overlaps_the_backend or test_gpu_bench or outlier or per_engine or forward_hooks or full_depth" > $O/pytest_new.log 2>&1; tail -8 $O/pytest_new.log | cut -c1-300;;
     stale) timeout -k 10 300 python tools/diag_s3_stale.py > $O/s3_stale.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/s3_stale.txt | cut -c1-300;;
     headrace) timeout -k 10 300 python tools/diag_head_race.py > $O/head_race.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/head_race.txt | cut -c1-300;;
