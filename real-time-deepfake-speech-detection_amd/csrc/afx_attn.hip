@@ -311,9 +311,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mhsa_split_kernel(const float* __r
   typedef f16x4 V4;
   constexpr int NKT = KS * 2, KEYS = KS * 32;
   constexpr int ATT_KEYS = KS <= 7 ? afx::ATT_KEYS : KS * 32;                 // (8 steps = the ring's 256 slots)
-  constexpr int ATT_VT_STRIDE = KS <= 7 ? afx::ATT_VT_STRIDE : KS * 32 + 8;
   __shared__ __attribute__((aligned(16))) char k_lds[2][ATT_KEYS * 128];        // [hi / lo][key][64 halfs], swizzled rows
-  __shared__ __attribute__((aligned(16))) Tt vt_lds[2][64 * ATT_VT_STRIDE];     // [hi / lo][dim][key]
+  __shared__ __attribute__((aligned(16))) Tt vt_lds[2][ATT_KEYS * 64];          // [hi / lo][key][64 dims], chunk c at c ^ (key & 7): V stays
+                                                                                // row-major, the PV fragments are transposing reads (mhsa_kernel's VTR)
   __shared__ __attribute__((aligned(16))) float mask_lds[ATT_KEYS];
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -350,11 +350,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mhsa_split_kernel(const float* __r
       const int off = key * 128 + ((c ^ ((key >> 1) & 7)) * 16);
       *(V8*)(k_lds[0] + off) = kh;
       *(V8*)(k_lds[1] + off) = kl;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        vt_lds[0][(c * 8 + i) * ATT_VT_STRIDE + key] = vh[i];
-        vt_lds[1][(c * 8 + i) * ATT_VT_STRIDE + key] = vl[i];
-      }
+      const int voff = key * 128 + ((c ^ (key & 7)) * 16);
+      *(V8*)((char*)vt_lds[0] + voff) = vh;
+      *(V8*)((char*)vt_lds[1] + voff) = vl;
     }
   }
   for (int i = tid; i < KEYS; i += 64 * NW) mask_lds[i] = (RING ? (i & 15) < ring.cnt[(i >> 4) & 15] : i < T) ? 0.f : -1e30f;
@@ -418,16 +416,19 @@ __global__ __launch_bounds__(64 * NW, 2) void mhsa_split_kernel(const float* __r
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         V8 vh, vl;
+        // lane 4q + p of a 16-lane group supplies the address of key (block + q), dims 16 nt + 4p .. + 3; the group's lane i receives
+        // dim 16 nt + i of the block's 4 keys.  Blocks: keys 32 s2 + 4g .. + 3 (first four k-slots) and 16 beyond (last four).
+        typedef short tr4 __attribute__((__vector_size__(4 * sizeof(short))));
+        const int tq = ql >> 2, tp = ql & 3, chunk = nt * 2 + (tp >> 1);
+        const int k_a = s2 * 32 + g * 4 + tq, k_b = k_a + 16;
+        const int off_a = k_a * 128 + ((chunk ^ (k_a & 7)) * 16) + (tp & 1) * 8, off_b = k_b * 128 + ((chunk ^ (k_b & 7)) * 16) + (tp & 1) * 8;
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl) {
-          const Tt* vr = vt_lds[hl] + (nt * 16 + ql) * ATT_VT_STRIDE + s2 * 32 + g * 4;
-          const V4 lo4 = *(const V4*)vr, hi4 = *(const V4*)(vr + 16);
-          V8& dst = hl ? vl : vh;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            dst[r] = lo4[r];
-            dst[4 + r] = hi4[r];
-          }
+          const char* vb_ = (const char*)vt_lds[hl];
+          union { tr4 v[2]; V8 f; } u;
+          u.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)(vb_ + off_a));
+          u.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)(vb_ + off_b));
+          (hl ? vl : vh) = u.f;
         }
         o[nt] = FP16::mfma(vl, ph, o[nt]);
         o[nt] = FP16::mfma(vh, pl, o[nt]);

@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "725db11312d5";
+const char afx_build_id_str[] = "4ba43b4b5f6d";
