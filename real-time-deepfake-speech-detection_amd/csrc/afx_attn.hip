@@ -373,19 +373,34 @@ __global__ __launch_bounds__(64 * NW, 2) void mhsa_split_kernel(const float* __r
       split8(*(const f32x4*)qp, *(const f32x4*)(qp + 4), qh[ks], qlo[ks]);
     }
     f32x4 s[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+    // one key tile's four fragments (hi / lo x two k-steps) are requested before the previous tile's six MFMAs (round 4, late: the
+    // loop used to read, wait and multiply tile by tile -- 21.8 -> see DESIGN section 4); the sched_barriers keep hipcc from hoisting
+    // all 56 fragment reads to the top (that spilled)
+    auto read_k = [&](int kt, V8 (&kf)[2][2]) {
       const int krow = kt * 16 + ql, sw = (krow >> 1) & 7;
-      s[kt] = *(const f32x4*)(mask_lds + kt * 16 + g * 4);  // the accumulators start at the key mask (0 / -1e30)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int off = krow * 128 + (((ks * 4 + g) ^ sw) * 16);
-        const V8 kh = *(const V8*)(k_lds[0] + off), kl = *(const V8*)(k_lds[1] + off);
-        s[kt] = FP16::mfma(kl, qh[ks], s[kt]);   // the small terms first, the large one last
-        s[kt] = FP16::mfma(kh, qlo[ks], s[kt]);
-        s[kt] = FP16::mfma(kh, qh[ks], s[kt]);
+        kf[ks][0] = *(const V8*)(k_lds[0] + off);
+        kf[ks][1] = *(const V8*)(k_lds[1] + off);
       }
-      __builtin_amdgcn_sched_barrier(0);  // (keeps hipcc from hoisting all 56 fragment reads to the top: that spilled)
+    };
+    V8 kfa[2][2], kfb[2][2];
+    read_k(0, kfa);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      V8(&cur)[2][2] = (kt & 1) ? kfb : kfa;
+      V8(&nxt)[2][2] = (kt & 1) ? kfa : kfb;
+      if (kt + 1 < NKT) read_k(kt + 1, nxt);
+      s[kt] = *(const f32x4*)(mask_lds + kt * 16 + g * 4);  // the accumulators start at the key mask (0 / -1e30)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s[kt] = FP16::mfma(cur[ks][1], qh[ks], s[kt]);   // the small terms first, the large one last
+        s[kt] = FP16::mfma(cur[ks][0], qlo[ks], s[kt]);
+        s[kt] = FP16::mfma(cur[ks][0], qh[ks], s[kt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     const float c2 = scale * 1.4426950408889634f;
     float mx = -1e30f;
@@ -409,18 +424,16 @@ __global__ __launch_bounds__(64 * NW, 2) void mhsa_split_kernel(const float* __r
     f32x4 o[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) {
-      V8 ph, pl;
-      split8(s[2 * s2], s[2 * s2 + 1], ph, pl);
+    // V fragments by transposing reads: lane 4q + p of a 16-lane group supplies the address of key (block + q), dims 16 nt + 4p .. + 3;
+    // the group's lane i receives dim 16 nt + i of the block's 4 keys.  Blocks: keys 32 s2 + 4g .. + 3 (first four k-slots) and 16
+    // beyond (last four).  The next 32-key step's eight fragments (hi / lo x four dim tiles) are requested before this step's MFMAs.
+    auto read_v = [&](int s2, V8 (&vf)[4][2]) {
+      typedef short tr4 __attribute__((__vector_size__(4 * sizeof(short))));
+      const int tq = ql >> 2, tp = ql & 3;
+      const int k_a = s2 * 32 + g * 4 + tq, k_b = k_a + 16;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        V8 vh, vl;
-        // lane 4q + p of a 16-lane group supplies the address of key (block + q), dims 16 nt + 4p .. + 3; the group's lane i receives
-        // dim 16 nt + i of the block's 4 keys.  Blocks: keys 32 s2 + 4g .. + 3 (first four k-slots) and 16 beyond (last four).
-        typedef short tr4 __attribute__((__vector_size__(4 * sizeof(short))));
-        const int tq = ql >> 2, tp = ql & 3, chunk = nt * 2 + (tp >> 1);
-        const int k_a = s2 * 32 + g * 4 + tq, k_b = k_a + 16;
+        const int chunk = nt * 2 + (tp >> 1);
         const int off_a = k_a * 128 + ((chunk ^ (k_a & 7)) * 16) + (tp & 1) * 8, off_b = k_b * 128 + ((chunk ^ (k_b & 7)) * 16) + (tp & 1) * 8;
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl) {
@@ -428,11 +441,25 @@ __global__ __launch_bounds__(64 * NW, 2) void mhsa_split_kernel(const float* __r
           union { tr4 v[2]; V8 f; } u;
           u.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)(vb_ + off_a));
           u.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)(vb_ + off_b));
-          (hl ? vl : vh) = u.f;
+          vf[nt][hl] = u.f;
         }
-        o[nt] = FP16::mfma(vl, ph, o[nt]);
-        o[nt] = FP16::mfma(vh, pl, o[nt]);
-        o[nt] = FP16::mfma(vh, ph, o[nt]);
+      }
+    };
+    V8 vfa[4][2], vfb[4][2];
+    read_v(0, vfa);
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      V8(&cur)[4][2] = (s2 & 1) ? vfb : vfa;
+      V8(&nxt)[4][2] = (s2 & 1) ? vfa : vfb;
+      if (s2 + 1 < KS) read_v(s2 + 1, nxt);
+      V8 ph, pl;
+      split8(s[2 * s2], s[2 * s2 + 1], ph, pl);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        o[nt] = FP16::mfma(cur[nt][1], ph, o[nt]);
+        o[nt] = FP16::mfma(cur[nt][0], pl, o[nt]);
+        o[nt] = FP16::mfma(cur[nt][0], ph, o[nt]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "4ba43b4b5f6d";
+const char afx_build_id_str[] = "9746b05cf6b1";
