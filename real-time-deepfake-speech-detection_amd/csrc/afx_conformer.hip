@@ -294,9 +294,8 @@ __global__ __launch_bounds__(64 * NW) void conf_attn_mfma_kernel(const float* __
         }
     }
     // relative term for every offset this tile can see: r_local = r - q0, E row = r - (N-1) + max_pos
-#pragma unroll
-    for (int rp = 0; rp < CA_NKT; rp += 2) {
-      V8 ef[2][2];
+    // (round 4, late: the table rows of the NEXT pair of offset tiles -- L2 round trips -- are requested before this pair's MFMAs)
+    auto read_e = [&](int rp, V8 (&ef)[2][2]) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         int er = q0 + (rp + u) * 16 + ql - (N - 1);
@@ -305,6 +304,14 @@ __global__ __launch_bounds__(64 * NW) void conf_attn_mfma_kernel(const float* __
         ef[u][0] = *(const V8*)ep;
         ef[u][1] = *(const V8*)(ep + 32);
       }
+    };
+    V8 efa[2][2], efb[2][2];
+    read_e(0, efa);
+#pragma unroll
+    for (int rp = 0; rp < CA_NKT; rp += 2) {
+      V8(&ef)[2][2] = (rp & 2) ? efb : efa;
+      V8(&efn)[2][2] = (rp & 2) ? efa : efb;
+      if (rp + 2 < CA_NKT) read_e(rp + 2, efn);
       f32x4 r2[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) r2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -317,9 +324,7 @@ __global__ __launch_bounds__(64 * NW) void conf_attn_mfma_kernel(const float* __
     }
     // S^T tiles: s[kt][c] = S1[q0+ql][16kt + 4g + c], two key tiles at a time
     f32x4 s[CA_NKT];
-#pragma unroll
-    for (int kp = 0; kp < CA_NKT; kp += 2) {
-      V8 kf[2][2];
+    auto read_k = [&](int kp, V8 (&kf)[2][2]) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int krow = (kp + u) * 16 + ql;
@@ -327,6 +332,14 @@ __global__ __launch_bounds__(64 * NW) void conf_attn_mfma_kernel(const float* __
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) kf[u][ks] = *(const V8*)(k_lds + krow * 128 + (((ks * 4 + g) ^ sw) * 16));
       }
+    };
+    V8 kfa[2][2], kfb[2][2];
+    read_k(0, kfa);
+#pragma unroll
+    for (int kp = 0; kp < CA_NKT; kp += 2) {
+      V8(&kf)[2][2] = (kp & 2) ? kfb : kfa;
+      V8(&kfn)[2][2] = (kp & 2) ? kfa : kfb;
+      if (kp + 2 < CA_NKT) read_k(kp + 2, kfn);  // the next pair's fragments under this pair's MFMAs
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 2; ++u) s[kp + u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -366,15 +379,7 @@ __global__ __launch_bounds__(64 * NW) void conf_attn_mfma_kernel(const float* __
     f32x4 o[DT];
 #pragma unroll
     for (int nt = 0; nt < DT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s2 = 0; s2 < CA_KS; ++s2) {
-      V8 pf;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        pf[c] = (Tt)s[2 * s2][c];
-        pf[4 + c] = (Tt)s[2 * s2 + 1][c];
-      }
-      V8 vf[DT];
+    auto read_v = [&](int s2, V8 (&vf)[DT]) {
 #pragma unroll
       for (int nt = 0; nt < DT; ++nt) {
         const Tt* vr = vt_lds + (nt * 16 + ql) * CA_VT_STRIDE + s2 * 32 + g * 4;
@@ -385,6 +390,20 @@ __global__ __launch_bounds__(64 * NW) void conf_attn_mfma_kernel(const float* __
           vf[nt][c] = lo[c];
           vf[nt][4 + c] = hi[c];
         }
+      }
+    };
+    V8 vfa[DT], vfb[DT];
+    read_v(0, vfa);
+#pragma unroll
+    for (int s2 = 0; s2 < CA_KS; ++s2) {
+      V8(&vf)[DT] = (s2 & 1) ? vfb : vfa;
+      V8(&vfn)[DT] = (s2 & 1) ? vfa : vfb;
+      if (s2 + 1 < CA_KS) read_v(s2 + 1, vfn);  // the next key step's fragments under this step's MFMAs
+      V8 pf;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        pf[c] = (Tt)s[2 * s2][c];
+        pf[4 + c] = (Tt)s[2 * s2 + 1][c];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

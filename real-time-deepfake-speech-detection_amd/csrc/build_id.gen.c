@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "9746b05cf6b1";
+const char afx_build_id_str[] = "f8678a57401f";

@@ -46,6 +46,7 @@ for (n, gx, wg, lds, vg, ag), (c, t) in seen.items():
 PYEOF
     ;;
     vtr) for rep in 1 2; do timeout -k 10 200 python tools/diag_mhsa_split_vtr.py 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-200 | tee -a $O/vtr.txt; AFX_LIB=$PWD/real-time-deepfake-speech-detection_amd/lib/libafx_vtr.so timeout -k 10 200 python tools/diag_mhsa_split_vtr.py 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-200 | tee -a $O/vtr.txt; done;;
+    capipe) for rep in 1 2; do timeout -k 10 200 python tools/diag_conf_attn_pipe.py 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-200 | tee -a $O/capipe.txt; AFX_LIB=$PWD/real-time-deepfake-speech-detection_amd/lib/libafx_ca.so timeout -k 10 200 python tools/diag_conf_attn_pipe.py 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|check(" | cut -c1-200 | tee -a $O/capipe.txt; done;;
     newtests) timeout -k 10 1000 python -m pytest tests -m gpu -q --timeout 600 -k "deep_tile or overlaps_the_backend or test_gpu_bench or outlier or per_engine or forward_hooks or full_depth" > $O/pytest_new.log 2>&1; tail -8 $O/pytest_new.log | cut -c1-300;;
     stale) timeout -k 10 300 python tools/diag_s3_stale.py > $O/s3_stale.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/s3_stale.txt | cut -c1-300;;
     headrace) timeout -k 10 300 python tools/diag_head_race.py > $O/head_race.txt 2>&1; grep -v "amdgpu.ids\|RuntimeWarning\|check(" $O/head_race.txt | cut -c1-300;;
