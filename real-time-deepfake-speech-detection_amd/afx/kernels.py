@@ -109,7 +109,7 @@ def conf_attn(dtype, q, kv, rel, B, N, H, dh, max_pos=512):
 
 def conf_attn_mfma(dtype, q, kv, rel, B, N, H, dh, max_pos=512):
     """Matrix-core form of conf_attn (head dim 36, N <= 209): the table is packed to (2*max_pos+1, 64) halfs first."""
-    rel_h = pack_linear(dtype, rel, 64)
+    rel_h = pack_linear("fp32" if dtype == "fp16x3" else dtype, rel, 64)  # (split precision: fp32 rows, split inside the kernel)
     out = torch.empty(B * N, H * dh, dtype=torch_dtype(dtype), device=q.device)
     check(call_on(q, lib().afx_k_conf_attn_mfma, DTYPES[dtype], ptr(q), q.stride(0), ptr(kv), kv.stride(0), ptr(rel_h), max_pos, B, N,
                                      H, dh, ptr(out), H * dh))

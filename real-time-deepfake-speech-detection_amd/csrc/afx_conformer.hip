@@ -427,6 +427,267 @@ __global__ __launch_bounds__(64 * NW) void conf_attn_mfma_kernel(const float* __
 }
 
 // ---------------------------------------------------------------------------------
+// The same one-pass Shaw attention in SPLIT PRECISION (the engine's dtype "fp16x3", round 4): fp32 q | k | v rows and an fp32 table
+// (rows padded to 64) in, fp32 rows out; every product -- E Q^T, K Q^T, V^T P^T -- as three fp16 MFMAs on hi / lo halves
+// (x ~ xh + xl: xl.yh + xh.yl + xh.yh, the small terms first), K and V^T staged as hi and lo images, Q / E / P split in registers.
+// It replaces the fp32 VALU kernel in that mode for N <= 209 (147 -> see DESIGN section 4, us per launch at B = 64).  LDS: two K
+// images, two V^T images and the waves' relative-term tiles = 156.5 KB with FOUR waves (seven do not fit).
+// ---------------------------------------------------------------------------------
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void conf_attn_split_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ kv, long ldkv,
+                                                                  const float* __restrict__ rel64, int max_pos, int N, int H,
+                                                                  float* __restrict__ out, long ldo, const int* __restrict__ lens, int len_add) {
+  typedef _Float16 Tt;
+  typedef f16x8 V8;
+  typedef f16x4 V4;
+  const int Nrow = N;
+  if (lens) N = lens[blockIdx.y] + len_add;
+  constexpr int DT = (DH + 15) / 16;
+  static_assert(DH % 4 == 0 && DH <= 64, "head dim");
+  extern __shared__ __attribute__((aligned(16))) float sm_f[];
+  char* sm = (char*)sm_f;
+  constexpr int KB = CA_KEYS * 128, VB = 16 * DT * CA_VT_STRIDE * 2;
+  char* k_lds[2] = {sm, sm + KB};                                        // [hi / lo][224][128 B]
+  Tt* vt_lds[2] = {(Tt*)(sm + 2 * KB), (Tt*)(sm + 2 * KB + VB)};         // [hi / lo][16 DT][232]
+  float* r_lds = (float*)(sm + 2 * KB + 2 * VB);                         // [NW waves][16][228]
+  constexpr int NT = 64 * NW;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int inner = H * DH;
+  auto split4 = [](const f32x4& a, V4& hi, V4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      hi[i] = (Tt)a[i];
+      lo[i] = (Tt)(a[i] - (float)hi[i]);
+    }
+  };
+  auto split8 = [](const f32x4& a, const f32x4& c, V8& hi, V8& lo) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      hi[r] = (Tt)a[r];
+      hi[4 + r] = (Tt)c[r];
+      lo[r] = (Tt)(a[r] - (float)hi[r]);
+      lo[4 + r] = (Tt)(c[r] - (float)hi[4 + r]);
+    }
+  };
+  // ---- stage K (hi / lo, swizzled, zero padded) and V^T (hi / lo) -----------------------
+  for (int i = tid; i < (2 * KB + 2 * VB) / 16; i += NT) ((u32x4*)sm)[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  {
+    constexpr int IT = (209 * (DH / 4) + NT - 1) / NT;
+    f32x4 kreg[IT], vreg[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * NT;
+      if (idx < N * (DH / 4)) {
+        const int key = idx / (DH / 4), q4 = idx % (DH / 4);
+        const float* row = kv + ((long)b * Nrow + key) * ldkv + h * DH + q4 * 4;
+        kreg[it] = *(const f32x4*)row;
+        vreg[it] = *(const f32x4*)(row + inner);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * NT;
+      if (idx < N * (DH / 4)) {
+        const int key = idx / (DH / 4), q4 = idx % (DH / 4);
+        V4 kh, kl, vh, vl;
+        split4(kreg[it], kh, kl);
+        split4(vreg[it], vh, vl);
+        const int c = q4 >> 1;
+        const int off = key * 128 + ((c ^ ((key >> 1) & 7)) * 16) + (q4 & 1) * 8;
+        *(V4*)(k_lds[0] + off) = kh;
+        *(V4*)(k_lds[1] + off) = kl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          vt_lds[0][(q4 * 4 + i) * CA_VT_STRIDE + key] = vh[i];
+          vt_lds[1][(q4 * 4 + i) * CA_VT_STRIDE + key] = vl[i];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int ql = lane & 15, g = lane >> 4;
+  const float scale = 1.0f / sqrtf((float)DH);
+  float* rw = r_lds + wave * 16 * CA_RS;
+  const int nqt = (N + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += NW) {
+    const int q0 = qt * 16;
+    int qrow = q0 + ql;
+    qrow = qrow < N ? qrow : N - 1;
+    // Q fragments (scaled, hi / lo): k-slot (g, j) of step ks <-> head dim 32 ks + 8 g + j
+    V8 qh[2], qlo[2];
+    {
+      const float* qp = q + ((long)b * Nrow + qrow) * ldq + h * DH;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        f32x4 t[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int d = ks * 32 + g * 8 + half * 4;
+          t[half] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (d < DH) t[half] = *(const f32x4*)(qp + d) * scale;
+        }
+        split8(t[0], t[1], qh[ks], qlo[ks]);
+      }
+    }
+    // relative term for every offset this tile can see (table rows from L2, fp32, split here); the next pair's rows are requested
+    // before this pair's MFMAs
+    auto read_e = [&](int rp, f32x4 (&ef)[2][2][2]) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        int er = q0 + (rp + u) * 16 + ql - (N - 1);
+        er = er < -max_pos ? -max_pos : (er > max_pos ? max_pos : er);
+        const float* ep = rel64 + (long)(er + max_pos) * 64 + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          ef[u][ks][0] = *(const f32x4*)(ep + ks * 32);
+          ef[u][ks][1] = *(const f32x4*)(ep + ks * 32 + 4);
+        }
+      }
+    };
+    f32x4 efa[2][2][2], efb[2][2][2];
+    read_e(0, efa);
+#pragma unroll
+    for (int rp = 0; rp < CA_NKT; rp += 2) {
+      f32x4(&ef)[2][2][2] = (rp & 2) ? efb : efa;
+      f32x4(&efn)[2][2][2] = (rp & 2) ? efa : efb;
+      if (rp + 2 < CA_NKT) read_e(rp + 2, efn);
+      f32x4 r2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) r2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          V8 eh, el;
+          split8(ef[u][ks][0], ef[u][ks][1], eh, el);
+          r2[u] = FP16::mfma(el, qh[ks], r2[u]);
+          r2[u] = FP16::mfma(eh, qlo[ks], r2[u]);
+          r2[u] = FP16::mfma(eh, qh[ks], r2[u]);
+        }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) *(f32x4*)(rw + ql * CA_RS + (rp + u) * 16 + g * 4) = r2[u];
+    }
+    // S^T tiles: s[kt][c] = S1[q0+ql][16kt + 4g + c]; one key tile's four fragments ahead of the MFMAs
+    f32x4 s[CA_NKT];
+    auto read_k = [&](int kt, V8 (&kf)[2][2]) {
+      const int krow = kt * 16 + ql, sw = (krow >> 1) & 7;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = krow * 128 + (((ks * 4 + g) ^ sw) * 16);
+        kf[ks][0] = *(const V8*)(k_lds[0] + off);
+        kf[ks][1] = *(const V8*)(k_lds[1] + off);
+      }
+    };
+    V8 kfa[2][2], kfb[2][2];
+    read_k(0, kfa);
+#pragma unroll
+    for (int kt = 0; kt < CA_NKT; ++kt) {
+      V8(&kf)[2][2] = (kt & 1) ? kfb : kfa;
+      V8(&kfn)[2][2] = (kt & 1) ? kfa : kfb;
+      if (kt + 1 < CA_NKT) read_k(kt + 1, kfn);
+      __builtin_amdgcn_sched_barrier(0);
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s[kt] = FP16::mfma(kf[ks][1], qh[ks], s[kt]);
+        s[kt] = FP16::mfma(kf[ks][0], qlo[ks], s[kt]);
+        s[kt] = FP16::mfma(kf[ks][0], qh[ks], s[kt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // add the shifted relative term, mask, softmax (the wave's own R tile: LDS accesses of one wave complete in order)
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < CA_NKT; ++kt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int key = kt * 16 + g * 4 + c;
+        int rl = ql + (N - 1) - key;
+        rl = rl < 0 ? 0 : rl;
+        const float v = key < N ? s[kt][c] + rw[ql * CA_RS + rl] : -1e30f;
+        s[kt][c] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = rows_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < CA_NKT; ++kt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float e = __builtin_amdgcn_exp2f((s[kt][c] - mx) * 1.4426950408889634f);
+        s[kt][c] = e;
+        sum += e;
+      }
+    sum = rows_sum(sum);
+    const float rinv = 1.0f / sum;
+    // O = P V : k-slot (g, jj) of step s2 <-> key 32*s2 + 16*(jj>>2) + 4g + (jj&3)
+    f32x4 o[DT];
+#pragma unroll
+    for (int nt = 0; nt < DT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto read_v = [&](int s2, V8 (&vf)[DT][2]) {
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+          const Tt* vr = vt_lds[hl] + (nt * 16 + ql) * CA_VT_STRIDE + s2 * 32 + g * 4;
+          const V4 lo = *(const V4*)vr;
+          const V4 hi = *(const V4*)(vr + 16);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            vf[nt][hl][c] = lo[c];
+            vf[nt][hl][4 + c] = hi[c];
+          }
+        }
+    };
+    V8 vfa[DT][2], vfb[DT][2];
+    read_v(0, vfa);
+#pragma unroll
+    for (int s2 = 0; s2 < CA_KS; ++s2) {
+      V8(&vf)[DT][2] = (s2 & 1) ? vfb : vfa;
+      V8(&vfn)[DT][2] = (s2 & 1) ? vfa : vfb;
+      if (s2 + 1 < CA_KS) read_v(s2 + 1, vfn);
+      V8 ph, pl;
+      split8(s[2 * s2], s[2 * s2 + 1], ph, pl);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) {
+        o[nt] = FP16::mfma(vf[nt][1], ph, o[nt]);
+        o[nt] = FP16::mfma(vf[nt][0], pl, o[nt]);
+        o[nt] = FP16::mfma(vf[nt][0], ph, o[nt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int qi = q0 + ql;
+    if (qi < N) {
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) {
+        const int d = nt * 16 + g * 4;
+        if (d < DH) *(f32x4*)(out + ((long)b * Nrow + qi) * ldo + h * DH + d) = o[nt] * rinv;
+      }
+    }
+  }
+}
+// fp32 rows in / out, the table as fp32 rows padded to 64 (launch_pack_linear(..., 64, ..., DT_FP32)); N <= 209, head dim 36
+const char* launch_conf_attn_split(const float* q, long ldq, const float* kv, long ldkv, const float* rel64, int max_pos, int B, int N,
+                                   int H, int dh, float* out, long ldo, hipStream_t s, const int* lens, int len_add) {
+  if (dh != 36) return "conf_attn_split: built for head dim 36 (emb 144 / 4 heads)";
+  if (N <= 0 || N + 15 > CA_KEYS || B <= 0 || B > 65535) return "conf_attn_split: 1..209 tokens";
+  if ((ldq % 4) || (ldkv % 4) || (ldo % 4)) return "conf_attn_split: row strides must be multiples of 4";
+  constexpr int DT = 3, NW = 4;
+  const int lds = 2 * CA_KEYS * 128 + 2 * 16 * DT * CA_VT_STRIDE * 2 + NW * 16 * CA_RS * 4;
+  static LdsLimit lim;
+  hipError_t e = lim.ensure((const void*)conf_attn_split_kernel<36, NW>, lds);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL((conf_attn_split_kernel<36, NW>), dim3(H, B), dim3(64 * NW), lds, s, q, ldq, kv, ldkv, rel64, max_pos, N, H, out, ldo, lens, len_add);
+    e = hipGetLastError();
+  }
+  return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------
 // The matrix-core Shaw attention for sequences of any length (clips beyond 4 s): one workgroup per
 // (utterance, head, 64-query chunk), a wave keeps ONE 16-query tile -- Q fragments, output accumulators and
 // row statistics in registers -- while the keys pass through LDS 128 at a time.  Per (query tile, key

@@ -1242,6 +1242,9 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
       if (e->conf_attn_mfma && dt != DT_FP32 && e->dh == 36)
         return launch_conf_attn_mfma(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner, K.rel_h, 512, B, N, e->heads,
                                      e->dh, w.ao, Ep, dt, s, w.lens, 1);
+      if (e->conf_attn_mfma && e->s3 && e->dh == 36 && N <= 209)  // split precision: the one-pass kernel on hi / lo halves, fp32 rows out
+        return launch_conf_attn_split(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner, (const float*)K.rel_h, 512, B, N,
+                                      e->heads, e->dh, (float*)w.ao, Ep, s, w.lens, 1);
       return launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
                               e->F(P + "attn.fn.rel_pos_emb.weight"), 512, B, N, e->heads, e->dh, w.ao, Ep, dt, s, w.lens, 1);
     }));
@@ -1299,6 +1302,9 @@ static int run_conformer(afx_engine* e, int B, int T, Ws& w, float* logits, hipS
       if (e->conf_attn_mfma && dt != DT_FP32 && e->dh == 36)
         return launch_conf_attn_mfma(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner, K.rel_h, 512, B, N, e->heads,
                                      e->dh, w.ao, Ep, dt, s, w.lens, 1);
+      if (e->conf_attn_mfma && e->s3 && e->dh == 36 && N <= 209)  // split precision: the one-pass kernel on hi / lo halves, fp32 rows out
+        return launch_conf_attn_split(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner, (const float*)K.rel_h, 512, B, N,
+                                      e->heads, e->dh, (float*)w.ao, Ep, s, w.lens, 1);
       return launch_conf_attn(w.qkv32, 3 * e->inner, w.qkv32 + e->inner, 3 * e->inner,
                               e->F(P + "attn.fn.rel_pos_emb.weight"), 512, B, N, e->heads, e->dh, w.ao, Ep, dt, s, w.lens, 1);
     }));
@@ -2047,6 +2053,8 @@ extern "C" int afx_k_conf_attn(int dtype, const float* q, long ldq, const float*
 }
 extern "C" int afx_k_conf_attn_mfma(int dtype, const float* q, long ldq, const float* kv, long ldkv, const void* rel_h,
                                     int max_pos, int B, int N, int H, int dh, void* out_h, long ldo, void* stream) {
+  if (dtype == DT_FP16X3)  // split precision: fp32 rows out, the table as fp32 rows padded to 64 (afx_k_pack_linear with dtype fp32)
+    KRET(launch_conf_attn_split(q, ldq, kv, ldkv, (const float*)rel_h, max_pos, B, N, H, dh, (float*)out_h, ldo, (hipStream_t)stream));
   KRET(launch_conf_attn_mfma(q, ldq, kv, ldkv, rel_h, max_pos, B, N, H, dh, out_h, ldo, dtype, (hipStream_t)stream));
 }
 extern "C" int afx_k_conf_dwconv(int dtype, const float* x, long ldx, const float* w, const float* bias,

@@ -206,6 +206,9 @@ const char* launch_conf_attn(const float* q, long ldq, const float* kv, long ldk
                              const int* lens = nullptr, int len_add = 0);  // ragged: tokens of utterance b = lens[b] + len_add
 // the same on the matrix cores: rel_h is the embedding table in operand type, rows padded to 64
 // (pack_linear with Kpad = 64); N <= 209 tokens, head dim 36
+// the same in split precision (dtype "fp16x3"): fp32 rows in / out, rel64 = the table as fp32 rows padded to 64; N <= 209, head dim 36
+const char* launch_conf_attn_split(const float* q, long ldq, const float* kv, long ldkv, const float* rel64, int max_pos, int B, int N,
+                                   int H, int dh, float* out, long ldo, hipStream_t s, const int* lens = nullptr, int len_add = 0);
 const char* launch_conf_attn_mfma(const float* q, long ldq, const float* kv, long ldkv, const void* rel_h, int max_pos,
                                   int B, int N, int H, int dh, void* out_h, long ldo, int dtype, hipStream_t s,
                                   const int* lens = nullptr, int len_add = 0);

@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "f8678a57401f";
+const char afx_build_id_str[] = "037c91e27bb3";

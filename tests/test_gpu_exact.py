@@ -138,6 +138,33 @@ def test_fp32_conformer_student_logits(dtype):
     assert err <= 1e-5
 
 
+@pytest.mark.parametrize("N", [200, 209, 50, 13])
+def test_split_precision_shaw_attention_on_matrix_cores(K, N):
+    """dtype "fp16x3": the one-pass Shaw attention with every product -- E Q^T, K Q^T, V^T P^T -- as three fp16 MFMAs on hi / lo halves
+    (conf_attn_split_kernel) against the definition in fp64, and against the fp32 VALU kernel it replaces in that mode (exact mode
+    keeps the VALU kernel); a ragged pair of lengths through the same call."""
+    B, H, dh = 3, 4, 36
+    g = torch.Generator().manual_seed(100 + N)
+    q = torch.randn(B * N, H * dh, generator=g)
+    kv = torch.randn(B * N, 2 * H * dh, generator=g)
+    rel = torch.randn(1025, dh, generator=g)
+    got = K.conf_attn_mfma("fp16x3", q.cuda(), kv.cuda(), rel.cuda(), B, N, H, dh).cpu()
+    assert got.dtype == torch.float32
+    valu = K.conf_attn("fp32", q.cuda(), kv.cuda(), rel.cuda(), B, N, H, dh).cpu()
+    qq = (q.double() * dh ** -0.5).view(B, N, H, dh).transpose(1, 2)
+    kk = kv[:, : H * dh].double().reshape(B, N, H, dh).transpose(1, 2)
+    vv = kv[:, H * dh:].double().reshape(B, N, H, dh).transpose(1, 2)
+    seq = torch.arange(N)
+    dist = (seq[:, None] - seq[None, :]).clamp(-512, 512) + 512
+    dots = torch.einsum("bhid,bhjd->bhij", qq, kk)
+    for bi in range(B):
+        dots[bi] += torch.einsum("hnd,nrd->hnr", qq[bi], rel.double()[dist])
+    ref = torch.einsum("bhij,bhjd->bhid", torch.softmax(dots, -1), vv).transpose(1, 2).reshape(B * N, H * dh)
+    err, err_valu = (got.double() - ref).abs().max().item(), (valu.double() - ref).abs().max().item()
+    print(f"N {N}: split-precision MFMA kernel max|d| {err:.2e}, fp32 VALU kernel {err_valu:.2e} (vs fp64)")
+    assert err <= 5e-6 and err_valu <= 5e-6
+
+
 def test_split_precision_conformer_chains_against_the_per_op_path():
     """dtype "fp16x3": the Conformer block's row-local chains fused (afx_conformer_fused.hip, S3 form: pair-form weights
     streamed through LDS, the fp32 rows split into hi / lo halves in registers, three matrix-core passes per k-step) against

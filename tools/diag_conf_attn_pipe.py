@@ -32,3 +32,25 @@ for B, N in ((64, 200), (16, 200), (8, 120)):
     e1.record()
     torch.cuda.synchronize()
     print(f"B {B:3d} N {N:3d}: {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us per launch; checksum {out.double().sum().item():.10e} / {o.double().sum().item():.10e}", flush=True)
+    # split precision: the fp32 VALU kernel against the hi / lo MFMA kernel (dtype "fp16x3")
+    rel32 = pack_linear("fp32", rel, 64)
+    o32 = torch.empty(B * N, 144, dtype=torch.float32, device="cuda")
+
+    def run_valu():
+        check(call_on(q, lib().afx_k_conf_attn, DTYPES["fp32"], ptr(q), q.stride(0), ptr(kv), kv.stride(0), ptr(rel), 512, B, N, 4, 36, ptr(o32), 144))
+
+    def run_split():
+        check(call_on(q, lib().afx_k_conf_attn_mfma, DTYPES["fp16x3"], ptr(q), q.stride(0), ptr(kv), kv.stride(0), ptr(rel32), 512, B, N, 4, 36, ptr(o32), 144))
+    for name, fn in (("fp32 VALU kernel", run_valu), ("split-precision MFMA kernel", run_split)):
+        try:
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(30):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            print(f"      {name:28s}: {e0.elapsed_time(e1) / 30 * 1e3:7.1f} us per launch; checksum {o32.double().sum().item():.10e}", flush=True)
+        except Exception as exc:
+            print(f"      {name}: {str(exc)[:100]}")
