@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64 * NW) void conf_attn_split_kernel(const float* _
     const int q0 = qt * 16;
     int qrow = q0 + ql;
     qrow = qrow < N ? qrow : N - 1;
-    // Q fragments (scaled, hi / lo): k-slot (g, j) of step ks <-> head dim 32 ks + 8 g + j
+    // Q fragments (hi / lo): k-slot (g, j) of step ks <-> head dim 32 ks + 8 g + j
     V8 qh[2], qlo[2];
     {
       const float* qp = q + ((long)b * Nrow + qrow) * ldq + h * DH;
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64 * NW) void conf_attn_split_kernel(const float* _
         for (int half = 0; half < 2; ++half) {
           const int d = ks * 32 + g * 8 + half * 4;
           t[half] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (d < DH) t[half] = *(const f32x4*)(qp + d) * scale;
+          if (d < DH) t[half] = *(const f32x4*)(qp + d);  // (unscaled: 1 / sqrt(dh) is applied to the fp32 products below)
         }
         split8(t[0], t[1], qh[ks], qlo[ks]);
       }
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(64 * NW) void conf_attn_split_kernel(const float* _
           r2[u] = FP16::mfma(eh, qh[ks], r2[u]);
         }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) *(f32x4*)(rw + ql * CA_RS + (rp + u) * 16 + g * 4) = r2[u];
+      for (int u = 0; u < 2; ++u) *(f32x4*)(rw + ql * CA_RS + (rp + u) * 16 + g * 4) = r2[u] * scale;
     }
     // S^T tiles: s[kt][c] = S1[q0+ql][16kt + 4g + c]; one key tile's four fragments ahead of the MFMAs
     f32x4 s[CA_NKT];
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(64 * NW) void conf_attn_split_kernel(const float* _
         const int key = kt * 16 + g * 4 + c;
         int rl = ql + (N - 1) - key;
         rl = rl < 0 ? 0 : rl;
-        const float v = key < N ? s[kt][c] + rw[ql * CA_RS + rl] : -1e30f;
+        const float v = key < N ? fmaf(s[kt][c], scale, rw[ql * CA_RS + rl]) : -1e30f;
         s[kt][c] = v;
         mx = fmaxf(mx, v);
       }
@@ -667,6 +667,12 @@ __global__ __launch_bounds__(64 * NW) void conf_attn_split_kernel(const float* _
         const int d = nt * 16 + g * 4;
         if (d < DH) *(f32x4*)(out + ((long)b * Nrow + qi) * ldo + h * DH + d) = o[nt] * rinv;
       }
+#ifdef SHAW_DBG  // diagnostics: the row's maximum logit and softmax denominator in head dims 0 / 1 (tools/diag_shaw_split_err.py)
+      if (g == 0) {
+        out[((long)b * Nrow + qi) * ldo + h * DH + 0] = mx;
+        out[((long)b * Nrow + qi) * ldo + h * DH + 1] = sum;
+      }
+#endif
     }
   }
 }

@@ -1,1 +1,1 @@
-const char afx_build_id_str[] = "037c91e27bb3";
+const char afx_build_id_str[] = "9b1572c5ee51";
