@@ -38,6 +38,15 @@ victims = [
     ("Shaw attention on the matrix cores (B 64, N 200, 4 x 36)", lambda: K.conf_attn_mfma("fp16", cq, ckv, crel, 64, 200, 4, 36)),
     ("Conformer head: fused row chains + attention + depthwise conv (B 16)", lambda: eng.head(feats)),
 ]
+# the split-precision forms of the same units (fp32 rows in / out)
+qkv32 = rnd(16 * 199, 3072)
+eng3 = engine.Engine("conformer", n_layers=1, dtype="fp16x3", conf_blocks=2)
+eng3.load_state_dict(sd)
+victims += [
+    ("fp16x3: transformer attention (B 16, T 199)", lambda: K.mhsa("fp16x3", qkv32, 16, 199, 16)),
+    ("fp16x3: Shaw attention on the matrix cores (B 64, N 200)", lambda: K.conf_attn_mfma("fp16x3", cq, ckv, crel, 64, 200, 4, 36)),
+    ("fp16x3: Conformer head, fused split-precision chains (B 16)", lambda: eng3.head(feats)),
+]
 side = torch.cuda.Stream()
 
 
