@@ -298,7 +298,7 @@ def test_packed_math_matrix_core_kernels_are_exact_beside_vendor_gemms():
     chains keep their packed fp32 epilogue / softmax math.  They run it beside MFMAs by construction; this puts them beside the
     neighbours that moved 45-57 of 60 launches of the packed VALU conv0 kernel -- the vendor library's 2048^3 fp16 / bf16 GEMMs on a
     second stream -- and compares every output with the first one, bit for bit (tools/diag_pk_units.py is the long form:
-    profiles/r04_pk_units_beside_vendor_gemm.txt, 0 of 40 in 30 cases)."""
+    profiles/r04_pk_units_beside_vendor_gemm.txt, 0 of 40 in 45 cases)."""
     from afx import engine, kernels as K, synth
     g = torch.Generator(device="cuda").manual_seed(3)
 
