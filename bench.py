@@ -28,8 +28,9 @@ Besides the contract fields the JSON line carries
                   within 1e-3 on EVERY utterance, EER unchanged to 2 d.p." holds whatever the checkpoint's top-k gaps
                   (DESIGN.md section 5): its rate, its own parity sample and its roofline against 2.5 PF / 3.  Carried by
                   the headline and by config3;
-  issue_probe  -- both ways of issuing a step (one stream / back-end on a side stream under the next trunk) timed over the
-                  warm-up count before the timed region; the faster one is what the timed region runs (`issue`);
+  issue_probe  -- the three ways of issuing a step (one stream / the back-end on a side stream under the next trunk / whole forwards
+                  of consecutive steps on alternating streams) timed over the warm-up count before the timed region; the fastest
+                  one is what the timed region runs (`issue`);
   config3      -- (default workload only) BASELINE configs[2] / [3] beside the headline: the
                   XLS-R-24 + AASIST teacher at batch 16 per GPU timed the same way (same
                   warm-up, K steps, barriers, max over ranks), so that the driver's N = 1
@@ -290,6 +291,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8, help="utterances timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="back-end on the trunk's stream (no head / trunk overlap across steps)")
     ap.add_argument("--force-overlap", action="store_true", help="issue the two-stream form without the probe (diagnostics: tools/diag_queue_cliff.sh)")
+    ap.add_argument("--force-lanes", action="store_true", help="issue the two-lanes form (whole forwards on alternating streams) without the probe")
     ap.add_argument("--no-config3", action="store_true", help="skip the teacher (BASELINE configs[2]/[3]) side measurement")
     ap.add_argument("--allow-parity-miss", action="store_true", help="report, do not fail, when the parity sample misses 1e-3")
     args = ap.parse_args()
@@ -317,21 +319,26 @@ def main():
 
     from afx.dist import all_gather_scores
 
-    def make_step(w, overlapped):
+    def make_step(w, form):
         """One step = one forward of the hot path over the resident batch (+ the RCCL score all-gather when N > 1).
         overlapped: issued the way the scoring loop issues it (afx.harness.produce_evaluation_file) -- the back-end of step i
         (Conformer head / AASIST graph head) on the engine's side stream under the trunk of step i+1, scores read after the
         last step; every step completes inside the timed region (the current stream joins the side stream, behind the last
         collective, before the closing event and synchronize)."""
         idx = torch.arange(rank * w["B"], (rank + 1) * w["B"], dtype=torch.int32, device="cuda")
+        # form: "one_stream" | "two_stream" (the back-end of step i beside the trunk of step i+1) | "two_lanes" (whole forwards of
+        # consecutive steps on alternating streams: Engine.forward_lanes)
+        overlapped = form != "one_stream"
+        if overlapped:
+            w["eng"].set_issue("lanes" if form == "two_lanes" else "overlap")
 
         def step():
             if not overlapped:
                 scores = w["eng"].forward(w["wave"])[:, 1]
                 return all_gather_scores(idx, scores, world) if use_dist else (idx, scores)
             scores = w["eng"].forward_overlapped(w["wave"])[:, 1]
-            if use_dist:  # the collective follows the head on ITS stream: the next trunk does not wait for it
-                with torch.cuda.stream(w["eng"]._side):
+            if use_dist:  # the collective follows the logits on THEIR stream: the next trunk does not wait for it
+                with torch.cuda.stream(w["eng"].last_stream):
                     out = all_gather_scores(idx, scores, world)
                 w["eng"].mark_side()  # join() then covers the collective too
                 return out
@@ -348,28 +355,31 @@ def main():
         the bench does not assume: both forms are timed over the warm-up count right here, max over ranks, and the faster
         one is what the timed region issues.  Returns (overlapped, probe)."""
         if args.no_overlap:
-            return False, None
+            return "one_stream", None
         if args.force_overlap:
-            return True, None
+            return "two_stream", None
+        if args.force_lanes:
+            return "two_lanes", None
         if not w["eng"].overlap_is_bit_stable:  # (a combination whose two-stream form does not reproduce the one-stream bits: engine.py)
-            return False, {"issued": "one_stream", "note": "the two-stream step is disabled for this engine: it was measured not to "
-                           "reproduce the one-stream bits (Engine.overlap_is_bit_stable, DESIGN.md section 7)"}
+            return "one_stream", {"issued": "one_stream", "note": "the two-stream step is disabled for this engine: it was measured not to "
+                                  "reproduce the one-stream bits (Engine.overlap_is_bit_stable, DESIGN.md section 7)"}
         n = max(args.warmup, 3)
         ms = {}
-        for name, ov in (("two_stream", True), ("one_stream", False)):
-            st, jn = make_step(w, ov)
+        for name in ("two_lanes", "two_stream", "one_stream"):
+            st, jn = make_step(w, name)
             el, _, _ = time_steps(st, n, 2, use_dist, dist, join=jn)
             ms[name] = el / n * 1e3
-        ov = ms["two_stream"] <= ms["one_stream"]
-        return ov, {"steps_each": n, "one_stream_ms_per_step": round(ms["one_stream"], 3), "two_stream_ms_per_step": round(ms["two_stream"], 3),
-                    "issued": "two_stream" if ov else "one_stream"}
+        form = min(("one_stream", "two_stream", "two_lanes"), key=lambda k: ms[k])  # (ties go to the simpler form)
+        return form, {"steps_each": n, "one_stream_ms_per_step": round(ms["one_stream"], 3), "two_stream_ms_per_step": round(ms["two_stream"], 3),
+                      "two_lanes_ms_per_step": round(ms["two_lanes"], 3), "issued": form}
 
-    ISSUE = {True: "back-end of step i on a side stream under the trunk of step i+1 (the scoring loop's form)", False: "one stream"}
+    ISSUE = {"two_stream": "back-end of step i on a side stream under the trunk of step i+1 (the scoring loop's form)", "one_stream": "one stream",
+             "two_lanes": "two steps in flight: whole forwards of consecutive steps on alternating streams (the scoring loop's form)"}
 
     def measure(w, workload, dtype):
         """Warm-up, K timed steps (barriers, max over ranks), then the instrumented roofline pass: the fields every
         timed configuration of this file carries."""
-        ov, probe = pick_issue(w)
+        ov, probe = pick_issue(w)  # (the form's name)
         st, jn = make_step(w, ov)
         el, dms, out = time_steps(st, args.steps, args.warmup, use_dist, dist, join=jn)
         if use_dist:

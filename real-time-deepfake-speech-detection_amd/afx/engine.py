@@ -167,6 +167,8 @@ class Engine:
             return self.forward(wave)
         if not self.overlap_is_bit_stable:
             return self.forward(wave)
+        if getattr(self, "_issue", None) == "lanes":  # (``overlap_pays`` / the caller chose the other two-stream form)
+            return self.forward_lanes(wave)
         x = self._wave(wave)
         B, L = x.shape
         l = lib()
@@ -200,7 +202,74 @@ class Engine:
             slot["head_done"] = torch.cuda.Event()
             slot["head_done"].record(self._side)
             self._last_head = slot["head_done"]
+            self._last_stream = self._side
         return out
+
+    def forward_lanes(self, wave):
+        """The other way of keeping two batches in flight (round 4, late): WHOLE forwards of consecutive calls on alternating streams --
+        torch's current stream and the engine's side stream, a workspace each -- instead of one batch's back-end beside the next
+        batch's trunk.  The teacher's small-M products fill 200 of the 256 CUs and its LayerNorms / attention far fewer; a second
+        batch's kernels take what is free: 4.50 -> 3.94 ms per batch of 16 (4 059 utt/s), in fp16x3 8.24 -> 7.64 (2 093); the
+        student 4.88 -> 4.65 (tools/diag_two_lanes.py).  Same kernels on the same data, each batch on one stream: the one-stream bits.
+        A call on the side stream waits for what the current stream holds at that moment (its input is ready; the previous call's
+        forward there has then ended, which is when the next current-stream forward starts: the two lanes stay busy together).
+        Logits of a side-lane call must not be read on the current stream before ``join()``."""
+        if self._taps:
+            return self.forward(wave)
+        x = self._wave(wave)
+        B, L = x.shape
+        l = lib()
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            if getattr(self, "_side", None) is None:
+                self._side = side_stream(self.device)
+                self._ov = [dict(ws=None, head_done=None), dict(ws=None, head_done=None)]
+                self._ov_i = 0
+            if getattr(self, "_ln", None) is None:
+                self._ln = [dict(ws=None, done=None), dict(ws=None, done=None)]
+                self._ln_i = 0
+            k = self._ln_i
+            self._ln_i ^= 1
+            slot = self._ln[k]
+            nbytes = l.afx_workspace_bytes(self._h, B, L)
+            if slot["ws"] is None or slot["ws"].numel() < nbytes:
+                if slot["done"] is not None:
+                    slot["done"].synchronize()
+                slot["ws"] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                if k == 1:
+                    slot["ws"].record_stream(self._side)
+            ws = slot["ws"]
+            out = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+            if k == 0:
+                check(l.afx_forward(self._h, ptr(x), B, L, ptr(out), ptr(ws), ws.numel(), C.c_void_p(cur.cuda_stream)))
+                self._last_stream = cur
+            else:
+                ready = torch.cuda.Event()
+                ready.record(cur)
+                self._side.wait_event(ready)
+                x.record_stream(self._side)
+                out.record_stream(self._side)
+                check(l.afx_forward(self._h, ptr(x), B, L, ptr(out), ptr(ws), ws.numel(), C.c_void_p(self._side.cuda_stream)))
+                slot["done"] = torch.cuda.Event()
+                slot["done"].record(self._side)
+                self._last_head = slot["done"]
+                self._last_stream = self._side
+        return out
+
+    def set_issue(self, form):
+        """Which two-stream form ``forward_overlapped`` issues: "overlap" (the back-end beside the next trunk) or "lanes" (whole
+        forwards on alternating streams).  ``overlap_pays`` sets it from a timing; bench.py sets it for each form it probes."""
+        if form not in ("overlap", "lanes"):
+            raise ValueError("issue form: 'overlap' or 'lanes'")
+        self.join()
+        self._issue = form
+
+    @property
+    def last_stream(self):
+        """The stream the logits of the last ``forward_overlapped`` / ``forward_lanes`` call are produced on (a caller that queues work
+        of its own behind them -- bench.py's score all-gather -- puts it there and calls ``mark_side()``)."""
+        st = getattr(self, "_last_stream", None)
+        return st if st is not None else getattr(self, "_side", None)
 
     @property
     def overlap_is_bit_stable(self):
@@ -243,17 +312,23 @@ class Engine:
                     e1.record(torch.cuda.current_stream(dev))
                 torch.cuda.synchronize(dev)
                 return e0.elapsed_time(e1)
-            two, one = run(self.forward_overlapped), run(self.forward)
-            self._overlap_probe = {"one_stream_ms": one / steps, "two_stream_ms": two / steps}
-            self._overlap_pays = two <= one
+            self._issue = "overlap"
+            two = run(self.forward_overlapped)
+            lanes = run(self.forward_lanes) if self.overlap_is_bit_stable and not self._taps else float("inf")
+            one = run(self.forward)
+            self._overlap_probe = {"one_stream_ms": one / steps, "two_stream_ms": two / steps, "two_lanes_ms": lanes / steps}
+            # which two-stream form ``forward_overlapped`` issues from now on, and whether either beats one stream
+            self._issue = "lanes" if lanes < two else "overlap"
+            self._overlap_pays = min(two, lanes) <= one
         return self._overlap_pays
 
     def mark_side(self):
         """The caller put work of its own on the side stream behind the last back-end (bench.py: the RCCL score all-gather
         of a step): ``join()`` waits for it too from now on."""
-        if getattr(self, "_side", None) is not None:
+        st = self.last_stream
+        if st is not None:
             ev = torch.cuda.Event()
-            ev.record(self._side)
+            ev.record(st)
             self._last_head = ev
 
     def check_finite(self):

@@ -177,10 +177,14 @@ def produce_evaluation_file(dataset, model, device, save_path, batch_size, num_w
     names, chunks = [], []
     # the back-end of a batch (Conformer head: +5 %, AASIST graph head: +5.7 %) runs on a side stream under the next batch's
     # trunk: the scores are only read after the last batch, so nothing waits for a head inside the loop
-    overlapped = _may_overlap(model)
+    overlapped, asked = _may_overlap(model), False
     with torch.no_grad():
         loader = ((utt_id, batch_x) for utt_id, batch_x, _label in _loader(dataset, batch_size, num_workers))
         for utt_id, x in prefetch_to_device(loader, device):
+            if overlapped and not asked:
+                # which way of keeping two batches in flight is the fastest HERE (one stream / back-end beside the next trunk / whole
+                # forwards on alternating streams) is timed once on the first batch (Engine.overlap_pays); same bits either way
+                overlapped, asked = bool(model.overlap_pays(x)) if hasattr(model, "overlap_pays") else overlapped, True
             out = model.forward_overlapped(x) if overlapped else model(x)
             chunks.append(out[:, 1])  # bonafide score (main.py:211-212)
             names.extend(utt_id)

@@ -236,12 +236,18 @@ def test_scoring_loop_overlaps_the_backend_with_the_next_trunk_bit_for_bit(tmp_p
     waves = [synth.waveforms(b, 16000, batch_idx=700 + i).cuda() for i, b in enumerate([5, 5, 5, 3, 7, 5, 1] * 3)]
     assert eng.overlap_is_bit_stable
     want = [eng.forward(w).clone() for w in waves]
-    for _ in range(2):  # twice: the second pass starts from slots that have a pending head
-        got = [eng.forward_overlapped(w) for w in waves]
-        eng.join()
-        for g, w_ in zip(got, want):
-            assert torch.equal(g, w_)
+    for form in ("overlap", "lanes", "overlap"):  # the back-end beside the next trunk; whole forwards on alternating streams; and back
+        eng.set_issue(form)
+        for _ in range(2):  # twice: the second pass starts from slots that have a pending head / a busy side lane
+            got = [eng.forward_overlapped(w) for w in waves]
+            eng.join()
+            for g, w_ in zip(got, want):
+                assert torch.equal(g, w_), form
     assert torch.equal(eng.forward(waves[0]), want[0])  # and the one-stream call is unaffected afterwards
+    assert eng.overlap_pays(waves[0]) in (True, False) and eng._issue in ("overlap", "lanes")  # the probe picks a form and says which
+    got = [eng.forward_overlapped(w) for w in waves[:5]]
+    eng.join()
+    assert all(torch.equal(g, w_) for g, w_ in zip(got, want))
     eng.check_finite()
 
     class Toy(torch.utils.data.Dataset):
