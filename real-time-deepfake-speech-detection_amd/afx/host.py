@@ -227,15 +227,18 @@ class AfxModule(nn.Module):
         return eng.ssl_ragged(clips) if self.afx_arch == "ssl" else eng.forward_ragged(clips)
 
     def forward_overlapped(self, x):
-        """``self(x)`` with the back-end of this batch on a side stream under the NEXT call's trunk (Engine.forward_overlapped);
-        the logits must not be read on the current stream before ``join_overlapped()``.  For scoring loops that collect
-        scores and read them once at the end (afx.harness.produce_evaluation_file); ``self(x)`` itself stays one stream."""
+        """``self(x)`` issued so that two batches are in flight: either the back-end of this batch on a side stream under the NEXT
+        call's trunk, or whole forwards of consecutive calls on alternating streams (Engine.forward_overlapped / forward_lanes;
+        ``overlap_pays`` times both against one stream and picks); the logits must not be read on the current stream before
+        ``join_overlapped()``.  For scoring loops that collect scores and read them once at the end
+        (afx.harness.produce_evaluation_file); ``self(x)`` itself stays one stream.  Same bits in every form."""
         x = x.squeeze(-1) if x.ndim == 3 else x
         self._afx_check(x)
         return self._afx_engine().forward_overlapped(x)
 
     def overlap_pays(self, x):
-        """Engine.overlap_pays on this model's engine: whether the two-stream form is the faster one in this process."""
+        """Engine.overlap_pays on this model's engine: times one stream and the two two-stream forms on ``x``, makes
+        ``forward_overlapped`` issue the faster two-stream form, and says whether that beats one stream in this process."""
         x = x.squeeze(-1) if x.ndim == 3 else x
         self._afx_check(x)
         return self._afx_engine().overlap_pays(x)
